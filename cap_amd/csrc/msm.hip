@@ -1,0 +1,346 @@
+// K3-K6: Pippenger MSM over BN254 G1 with fixed-base window precomputation.
+// Design notes in msm.hpp.  Kernel sequence for one (batched) MSM:
+//   msm_digits_hist   K3  scalar -> signed base-2^c digits, histogram rank per (digit, bucket)
+//   msm_scan          K4  exclusive scan of bucket counts
+//   msm_scatter       K4  counting-sort scatter of table indices into bucket lists
+//   msm_accumulate    K5  S lanes per bucket: mixed adds of gathered 64 B points, shuffle merge
+//   msm_reduce_bits   K6  T_b = sum of buckets whose weight has bit b set (log-depth trees)
+//   msm_reduce_final  K6  sum_b 2^b T_b  ->  one Jacobian point per MSM
+#include "msm.hpp"
+#include "launch.hpp"
+
+#include <stdio.h>
+#include <stdlib.h>
+
+namespace cap {
+
+namespace {
+
+constexpr uint32_t kSkip = 0xFFFFFFFFu;
+constexpr int kThreads = 256;
+constexpr uint32_t kReduceChunk = 1024;  // buckets per msm_reduce_bits workgroup
+
+__device__ __forceinline__ fe shfl_down_fe(const fe& a, int d) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = __shfl_down(a.v[i], d);
+  return r;
+}
+__device__ __forceinline__ g1_xyzz shfl_down_pt(const g1_xyzz& a, int d) {
+  g1_xyzz r;
+  r.x = shfl_down_fe(a.x, d);
+  r.y = shfl_down_fe(a.y, d);
+  r.zz = shfl_down_fe(a.zz, d);
+  r.zzz = shfl_down_fe(a.zzz, d);
+  return r;
+}
+
+// ---- setup: window multiples of every base -----------------------------------------------
+__global__ __launch_bounds__(kThreads) void msm_precompute_kernel(g1_affine* __restrict__ ext,
+                                                                  const g1_affine* __restrict__ bases, size_t n,
+                                                                  uint32_t c, uint32_t windows) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  g1_affine p = bases[i];
+  ext[i] = p;
+  g1_xyzz acc = G1::from_affine(p);
+  for (uint32_t w = 1; w < windows; w++) {
+    for (uint32_t k = 0; k < c; k++) acc = G1::dbl(acc);
+    ext[(size_t)w * n + i] = G1::to_affine(acc);
+  }
+}
+
+// ---- K3: digits + histogram ----------------------------------------------------------------
+// one thread per (batch, i).  keys[(b*W + w)*n + i] = (bucket | sign << 31) or kSkip.
+__global__ __launch_bounds__(kThreads) void msm_digits_hist(const fe* __restrict__ scalars, size_t scalar_stride,
+                                                            size_t n, uint32_t batch, int montgomery, uint32_t c,
+                                                            uint32_t windows, uint32_t* __restrict__ counts,
+                                                            uint32_t* __restrict__ keys,
+                                                            uint32_t* __restrict__ ranks) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n * batch) return;
+  uint32_t b = (uint32_t)(t / n);
+  size_t i = t - (size_t)b * n;
+  fe k = scalars[(size_t)b * scalar_stride + i];
+  if (montgomery) k = Fr::from_mont(k);
+  const uint32_t half = 1u << (c - 1);
+  const uint32_t mask = (1u << c) - 1;
+  uint32_t carry = 0;
+  for (uint32_t w = 0; w < windows; w++) {
+    uint32_t bit = w * c;
+    uint32_t limb = bit >> 5, off = bit & 31;
+    uint32_t v = 0;
+    if (limb < 8) {
+      uint64_t two = (uint64_t)k.v[limb] | (limb + 1 < 8 ? ((uint64_t)k.v[limb + 1] << 32) : 0);
+      v = (uint32_t)(two >> off) & mask;
+    }
+    v += carry;
+    uint32_t neg = 0;
+    if (v > half) {
+      v = (1u << c) - v;
+      neg = 1;
+      carry = 1;
+    } else {
+      carry = 0;
+    }
+    size_t e = ((size_t)b * windows + w) * n + i;
+    if (v == 0) {
+      keys[e] = kSkip;
+    } else {
+      uint32_t bucket = v - 1;
+      uint32_t r = atomicAdd(&counts[(size_t)b * half + bucket], 1u);
+      keys[e] = bucket | (neg << 31);
+      ranks[e] = r;
+    }
+  }
+}
+
+// ---- K4: exclusive scan, one workgroup per batch entry ------------------------------------------
+__global__ __launch_bounds__(1024) void msm_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
+                                                 uint32_t nb) {
+  __shared__ uint32_t sh[1024];
+  __shared__ uint32_t carry_s;
+  const uint32_t* cnt = counts + (size_t)blockIdx.x * nb;
+  uint32_t* off = offsets + (size_t)blockIdx.x * nb;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nb; base += 1024) {
+    uint32_t idx = base + threadIdx.x;
+    uint32_t v = idx < nb ? cnt[idx] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+      uint32_t add = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += add;
+      __syncthreads();
+    }
+    uint32_t incl = sh[threadIdx.x];
+    uint32_t carry = carry_s;
+    if (idx < nb) off[idx] = carry + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + incl;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(kThreads) void msm_scatter(const uint32_t* __restrict__ keys,
+                                                        const uint32_t* __restrict__ ranks,
+                                                        const uint32_t* __restrict__ offsets, size_t n,
+                                                        uint32_t batch, uint32_t c, uint32_t windows,
+                                                        size_t srs_n, size_t base_offset,
+                                                        uint32_t* __restrict__ sorted) {
+  size_t per = (size_t)windows * n;
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= per * batch) return;
+  uint32_t key = keys[e];
+  if (key == kSkip) return;
+  uint32_t b = (uint32_t)(e / per);
+  size_t rem = e - (size_t)b * per;
+  uint32_t w = (uint32_t)(rem / n);
+  size_t i = rem - (size_t)w * n;
+  const uint32_t half = 1u << (c - 1);
+  uint32_t bucket = key & 0x7FFFFFFFu;
+  uint32_t pos = offsets[(size_t)b * half + bucket] + ranks[e];
+  uint32_t tidx = (uint32_t)((size_t)w * srs_n + base_offset + i);
+  sorted[(size_t)b * per + pos] = tidx | (key & 0x80000000u);
+}
+
+// ---- K5: bucket accumulation --------------------------------------------------------------------
+// thread -> (global bucket, slice); slices of one bucket are adjacent lanes of one wavefront.
+__global__ __launch_bounds__(kThreads) void msm_accumulate(const g1_affine* __restrict__ ext,
+                                                           const uint32_t* __restrict__ sorted,
+                                                           const uint32_t* __restrict__ counts,
+                                                           const uint32_t* __restrict__ offsets, size_t per,
+                                                           uint32_t half, uint32_t total_buckets, uint32_t log_s,
+                                                           g1_xyzz* __restrict__ buckets) {
+  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t gb = (uint32_t)(t >> log_s);
+  uint32_t slice = (uint32_t)t & ((1u << log_s) - 1);
+  const uint32_t S = 1u << log_s;
+  g1_xyzz acc = G1::inf();
+  bool live = gb < total_buckets;
+  if (live) {
+    uint32_t b = gb / half;
+    uint32_t cnt = counts[gb];
+    const uint32_t* lst = sorted + (size_t)b * per + offsets[gb];
+    for (uint32_t e = slice; e < cnt; e += S) {
+      uint32_t v = lst[e];
+      g1_affine p = ext[v & 0x7FFFFFFFu];
+      if (v >> 31) p.y = Fq::neg(p.y);
+      acc = G1::add_mixed(acc, p);
+    }
+  }
+  for (uint32_t d = S >> 1; d >= 1; d >>= 1) {
+    g1_xyzz o = shfl_down_pt(acc, (int)d);
+    if (slice < d) acc = G1::add(acc, o);
+  }
+  if (live && slice == 0) buckets[gb] = acc;
+}
+
+// ---- K6a: bit-plane sums ---------------------------------------------------------------------------
+// grid (chunks, c, batch).  partial[(b*c + bit)*chunks + chunk] = sum of buckets j in the chunk with
+// bit `bit` of (j+1) set.
+__global__ __launch_bounds__(kThreads) void msm_reduce_bits(const g1_xyzz* __restrict__ buckets, uint32_t half,
+                                                            uint32_t c, uint32_t chunks,
+                                                            g1_xyzz* __restrict__ partial) {
+  __shared__ g1_xyzz sh[kThreads / 64];
+  const uint32_t chunk = blockIdx.x, bit = blockIdx.y, b = blockIdx.z;
+  const g1_xyzz* bk = buckets + (size_t)b * half;
+  g1_xyzz acc = G1::inf();
+  for (uint32_t q = 0; q < kReduceChunk / kThreads; q++) {
+    uint32_t j = chunk * kReduceChunk + q * kThreads + threadIdx.x;
+    if (j < half && (((j + 1) >> bit) & 1)) acc = G1::add(acc, bk[j]);
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    g1_xyzz o = shfl_down_pt(acc, d);
+    acc = G1::add(acc, o);
+  }
+  uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (lane == 0) sh[wave] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    g1_xyzz r = sh[0];
+    for (uint32_t w = 1; w < kThreads / 64; w++) r = G1::add(r, sh[w]);
+    partial[((size_t)b * c + bit) * chunks + chunk] = r;
+  }
+}
+
+// ---- K6b: sum_b 2^b T_b ------------------------------------------------------------------------------
+// one wavefront per batch entry; lane = bit.
+__global__ __launch_bounds__(64) void msm_reduce_final(const g1_xyzz* __restrict__ partial, uint32_t c,
+                                                       uint32_t chunks, g1_jac* __restrict__ out) {
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  g1_xyzz acc = G1::inf();
+  if (lane < c) {
+    const g1_xyzz* p = partial + ((size_t)b * c + lane) * chunks;
+    for (uint32_t k = 0; k < chunks; k++) acc = G1::add(acc, p[k]);
+  }
+  for (uint32_t k = 0; k + 1 < c; k++) {
+    g1_xyzz d = G1::dbl(acc);
+    if (lane > k && lane < c) acc = d;
+  }
+  for (int d = 16; d >= 1; d >>= 1) {
+    g1_xyzz o = shfl_down_pt(acc, d);
+    acc = G1::add(acc, o);
+  }
+  if (lane == 0) out[b] = G1::to_jac(acc);
+}
+
+size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+struct WsLayout {
+  size_t counts, offsets, keys, ranks, sorted, buckets, partial, total;
+};
+WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t batch) {
+  WsLayout L{};
+  size_t half = (size_t)1 << (c - 1);
+  size_t per = (size_t)windows * n;
+  size_t chunks = (half + kReduceChunk - 1) / kReduceChunk;
+  size_t o = 0;
+  L.counts = o;  o = align_up(o + sizeof(uint32_t) * half * batch, 256);
+  L.offsets = o; o = align_up(o + sizeof(uint32_t) * half * batch, 256);
+  L.keys = o;    o = align_up(o + sizeof(uint32_t) * per * batch, 256);
+  L.ranks = o;   o = align_up(o + sizeof(uint32_t) * per * batch, 256);
+  L.sorted = o;  o = align_up(o + sizeof(uint32_t) * per * batch, 256);
+  L.buckets = o; o = align_up(o + sizeof(g1_xyzz) * half * batch, 256);
+  L.partial = o; o = align_up(o + sizeof(g1_xyzz) * c * chunks * batch, 256);
+  L.total = o;
+  return L;
+}
+
+}  // namespace
+
+uint32_t msm_choose_window(size_t n) {
+  const char* env = getenv("CAPGPU_MSM_C");
+  if (env) {
+    int v = atoi(env);
+    if (v >= 2 && v <= 24) return (uint32_t)v;
+  }
+  if (n <= ((size_t)1 << 10)) return 9;
+  if (n <= ((size_t)1 << 18)) return 13;
+  if (n <= ((size_t)1 << 22)) return 15;
+  return 17;
+}
+
+uint32_t msm_num_windows(uint32_t c) {
+  uint32_t w = (256 + c - 1) / c;
+  if (256 % c == 0) w += 1;  // room for the final signed-digit carry
+  return w;
+}
+
+int msm_precompute(MsmBases* out, const g1_affine* d_bases, size_t n, uint32_t c, hipStream_t stream) {
+  out->n = n;
+  out->c = c;
+  out->windows = msm_num_windows(c);
+  if ((size_t)out->windows * n >= ((size_t)1 << 31)) return (int)hipErrorInvalidValue;
+  hipError_t e = hipMalloc(&out->ext, sizeof(g1_affine) * n * out->windows);
+  if (e != hipSuccess) return (int)e;
+  if (n == 0) return 0;
+  size_t blocks = (n + kThreads - 1) / kThreads;
+  launch("msm_precompute_kernel", msm_precompute_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, out->ext, d_bases, n, c,
+                     out->windows);
+  return (int)hipGetLastError();
+}
+
+void msm_free_bases(MsmBases* b) {
+  if (b->ext) hipFree(b->ext);
+  b->ext = nullptr;
+  b->n = 0;
+}
+
+size_t msm_workspace_bytes(const MsmBases& bases, size_t n, uint32_t batch) {
+  return ws_layout(bases.c, bases.windows, n, batch).total;
+}
+
+int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t scalar_stride, size_t n,
+            uint32_t batch, int montgomery, g1_jac* d_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (batch == 0) return 0;
+  if (offset + n > bases.n) return (int)hipErrorInvalidValue;
+  const uint32_t c = bases.c, W = bases.windows;
+  const uint32_t half = 1u << (c - 1);
+  WsLayout L = ws_layout(c, W, n, batch);
+  if (ws_bytes < L.total) return (int)hipErrorInvalidValue;
+  char* base = reinterpret_cast<char*>(ws);
+  uint32_t* counts = reinterpret_cast<uint32_t*>(base + L.counts);
+  uint32_t* offsets = reinterpret_cast<uint32_t*>(base + L.offsets);
+  uint32_t* keys = reinterpret_cast<uint32_t*>(base + L.keys);
+  uint32_t* ranks = reinterpret_cast<uint32_t*>(base + L.ranks);
+  uint32_t* sorted = reinterpret_cast<uint32_t*>(base + L.sorted);
+  g1_xyzz* buckets = reinterpret_cast<g1_xyzz*>(base + L.buckets);
+  g1_xyzz* partial = reinterpret_cast<g1_xyzz*>(base + L.partial);
+  const size_t per = (size_t)W * n;
+  const uint32_t chunks = (half + kReduceChunk - 1) / kReduceChunk;
+  const uint32_t total_buckets = half * batch;
+
+  hipError_t e = hipMemsetAsync(counts, 0, sizeof(uint32_t) * (size_t)half * batch, stream);
+  if (e != hipSuccess) return (int)e;
+  if (n > 0) {
+    size_t nt = n * batch;
+    launch("msm_digits_hist", msm_digits_hist, dim3((unsigned)((nt + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
+                       d_scalars, scalar_stride, n, batch, montgomery, c, W, counts, keys, ranks);
+  }
+  launch("msm_scan", msm_scan, dim3(batch), dim3(1024), 0, stream, counts, offsets, half);
+  if (n > 0) {
+    size_t ne = per * batch;
+    launch("msm_scatter", msm_scatter, dim3((unsigned)((ne + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, keys,
+                       ranks, offsets, n, batch, c, W, bases.n, offset, sorted);
+  }
+  // lanes per bucket: aim at >= ~128K lanes in flight, never more than the mean list length / 2
+  uint32_t log_s = 0;
+  {
+    size_t mean = total_buckets ? (per * batch) / total_buckets : 0;
+    while (log_s < 6 && ((size_t)total_buckets << log_s) < (size_t)131072 && ((size_t)2 << log_s) <= mean) log_s++;
+  }
+  {
+    size_t nt = (size_t)total_buckets << log_s;
+    launch("msm_accumulate", msm_accumulate, dim3((unsigned)((nt + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
+                       bases.ext, sorted, counts, offsets, per, half, total_buckets, log_s, buckets);
+  }
+  launch("msm_reduce_bits", msm_reduce_bits, dim3(chunks, c, batch), dim3(kThreads), 0, stream, buckets, half, c, chunks,
+                     partial);
+  launch("msm_reduce_final", msm_reduce_final, dim3(batch), dim3(64), 0, stream, partial, c, chunks, d_out);
+  return (int)hipGetLastError();
+}
+
+}  // namespace cap

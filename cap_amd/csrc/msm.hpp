@@ -1,0 +1,55 @@
+// Pippenger multi-scalar multiplication over BN254 G1 for gfx950 (K3-K6 of
+// SURVEY.md §8a).
+//
+// Replaces ark-ec 0.3.0 `VariableBaseMSM::multi_scalar_mul(&[G1Affine],
+// &[BigInteger256])` (Cargo.lock:103-105), reached from KZG10::commit under
+// src/proof/transfer.rs:181-186 / src/proof/mint.rs:113 / src/proof/freeze.rs:151.
+//
+// MI355X-first design (not the reference's per-window rayon loop):
+//  * the commit key is fixed for the life of a proving key, and 288 GB of HBM is
+//    there to be used: at upload every base P_i is expanded to its W window
+//    multiples 2^(c*w) * P_i (affine, 64 B each).  All W windows of a scalar then
+//    fall into ONE bucket set, so the per-window running-sum reductions and the
+//    254 sequential doublings of the window combine (ruinous on a 64-lane SIMT
+//    machine where one field multiplication is ~1 us of latency) disappear;
+//  * signed digits halve the bucket count (2^(c-1) buckets);
+//  * bucket lists are built with a counting sort (histogram ranks + scan +
+//    scatter), accumulated with S lanes per bucket and merged by wavefront
+//    shuffles, and the weighted bucket sum  sum_j j*B_j  is evaluated bit-plane
+//    wise so that its dependency depth is logarithmic.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "curve.hpp"
+
+namespace cap {
+
+struct MsmBases {
+  size_t n = 0;              // number of caller bases
+  uint32_t c = 0;            // window bits
+  uint32_t windows = 0;      // W
+  g1_affine* ext = nullptr;  // [W][n]: ext[w*n + i] = 2^(c*w) * P_i  (w = 0 is the input itself)
+};
+
+struct MsmWorkspace {
+  void* buf = nullptr;
+  size_t bytes = 0;
+};
+
+uint32_t msm_choose_window(size_t n);
+uint32_t msm_num_windows(uint32_t c);
+
+// Expand `n` affine bases (device, Montgomery, (0,0) = infinity) into the window table.
+int msm_precompute(MsmBases* out, const g1_affine* d_bases, size_t n, uint32_t c, hipStream_t stream);
+void msm_free_bases(MsmBases* b);
+
+size_t msm_workspace_bytes(const MsmBases& bases, size_t n, uint32_t batch);
+
+// out[b] = sum_{i<n} scalars[b*scalar_stride + i] * bases[offset + i]   for b < batch.
+// d_scalars: device, 32 B each; montgomery != 0 -> converted to canonical integers first.
+// d_out: device, batch x g1_jac (Montgomery).  ws must hold msm_workspace_bytes().
+int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t scalar_stride, size_t n,
+            uint32_t batch, int montgomery, g1_jac* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
+
+}  // namespace cap

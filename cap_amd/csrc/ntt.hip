@@ -1,0 +1,321 @@
+// K2: multi-pass NTT over BN254 Fr with LDS-staged sub-transforms (see ntt.hpp).
+//
+// Decomposition (decimation in frequency, mixed radix 2^a x 2^b [x 2^c]):
+//   n = N1*N2*N3, input index i = (i1*N2 + i2)*N3 + i3, output index k = k1 + N1*k2 + N1*N2*k3.
+//   "column" passes transform one digit at a stride, multiply by the inter-pass
+//   twiddle omega_M^(col*k) and store in place (to scratch); the final "row"
+//   pass transforms contiguous rows and stores digit-reversed, C adjacent k1 per
+//   workgroup so the scattered stores are C*32 B contiguous.
+// Each workgroup stages a tile of len x C elements in LDS (<= 64 KiB) and runs
+// log2(len) radix-2 stages there; HBM sees one read + one write of the array per
+// pass.  All arithmetic is 254-bit modular integer work (no MFMA).
+#include "ntt.hpp"
+#include "launch.hpp"
+
+#include <vector>
+
+namespace cap {
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr uint32_t kMaxTileLog = 11;  // 2048 elements * 32 B = 64 KiB of LDS
+
+struct PassParams {
+  const fe* in;
+  fe* out;
+  size_t batch_stride;       // elements between consecutive arrays of the batch
+  const fe* tw_small;        // omega_len^i, i < len/2
+  const fe* tw_full;         // omega_N^e, e < N (col pass twiddles); may be null for row pass
+  const fe* pre_scale;       // indexed by global input index, or null
+  const fe* post_scale;      // indexed by global output index, or null
+  fe post_scalar;            // used when use_post_scalar
+  uint32_t use_post_scalar;
+  uint32_t log_n;
+  uint32_t log_len;          // sub-transform size
+  uint32_t log_c;            // tile width
+  uint32_t log_m;            // col pass: segment size
+  uint32_t log_n1, log_n2;   // row pass: digit sizes of the leading digits
+};
+
+__device__ __forceinline__ uint32_t bitrev32(uint32_t x, uint32_t bits) { return __brev(x) >> (32 - bits); }
+
+// radix-2 DIF stages on sh[len][C]; result in bit-reversed row order
+__device__ __forceinline__ void lds_ntt(fe* sh, const fe* __restrict__ tw_small, uint32_t log_len, uint32_t log_c) {
+  const uint32_t half_tile = 1u << (log_len + log_c - 1);
+  const uint32_t cmask = (1u << log_c) - 1;
+  for (int s = (int)log_len - 1; s >= 0; s--) {
+    const uint32_t half = 1u << s;
+    for (uint32_t b = threadIdx.x; b < half_tile; b += kThreads) {
+      uint32_t c = b & cmask;
+      uint32_t bb = b >> log_c;
+      uint32_t pos = bb & (half - 1);
+      uint32_t j = ((bb >> s) << (s + 1)) + pos;
+      uint32_t i0 = (j << log_c) + c, i1 = ((j + half) << log_c) + c;
+      fe u = sh[i0], v = sh[i1];
+      sh[i0] = Fr::add(u, v);
+      fe d = Fr::sub(u, v);
+      uint32_t e = pos << (log_len - 1 - s);
+      sh[i1] = e ? Fr::mul(d, tw_small[e]) : d;
+    }
+    __syncthreads();
+  }
+}
+
+// column pass: len rows at stride S = M/len, C adjacent columns per tile
+__global__ __launch_bounds__(kThreads) void ntt_col_pass(PassParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  fe* sh = reinterpret_cast<fe*>(smem);
+  const uint32_t log_s = p.log_m - p.log_len;           // columns per segment (log)
+  const uint32_t tiles_per_seg_log = log_s - p.log_c;
+  const uint32_t t = blockIdx.x;
+  const size_t seg = t >> tiles_per_seg_log;
+  const uint32_t col0 = (t & ((1u << tiles_per_seg_log) - 1)) << p.log_c;
+  const fe* in = p.in + (size_t)blockIdx.y * p.batch_stride;
+  fe* out = p.out + (size_t)blockIdx.y * p.batch_stride;
+  const size_t base = (seg << p.log_m) + col0;
+  const uint32_t tile = 1u << (p.log_len + p.log_c);
+  const uint32_t cmask = (1u << p.log_c) - 1;
+  for (uint32_t e = threadIdx.x; e < tile; e += kThreads) {
+    uint32_t c = e & cmask, j = e >> p.log_c;
+    size_t g = base + ((size_t)j << log_s) + c;
+    fe v = in[g];
+    if (p.pre_scale) v = Fr::mul(v, p.pre_scale[g]);
+    sh[e] = v;
+  }
+  __syncthreads();
+  lds_ntt(sh, p.tw_small, p.log_len, p.log_c);
+  const uint32_t tw_shift = p.log_n - p.log_m;  // omega_M^x = omega_N^(x << tw_shift)
+  for (uint32_t e = threadIdx.x; e < tile; e += kThreads) {
+    uint32_t c = e & cmask, k = e >> p.log_c;
+    fe v = sh[(bitrev32(k, p.log_len) << p.log_c) + c];
+    size_t ex = ((size_t)(col0 + c) * k) << tw_shift;
+    if (ex) v = Fr::mul(v, p.tw_full[ex]);
+    out[base + ((size_t)k << log_s) + c] = v;
+  }
+}
+
+// row pass: contiguous rows of len elements; C rows with adjacent k1 per tile; digit-reversed store
+__global__ __launch_bounds__(kThreads) void ntt_row_pass(PassParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  fe* sh = reinterpret_cast<fe*>(smem);
+  const uint32_t t = blockIdx.x;
+  const uint32_t k2 = t & ((1u << p.log_n2) - 1);
+  const uint32_t r0 = (t >> p.log_n2) << p.log_c;
+  const fe* in = p.in + (size_t)blockIdx.y * p.batch_stride;
+  fe* out = p.out + (size_t)blockIdx.y * p.batch_stride;
+  const uint32_t tile = 1u << (p.log_len + p.log_c);
+  const uint32_t lmask = (1u << p.log_len) - 1;
+  const uint32_t cmask = (1u << p.log_c) - 1;
+  for (uint32_t e = threadIdx.x; e < tile; e += kThreads) {
+    uint32_t j = e & lmask, c = e >> p.log_len;
+    size_t g = ((((size_t)(r0 + c) << p.log_n2) + k2) << p.log_len) + j;
+    fe v = in[g];
+    if (p.pre_scale) v = Fr::mul(v, p.pre_scale[g]);
+    sh[(j << p.log_c) + c] = v;
+  }
+  __syncthreads();
+  lds_ntt(sh, p.tw_small, p.log_len, p.log_c);
+  for (uint32_t e = threadIdx.x; e < tile; e += kThreads) {
+    uint32_t c = e & cmask, k = e >> p.log_c;
+    fe v = sh[(bitrev32(k, p.log_len) << p.log_c) + c];
+    size_t g = (size_t)(r0 + c) + ((size_t)k2 << p.log_n1) + ((size_t)k << (p.log_n1 + p.log_n2));
+    if (p.post_scale) v = Fr::mul(v, p.post_scale[g]);
+    else if (p.use_post_scalar) v = Fr::mul(v, p.post_scalar);
+    out[g] = v;
+  }
+}
+
+// out[e] = base^e * scale for e < n; pw[b] = base^(2^b)
+__global__ void powers_table(fe* out, size_t n, const fe* __restrict__ pw, fe scale, int has_scale) {
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  fe r = has_scale ? scale : Fr::one();
+  bool started = has_scale;
+  for (int b = 0; (e >> b) != 0; b++) {
+    if ((e >> b) & 1) {
+      r = started ? Fr::mul(r, pw[b]) : pw[b];
+      started = true;
+    }
+  }
+  out[e] = r;
+}
+
+fe host_root_of_unity(uint32_t log_n) {
+  // omega_28 = 5^((r-1)/2^28), canonical little-endian limbs
+  fe w;
+  const uint32_t root28[8] = {0x725b19f0u, 0x9bd61b6eu, 0x41112ed4u, 0x402d111eu,
+                              0x8ef62abcu, 0x00e0a7ebu, 0xa58a7e85u, 0x2a3c09f0u};
+  for (int i = 0; i < 8; i++) w.v[i] = root28[i];
+  w = Fr::to_mont(w);
+  for (uint32_t i = log_n; i < 28; i++) w = Fr::sqr(w);
+  return w;
+}
+
+fe host_from_u64(uint64_t v) {
+  fe t = Fr::zero();
+  t.v[0] = (uint32_t)v;
+  t.v[1] = (uint32_t)(v >> 32);
+  return Fr::to_mont(t);
+}
+
+int build_powers(fe* d_out, size_t n, fe base, const fe* scale, hipStream_t stream) {
+  std::vector<fe> pw(40);
+  fe x = base;
+  for (int b = 0; b < 40; b++) {
+    pw[b] = x;
+    x = Fr::sqr(x);
+  }
+  fe* d_pw = nullptr;
+  hipError_t e = hipMalloc(&d_pw, sizeof(fe) * pw.size());
+  if (e != hipSuccess) return (int)e;
+  e = hipMemcpyAsync(d_pw, pw.data(), sizeof(fe) * pw.size(), hipMemcpyHostToDevice, stream);
+  if (e != hipSuccess) return (int)e;
+  fe sc = scale ? *scale : Fr::one();
+  size_t blocks = (n + 255) / 256;
+  launch("powers_table", powers_table, dim3((unsigned)blocks), dim3(256), 0, stream, d_out, n, d_pw, sc, scale ? 1 : 0);
+  e = hipStreamSynchronize(stream);
+  hipFree(d_pw);
+  return (int)e;
+}
+
+}  // namespace
+
+int ntt_build_small_tables(NttSmallTables* t, hipStream_t stream) {
+  for (int s = 1; s <= kMaxLogTile; s++) {
+    size_t n = (size_t)1 << (s - 1);
+    hipError_t e = hipMalloc(&t->fwd[s], sizeof(fe) * n);
+    if (e != hipSuccess) return (int)e;
+    e = hipMalloc(&t->inv[s], sizeof(fe) * n);
+    if (e != hipSuccess) return (int)e;
+    fe w = host_root_of_unity(s);
+    int rc = build_powers(t->fwd[s], n, w, nullptr, stream);
+    if (rc) return rc;
+    rc = build_powers(t->inv[s], n, Fr::inv(w), nullptr, stream);
+    if (rc) return rc;
+  }
+  return 0;
+}
+
+void ntt_free_small_tables(NttSmallTables* t) {
+  for (int s = 0; s <= kMaxLogTile; s++) {
+    if (t->fwd[s]) hipFree(t->fwd[s]);
+    if (t->inv[s]) hipFree(t->inv[s]);
+    t->fwd[s] = t->inv[s] = nullptr;
+  }
+}
+
+int ntt_build_domain(NttDomain* d, uint32_t log_n, hipStream_t stream) {
+  d->log_n = log_n;
+  size_t n = (size_t)1 << log_n;
+  hipError_t e;
+  if ((e = hipMalloc(&d->tw_fwd, sizeof(fe) * n)) != hipSuccess) return (int)e;
+  if ((e = hipMalloc(&d->tw_inv, sizeof(fe) * n)) != hipSuccess) return (int)e;
+  if ((e = hipMalloc(&d->coset_fwd, sizeof(fe) * n)) != hipSuccess) return (int)e;
+  if ((e = hipMalloc(&d->coset_inv, sizeof(fe) * n)) != hipSuccess) return (int)e;
+  fe w = host_root_of_unity(log_n);
+  fe g = host_from_u64(5);
+  d->n_inv = Fr::inv(host_from_u64((uint64_t)n));
+  int rc;
+  if ((rc = build_powers(d->tw_fwd, n, w, nullptr, stream))) return rc;
+  if ((rc = build_powers(d->tw_inv, n, Fr::inv(w), nullptr, stream))) return rc;
+  if ((rc = build_powers(d->coset_fwd, n, g, nullptr, stream))) return rc;
+  if ((rc = build_powers(d->coset_inv, n, Fr::inv(g), &d->n_inv, stream))) return rc;
+  return 0;
+}
+
+void ntt_free_domain(NttDomain* d) {
+  if (d->tw_fwd) hipFree(d->tw_fwd);
+  if (d->tw_inv) hipFree(d->tw_inv);
+  if (d->coset_fwd) hipFree(d->coset_fwd);
+  if (d->coset_inv) hipFree(d->coset_inv);
+  d->tw_fwd = d->tw_inv = d->coset_fwd = d->coset_inv = nullptr;
+}
+
+int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scratch, size_t stride_elems,
+            uint32_t count, int dir, int coset, hipStream_t stream) {
+  const uint32_t log_n = dom.log_n;
+  if (count == 0) return 0;
+  if (log_n == 0) {
+    // n = 1: forward is the identity (5^0 = 1); inverse multiplies by 1^-1 = 1.
+    return 0;
+  }
+  // digit split
+  uint32_t lg[3] = {0, 0, 0};
+  int passes;
+  if (log_n <= 10) {
+    passes = 1;
+    lg[2] = log_n;
+  } else if (log_n <= 20) {
+    passes = 2;
+    lg[0] = (log_n + 1) / 2;
+    lg[2] = log_n / 2;
+  } else {
+    passes = 3;
+    lg[0] = (log_n + 2) / 3;
+    lg[1] = (log_n - lg[0] + 1) / 2;
+    lg[2] = log_n - lg[0] - lg[1];
+  }
+  if (lg[0] > 10 || lg[1] > 10 || lg[2] > 10) return (int)hipErrorInvalidValue;
+  const fe* const* tws = dir ? small.inv : small.fwd;
+  const fe* tw_full = dir ? dom.tw_inv : dom.tw_fwd;
+
+  PassParams p{};
+  p.batch_stride = stride_elems;
+  p.log_n = log_n;
+  p.tw_full = tw_full;
+  p.use_post_scalar = 0;
+
+  const fe* pre = (!dir && coset) ? dom.coset_fwd : nullptr;
+  bool first = true;
+  const fe* cur_in = data;
+  // column passes
+  uint32_t log_m = log_n;
+  for (int d = 0; d < passes - 1; d++) {
+    uint32_t log_len = lg[d];
+    uint32_t log_s = log_m - log_len;
+    uint32_t log_c = kMaxTileLog - log_len;
+    if (log_c > log_s) log_c = log_s;
+    if (log_c > 4) log_c = 4;
+    p.in = cur_in;
+    p.out = scratch;
+    p.tw_small = tws[log_len];
+    p.pre_scale = first ? pre : nullptr;
+    p.post_scale = nullptr;
+    p.log_len = log_len;
+    p.log_c = log_c;
+    p.log_m = log_m;
+    size_t tiles = (size_t)1 << (log_n - log_len - log_c);
+    size_t lds = sizeof(fe) << (log_len + log_c);
+    launch("ntt_col_pass", ntt_col_pass, dim3((unsigned)tiles, count), dim3(kThreads), lds, stream, p);
+    cur_in = scratch;
+    first = false;
+    log_m -= log_len;
+  }
+  // row pass
+  {
+    uint32_t log_len = lg[2];
+    uint32_t log_n1 = passes >= 2 ? lg[0] : 0;
+    uint32_t log_n2 = passes == 3 ? lg[1] : 0;
+    uint32_t log_c = kMaxTileLog - log_len;
+    if (log_c > log_n1) log_c = log_n1;
+    if (log_c > 4) log_c = 4;
+    p.in = cur_in;
+    p.out = data;
+    p.tw_small = tws[log_len];
+    p.pre_scale = first ? pre : nullptr;
+    p.post_scale = (dir && coset) ? dom.coset_inv : nullptr;
+    p.use_post_scalar = (dir && !coset) ? 1 : 0;
+    p.post_scalar = dom.n_inv;
+    p.log_len = log_len;
+    p.log_c = log_c;
+    p.log_n1 = log_n1;
+    p.log_n2 = log_n2;
+    size_t tiles = (size_t)1 << (log_n - log_len - log_c);
+    size_t lds = sizeof(fe) << (log_len + log_c);
+    launch("ntt_row_pass", ntt_row_pass, dim3((unsigned)tiles, count), dim3(kThreads), lds, stream, p);
+  }
+  return (int)hipGetLastError();
+}
+
+}  // namespace cap

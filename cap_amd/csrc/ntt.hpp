@@ -1,0 +1,45 @@
+// Radix-2 NTT / iNTT over BN254 Fr for gfx950 (K2 of SURVEY.md §8a).
+//
+// Replaces ark-poly 0.3.0 `Radix2EvaluationDomain::{fft,ifft,coset_fft,
+// coset_ifft}_in_place` (Cargo.lock:194-196) reached from
+// src/proof/transfer.rs:181-186 (PlonkKzgSnark::prove).  Semantics kept:
+// natural order in / out, omega_n = omega_28^(2^(28-log n)), coset generator 5,
+// inverse includes n^-1, coset inverse scales by 5^-i afterwards.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "field.hpp"
+
+namespace cap {
+
+// Per-domain-size device tables (built once per log_n, kept resident).
+struct NttDomain {
+  uint32_t log_n = 0;
+  fe* tw_fwd = nullptr;     // omega_n^e,  e in [0, n)
+  fe* tw_inv = nullptr;     // omega_n^-e, e in [0, n)
+  fe* coset_fwd = nullptr;  // 5^i,           i in [0, n)
+  fe* coset_inv = nullptr;  // n^-1 * 5^-i,   i in [0, n)
+  fe n_inv;                 // n^-1 (Montgomery)
+};
+
+// Small-size twiddles shared by every domain: small_fwd[s] -> omega_{2^s}^i, i < 2^(s-1), s <= kMaxLogTile
+constexpr int kMaxLogTile = 11;
+struct NttSmallTables {
+  fe* fwd[kMaxLogTile + 1] = {nullptr};
+  fe* inv[kMaxLogTile + 1] = {nullptr};
+};
+
+// Host-side table construction (runs tiny setup kernels).  Returns hipError_t as int.
+int ntt_build_small_tables(NttSmallTables* t, hipStream_t stream);
+int ntt_build_domain(NttDomain* d, uint32_t log_n, hipStream_t stream);
+void ntt_free_domain(NttDomain* d);
+void ntt_free_small_tables(NttSmallTables* t);
+
+// In-place (from the caller's view) batched transform of `count` arrays of 2^log_n
+// elements, array b at data + b * stride_elems.  `scratch` must hold count * 2^log_n
+// elements.  dir: 0 forward, 1 inverse.  coset: 0/1.
+int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scratch, size_t stride_elems,
+            uint32_t count, int dir, int coset, hipStream_t stream);
+
+}  // namespace cap

@@ -1,0 +1,236 @@
+"""ctypes binding of include/capgpu.h (the drop-in C ABI).  No compute happens in Python."""
+from __future__ import annotations
+
+import ctypes
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libcapgpu.so")
+_lib = None
+
+NUM_WIRE_TYPES = 5
+NUM_SELECTORS = 13
+
+CAPGPU_OK = 0
+ERR_NAMES = {
+    -1: "CAPGPU_ERR_INVALID_ARG", -2: "CAPGPU_ERR_NO_DEVICE", -3: "CAPGPU_ERR_HIP", -4: "CAPGPU_ERR_BAD_HANDLE",
+    -5: "CAPGPU_ERR_OOM", -6: "CAPGPU_ERR_NOT_INITIALISED", -7: "CAPGPU_ERR_PROOF",
+}
+
+u64p = ctypes.POINTER(ctypes.c_uint64)
+
+
+class CapGpuError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"{ERR_NAMES.get(code, code)}: {msg}")
+        self.code = code
+
+
+class Proof(ctypes.Structure):
+    """capgpu_proof (include/capgpu.h) == jf_plonk::proof_system::structs::Proof fields."""
+    _fields_ = [
+        ("wires_poly_comms", (ctypes.c_uint64 * 8) * NUM_WIRE_TYPES),
+        ("prod_perm_poly_comm", ctypes.c_uint64 * 8),
+        ("split_quot_poly_comms", (ctypes.c_uint64 * 8) * NUM_WIRE_TYPES),
+        ("opening_proof", ctypes.c_uint64 * 8),
+        ("shifted_opening_proof", ctypes.c_uint64 * 8),
+        ("wires_evals", (ctypes.c_uint64 * 4) * NUM_WIRE_TYPES),
+        ("wire_sigma_evals", (ctypes.c_uint64 * 4) * (NUM_WIRE_TYPES - 1)),
+        ("perm_next_eval", ctypes.c_uint64 * 4),
+    ]
+
+
+class VerifyingKey(ctypes.Structure):
+    _fields_ = [
+        ("domain_size", ctypes.c_uint64),
+        ("num_inputs", ctypes.c_uint64),
+        ("k", (ctypes.c_uint64 * 4) * NUM_WIRE_TYPES),
+        ("selector_comms", (ctypes.c_uint64 * 8) * NUM_SELECTORS),
+        ("sigma_comms", (ctypes.c_uint64 * 8) * NUM_WIRE_TYPES),
+    ]
+
+
+def lib_path() -> str:
+    return _SO
+
+
+def load():
+    """Load libcapgpu.so.  Fails loudly when it has not been built (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(_SO):
+        raise CapGpuError(-2, f"{_SO} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                              "(make -C cap_amd/csrc).  There is no CPU fallback.")
+    L = ctypes.CDLL(_SO)
+    L.capgpu_last_error.restype = ctypes.c_char_p
+    L.capgpu_version.restype = ctypes.c_char_p
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != CAPGPU_OK:
+        raise CapGpuError(rc, load().capgpu_last_error().decode())
+
+
+def init(device: int | None = None):
+    L = load()
+    if device is None:
+        device = int(os.environ.get("LOCAL_RANK", "0"))
+    ids = (ctypes.c_int * 1)(device)
+    check(L.capgpu_init(ids, 1))
+    return L
+
+
+def _p(a: np.ndarray):
+    assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
+    return a.ctypes.data_as(u64p)
+
+
+# ---- device buffers ----------------------------------------------------------------------------
+class DevBuf:
+    def __init__(self, nbytes: int):
+        self.ptr = ctypes.c_void_p()
+        self.nbytes = nbytes
+        check(load().capgpu_malloc(ctypes.byref(self.ptr), ctypes.c_size_t(nbytes)))
+
+    @classmethod
+    def from_numpy(cls, a: np.ndarray) -> "DevBuf":
+        a = np.ascontiguousarray(a)
+        b = cls(a.nbytes)
+        check(load().capgpu_memcpy_h2d(b.ptr, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(a.nbytes)))
+        return b
+
+    def to_numpy(self, dtype=np.uint64, count: int | None = None, offset_bytes: int = 0) -> np.ndarray:
+        itemsize = np.dtype(dtype).itemsize
+        n = (self.nbytes - offset_bytes) // itemsize if count is None else count
+        out = np.empty(n, dtype=dtype)
+        src = ctypes.c_void_p(self.ptr.value + offset_bytes)
+        check(load().capgpu_memcpy_d2h(out.ctypes.data_as(ctypes.c_void_p), src, ctypes.c_size_t(n * itemsize)))
+        return out
+
+    def free(self):
+        if self.ptr and self.ptr.value:
+            check(load().capgpu_free(self.ptr))
+            self.ptr = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def sync():
+    check(load().capgpu_sync())
+
+
+# ---- SRS -----------------------------------------------------------------------------------------
+def srs_upload(bases: np.ndarray, montgomery: bool = True) -> int:
+    """bases: (n, 8) uint64 packed affine points."""
+    bases = np.ascontiguousarray(bases, dtype=np.uint64).reshape(-1, 8)
+    h = ctypes.c_uint64()
+    check(load().capgpu_srs_upload(bases.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(bases.shape[0]),
+                                   ctypes.c_size_t(64), int(montgomery), ctypes.byref(h)))
+    return h.value
+
+
+def _limbs(v: int):
+    return (ctypes.c_uint64 * 4)(*[(v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(4)])
+
+
+def srs_generate(tau: int, n: int) -> int:
+    h = ctypes.c_uint64()
+    check(load().capgpu_srs_generate(_limbs(tau), ctypes.c_size_t(n), ctypes.byref(h)))
+    return h.value
+
+
+def srs_generate_affine_seq(a: int, b: int, n: int) -> int:
+    h = ctypes.c_uint64()
+    check(load().capgpu_srs_generate_affine_seq(_limbs(a), _limbs(b), ctypes.c_size_t(n), ctypes.byref(h)))
+    return h.value
+
+
+def srs_download(handle: int, offset: int, n: int) -> np.ndarray:
+    out = np.empty((n, 8), dtype=np.uint64)
+    check(load().capgpu_srs_download(ctypes.c_uint64(handle), ctypes.c_size_t(offset), ctypes.c_size_t(n),
+                                     out.ctypes.data_as(ctypes.c_void_p)))
+    return out
+
+
+def srs_free(handle: int):
+    check(load().capgpu_srs_free(ctypes.c_uint64(handle)))
+
+
+# ---- MSM -----------------------------------------------------------------------------------------
+def msm_g1(handle: int, scalars: np.ndarray, offset: int = 0) -> np.ndarray:
+    """scalars (n,4) canonical -> Jacobian (12,) Montgomery."""
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros(12, dtype=np.uint64)
+    check(load().capgpu_msm_g1(ctypes.c_uint64(handle), ctypes.c_size_t(offset), _p(scalars),
+                               ctypes.c_size_t(scalars.shape[0]), _p(out)))
+    return out
+
+
+def msm_g1_batch(handle: int, scalar_list, offsets=None) -> np.ndarray:
+    cnt = len(scalar_list)
+    arrs = [np.ascontiguousarray(s, dtype=np.uint64).reshape(-1, 4) for s in scalar_list]
+    offs = (ctypes.c_size_t * cnt)(*([0] * cnt if offsets is None else offsets))
+    ns = (ctypes.c_size_t * cnt)(*[a.shape[0] for a in arrs])
+    ptrs = (u64p * cnt)(*[_p(a) for a in arrs])
+    out = np.zeros((cnt, 12), dtype=np.uint64)
+    check(load().capgpu_msm_g1_batch(ctypes.c_uint64(handle), offs, ptrs, ns, cnt, _p(out)))
+    return out
+
+
+def msm_g1_dev(handle: int, d_scalars: DevBuf, n: int, count: int = 1, stride: int | None = None,
+               montgomery: bool = False, offset: int = 0, d_out: DevBuf | None = None) -> DevBuf:
+    if d_out is None:
+        d_out = DevBuf(96 * count)
+    check(load().capgpu_msm_g1_dev(ctypes.c_uint64(handle), ctypes.c_size_t(offset), d_scalars.ptr,
+                                   ctypes.c_size_t(n if stride is None else stride), ctypes.c_size_t(n), count,
+                                   int(montgomery), d_out.ptr))
+    return d_out
+
+
+# ---- NTT -----------------------------------------------------------------------------------------
+def ntt_fr(data: np.ndarray, log_n: int, inverse: bool = False, coset: bool = False) -> np.ndarray:
+    data = np.ascontiguousarray(data, dtype=np.uint64).copy()
+    assert data.size == 4 << log_n
+    check(load().capgpu_ntt_fr(_p(data), ctypes.c_uint32(log_n), int(inverse), int(coset)))
+    return data
+
+
+def ntt_fr_batch(arrays, log_n: int, inverse: bool = False, coset: bool = False):
+    arrs = [np.ascontiguousarray(a, dtype=np.uint64).copy() for a in arrays]
+    ptrs = (u64p * len(arrs))(*[_p(a) for a in arrs])
+    check(load().capgpu_ntt_fr_batch(ptrs, len(arrs), ctypes.c_uint32(log_n), int(inverse), int(coset)))
+    return arrs
+
+
+def ntt_fr_dev(d_data: DevBuf, log_n: int, count: int = 1, stride: int | None = None, inverse: bool = False,
+               coset: bool = False):
+    check(load().capgpu_ntt_fr_dev(d_data.ptr, ctypes.c_size_t((1 << log_n) if stride is None else stride), count,
+                                   ctypes.c_uint32(log_n), int(inverse), int(coset)))
+
+
+# ---- instrumentation ---------------------------------------------------------------------------
+def profile_enable(on: bool):
+    check(load().capgpu_profile_enable(int(on)))
+
+
+def profile_reset():
+    check(load().capgpu_profile_reset())
+
+
+def profile_stats() -> dict:
+    buf = ctypes.create_string_buffer(1 << 16)
+    check(load().capgpu_profile_dump(buf, ctypes.c_size_t(len(buf))))
+    out = {}
+    for line in buf.value.decode().splitlines():
+        name, ms, cnt = line.split()
+        out[name] = (float(ms), int(cnt))
+    return out

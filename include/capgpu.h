@@ -1,0 +1,175 @@
+/* capgpu.h - C ABI of libcapgpu.so: the MI355X (gfx950) replacement for the two
+ * primitives that dominate CAP's PLONK prove() path, and for the prover that
+ * schedules them.
+ *
+ * This is the drop-in boundary.  The reference (jf-cap, Rust)
+ * has no FFI of its own; the seam is cut where its prover hands flat arrays to
+ * arkworks.  Every entry point names the reference interface it replaces:
+ *
+ *   capgpu_msm_g1*        ark_ec::msm::VariableBaseMSM::multi_scalar_mul      (ark-ec 0.3.0, Cargo.lock:103-105)
+ *                         via ark_poly_commit::kzg10::KZG10::commit           (Cargo.lock:208-210)
+ *   capgpu_ntt_fr*        ark_poly::Radix2EvaluationDomain::{fft,ifft,
+ *                         coset_fft,coset_ifft}_in_place                      (ark-poly 0.3.0, Cargo.lock:194-196)
+ *   capgpu_srs_*          jf_plonk UniversalSrs / CommitKey powers_of_g       (src/proof/mod.rs:59-69, 74-109)
+ *   capgpu_plonk_preprocess   PlonkKzgSnark::preprocess   (call sites src/proof/transfer.rs:133, mint.rs:76, freeze.rs:102)
+ *   capgpu_plonk_prove        PlonkKzgSnark::prove::<_,_,SolidityTranscript>
+ *                                                         (call sites src/proof/transfer.rs:181-186, mint.rs:113, freeze.rs:151)
+ *
+ * Conventions
+ *   - All integers little-endian.  Field element Fr / Fq = uint64_t[4] (arkworks
+ *     BigInteger256 limb order).  "Montgomery" = arkworks' in-memory Fp256 form
+ *     (value * 2^256 mod p).  Scalars handed to the MSM are canonical integers
+ *     (what `into_repr()` yields), exactly as arkworks' MSM takes them.
+ *   - G1 affine = x, y (Montgomery), 64 bytes; the point at infinity is (0, 0)
+ *     when no flag byte is present (see capgpu_srs_upload for arkworks' 72-byte
+ *     struct).  G1 Jacobian = X, Y, Z (Montgomery), 96 bytes, infinity Z = 0
+ *     (arkworks GroupProjective field order).
+ *   - Every function returns CAPGPU_OK (0) or a negative CAPGPU_ERR_* code; it
+ *     never aborts and never unwinds.  capgpu_last_error() gives a thread-local
+ *     message.  The Rust shim maps non-zero to PlonkError, which prove()
+ *     already maps to TxnApiError::FailedSnark (src/proof/transfer.rs:187).
+ *   - Host-pointer entry points copy in/out; the caller owns its buffers for the
+ *     duration of the call.  *_dev entry points take device pointers obtained
+ *     from capgpu_malloc and enqueue on the library stream (capgpu_sync waits).
+ *   - Thread safety: entry points may be called from any thread (rayon workers
+ *     in the reference, src/utils/params_builder.rs:194-226); calls serialise
+ *     on an internal lock per process (one process drives one GPU).
+ *   - There is no CPU fallback: without a usable gfx950 device capgpu_init
+ *     fails with CAPGPU_ERR_NO_DEVICE and every other call fails with
+ *     CAPGPU_ERR_NOT_INITIALISED.
+ */
+#ifndef CAPGPU_H
+#define CAPGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CAPGPU_OK 0
+#define CAPGPU_ERR_INVALID_ARG (-1)
+#define CAPGPU_ERR_NO_DEVICE (-2)
+#define CAPGPU_ERR_HIP (-3)
+#define CAPGPU_ERR_BAD_HANDLE (-4)
+#define CAPGPU_ERR_OOM (-5)
+#define CAPGPU_ERR_NOT_INITIALISED (-6)
+#define CAPGPU_ERR_PROOF (-7) /* prover-side failure: wrong quotient degree (unsatisfied circuit), bad sizes */
+
+#define CAPGPU_NUM_WIRE_TYPES 5
+#define CAPGPU_NUM_SELECTORS 13
+
+/* ---- lifecycle ------------------------------------------------------------------------- */
+/* Binds this process to one GPU (device_ids[0]; one process per GPU is the scaling model).
+ * Idempotent.  device_ids == NULL selects HIP device 0. */
+int capgpu_init(const int* device_ids, int n_devices);
+void capgpu_shutdown(void);
+const char* capgpu_last_error(void);
+const char* capgpu_version(void);
+/* name (<= 255 chars + NUL), compute units, HBM bytes of the bound device */
+int capgpu_device_info(char* name_out, int* cu_count_out, uint64_t* hbm_bytes_out);
+
+/* ---- device memory / stream (plumbing for callers that keep data resident) -------------- */
+int capgpu_malloc(void** dev_ptr_out, size_t bytes);
+int capgpu_free(void* dev_ptr);
+int capgpu_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes);
+int capgpu_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);
+int capgpu_sync(void);
+/* Run all subsequent work on the caller's hipStream_t (e.g. torch's current stream); NULL
+ * restores the library's own stream. */
+int capgpu_set_stream(void* hip_stream);
+
+/* ---- SRS / commit key: stays device-resident across proofs -------------------------------- */
+/* bases: n affine G1 points, stride_bytes apart (64 = packed x,y; 72 = arkworks GroupAffine with
+ * a trailing `infinity: bool` byte at offset 64).  coords_montgomery: 1 for arkworks memory.
+ * Expands every base into its window multiples on device (one-time cost). */
+int capgpu_srs_upload(const void* bases, size_t n, size_t stride_bytes, int coords_montgomery,
+                      uint64_t* handle_out);
+/* Synthetic SRS [tau^i] G, i < n, generated on device - the counterpart of
+ * universal_setup(max_degree, rng) (src/proof/mod.rs:59-69) for benches without the Aztec file.
+ * tau: canonical Fr integer. */
+int capgpu_srs_generate(const uint64_t tau[4], size_t n, uint64_t* handle_out);
+/* bases[i] = [a + i*b] G (canonical Fr integers) - synthetic bases for the 2^24 scaling config */
+int capgpu_srs_generate_affine_seq(const uint64_t a[4], const uint64_t b[4], size_t n, uint64_t* handle_out);
+int capgpu_srs_size(uint64_t handle, size_t* n_out);
+/* copies bases [offset, offset+n) back as packed 64-byte Montgomery affine points */
+int capgpu_srs_download(uint64_t handle, size_t offset, size_t n, void* out);
+int capgpu_srs_free(uint64_t handle);
+
+/* ---- MSM: replaces VariableBaseMSM::multi_scalar_mul ------------------------------------------ */
+/* out = sum_i scalars[i] * bases[offset + i];  scalars canonical 4 x u64; out Jacobian 96 B. */
+int capgpu_msm_g1(uint64_t srs_handle, size_t offset, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]);
+int capgpu_msm_g1_batch(uint64_t srs_handle, const size_t* offsets, const uint64_t* const* scalars,
+                        const size_t* ns, int count, uint64_t* out_xyz /* count*12 */);
+/* Device-resident form: d_scalars = count arrays of n scalars, scalar_stride elements apart;
+ * scalars_montgomery != 0 converts from Montgomery first (what a polynomial's coefficients are);
+ * d_out_xyz = count * 96 bytes on device. */
+int capgpu_msm_g1_dev(uint64_t srs_handle, size_t offset, const void* d_scalars, size_t scalar_stride, size_t n,
+                      int count, int scalars_montgomery, void* d_out_xyz);
+
+/* ---- NTT: replaces Radix2EvaluationDomain::{fft, ifft, coset_fft, coset_ifft}_in_place -------- */
+/* in place, natural order in/out, Montgomery Fr; dir: 0 forward, 1 inverse (includes n^-1);
+ * coset: 0/1 (generator 5: scale by 5^i before the forward transform / by 5^-i after the inverse). */
+int capgpu_ntt_fr(uint64_t* data, uint32_t log_n, int dir, int coset);
+int capgpu_ntt_fr_batch(uint64_t* const* data, int count, uint32_t log_n, int dir, int coset);
+int capgpu_ntt_fr_dev(void* d_data, size_t stride_elems, int count, uint32_t log_n, int dir, int coset);
+
+/* ---- PLONK (TurboPlonk, 5 wires, 13 selectors) ------------------------------------------------ */
+typedef struct capgpu_proof {
+  uint64_t wires_poly_comms[CAPGPU_NUM_WIRE_TYPES][8];      /* affine, Montgomery */
+  uint64_t prod_perm_poly_comm[8];
+  uint64_t split_quot_poly_comms[CAPGPU_NUM_WIRE_TYPES][8];
+  uint64_t opening_proof[8];
+  uint64_t shifted_opening_proof[8];
+  uint64_t wires_evals[CAPGPU_NUM_WIRE_TYPES][4];           /* Fr, Montgomery */
+  uint64_t wire_sigma_evals[CAPGPU_NUM_WIRE_TYPES - 1][4];
+  uint64_t perm_next_eval[4];
+} capgpu_proof;
+
+typedef struct capgpu_verifying_key {
+  uint64_t domain_size;
+  uint64_t num_inputs;
+  uint64_t k[CAPGPU_NUM_WIRE_TYPES][4];                     /* coset representatives, Montgomery */
+  uint64_t selector_comms[CAPGPU_NUM_SELECTORS][8];         /* q_lc x4, q_mul x2, q_hash x4, q_o, q_c, q_ecc */
+  uint64_t sigma_comms[CAPGPU_NUM_WIRE_TYPES][8];
+} capgpu_verifying_key;
+
+/* selectors: 13 columns of n Fr (Montgomery), column-major, gate order above; sigma_evals: 5 columns
+ * of n Fr = sigma_i(omega^j) (the extended permutation as field elements k_i' * omega^j').
+ * n must be a power of two, 2 <= n, n + 3 <= SRS size. */
+int capgpu_plonk_preprocess(uint64_t srs_handle, size_t n, size_t num_inputs, const uint64_t* selectors,
+                            const uint64_t* sigma_evals, uint64_t* pk_handle_out, capgpu_verifying_key* vk_out);
+int capgpu_plonk_free_key(uint64_t pk_handle);
+
+/* wires: 5 columns of n Fr (Montgomery), column-major (the finalised circuit's wire assignment);
+ * pub_inputs: num_inputs Fr (Montgomery); ext_msg: the caller's transcript init message
+ * (src/proof/transfer.rs:178-180) or NULL; blinders: 13 Fr (Montgomery) drawn by the caller's RNG in
+ * the order jf-plonk draws them: 2 per wire polynomial (constant, linear), then 3 for the
+ * permutation product polynomial. */
+int capgpu_plonk_prove(uint64_t pk_handle, const uint64_t* wires, const uint64_t* pub_inputs, size_t num_inputs,
+                       const uint8_t* ext_msg, size_t ext_msg_len, const uint64_t* blinders, capgpu_proof* proof_out);
+/* Same, `count` independent proofs under one key pipelined on the device; per-proof arrays are
+ * consecutive (wires: count * 5 * n, pub_inputs: count * num_inputs, blinders: count * 13). */
+int capgpu_plonk_prove_batch(uint64_t pk_handle, int count, const uint64_t* wires, const uint64_t* pub_inputs,
+                             size_t num_inputs, const uint8_t* ext_msg, size_t ext_msg_len,
+                             const uint64_t* blinders, capgpu_proof* proofs_out);
+/* Device-resident witness form used by the benchmark (inputs already in HBM). */
+int capgpu_plonk_prove_batch_dev(uint64_t pk_handle, int count, const void* d_wires, const uint64_t* pub_inputs,
+                                 size_t num_inputs, const uint8_t* ext_msg, size_t ext_msg_len,
+                                 const uint64_t* blinders, capgpu_proof* proofs_out);
+
+/* ---- instrumentation ------------------------------------------------------------------------------ */
+/* When enabled, every kernel launch is bracketed by HIP events on the launch stream and accumulated
+ * per kernel name (costs a few microseconds per launch; leave off for throughput runs). */
+int capgpu_profile_enable(int on);
+int capgpu_profile_reset(void);
+/* name == kernel name (e.g. "msm_accumulate"); total milliseconds and launch count since reset */
+int capgpu_profile_get(const char* name, double* total_ms_out, uint64_t* launches_out);
+/* writes up to cap bytes of "name total_ms launches\n" lines */
+int capgpu_profile_dump(char* buf, size_t cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CAPGPU_H */
