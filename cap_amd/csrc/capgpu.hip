@@ -392,7 +392,7 @@ int capgpu_msm_g1_dev(uint64_t srs_handle, size_t offset, const void* d_scalars,
   size_t need = msm_workspace_bytes(B, n, (uint32_t)count);
   int rc = scratch_reserve(c.msm_ws, need);
   if (rc) return rc;
-  rc = msm_run(B, offset, (const fe*)d_scalars, scalar_stride, n, (uint32_t)count, scalars_montgomery,
+  rc = msm_run(B, offset, (const fe*)d_scalars, scalar_stride, 1, 0, n, (uint32_t)count, scalars_montgomery,
                (g1_jac*)d_out_xyz, c.msm_ws.p, c.msm_ws.cap, c.stream);
   if (rc) return hip_fail((hipError_t)rc, "msm_run");
   return CAPGPU_OK;

@@ -52,7 +52,8 @@ __global__ __launch_bounds__(kThreads) void msm_precompute_kernel(g1_affine* __r
 
 // ---- K3: digits + histogram ----------------------------------------------------------------
 // one thread per (batch, i).  keys[(b*W + w)*n + i] = (bucket | sign << 31) or kSkip.
-__global__ __launch_bounds__(kThreads) void msm_digits_hist(const fe* __restrict__ scalars, size_t scalar_stride,
+__global__ __launch_bounds__(kThreads) void msm_digits_hist(const fe* __restrict__ scalars, size_t outer_stride,
+                                                            uint32_t inner, size_t inner_stride,
                                                             size_t n, uint32_t batch, int montgomery, uint32_t c,
                                                             uint32_t windows, uint32_t* __restrict__ counts,
                                                             uint32_t* __restrict__ keys,
@@ -61,7 +62,7 @@ __global__ __launch_bounds__(kThreads) void msm_digits_hist(const fe* __restrict
   if (t >= n * batch) return;
   uint32_t b = (uint32_t)(t / n);
   size_t i = t - (size_t)b * n;
-  fe k = scalars[(size_t)b * scalar_stride + i];
+  fe k = scalars[(size_t)(b / inner) * outer_stride + (size_t)(b % inner) * inner_stride + i];
   if (montgomery) k = Fr::from_mont(k);
   const uint32_t half = 1u << (c - 1);
   const uint32_t mask = (1u << c) - 1;
@@ -293,8 +294,10 @@ size_t msm_workspace_bytes(const MsmBases& bases, size_t n, uint32_t batch) {
   return ws_layout(bases.c, bases.windows, n, batch).total;
 }
 
-int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t scalar_stride, size_t n,
-            uint32_t batch, int montgomery, g1_jac* d_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t outer_stride, uint32_t inner,
+            size_t inner_stride, size_t n, uint32_t batch, int montgomery, g1_jac* d_out, void* ws, size_t ws_bytes,
+            hipStream_t stream) {
+  if (inner == 0) inner = 1;
   if (batch == 0) return 0;
   if (offset + n > bases.n) return (int)hipErrorInvalidValue;
   const uint32_t c = bases.c, W = bases.windows;
@@ -318,7 +321,7 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t sc
   if (n > 0) {
     size_t nt = n * batch;
     launch("msm_digits_hist", msm_digits_hist, dim3((unsigned)((nt + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
-                       d_scalars, scalar_stride, n, batch, montgomery, c, W, counts, keys, ranks);
+                       d_scalars, outer_stride, inner, inner_stride, n, batch, montgomery, c, W, counts, keys, ranks);
   }
   launch("msm_scan", msm_scan, dim3(batch), dim3(1024), 0, stream, counts, offsets, half);
   if (n > 0) {

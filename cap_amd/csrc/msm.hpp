@@ -46,10 +46,12 @@ void msm_free_bases(MsmBases* b);
 
 size_t msm_workspace_bytes(const MsmBases& bases, size_t n, uint32_t batch);
 
-// out[b] = sum_{i<n} scalars[b*scalar_stride + i] * bases[offset + i]   for b < batch.
+// out[b] = sum_{i<n} scalars_b[i] * bases[offset + i]   for b < batch, where
+// scalars_b = d_scalars + (b / inner) * outer_stride + (b % inner) * inner_stride   (elements).
 // d_scalars: device, 32 B each; montgomery != 0 -> converted to canonical integers first.
 // d_out: device, batch x g1_jac (Montgomery).  ws must hold msm_workspace_bytes().
-int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t scalar_stride, size_t n,
-            uint32_t batch, int montgomery, g1_jac* d_out, void* ws, size_t ws_bytes, hipStream_t stream);
+int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t outer_stride, uint32_t inner,
+            size_t inner_stride, size_t n, uint32_t batch, int montgomery, g1_jac* d_out, void* ws, size_t ws_bytes,
+            hipStream_t stream);
 
 }  // namespace cap

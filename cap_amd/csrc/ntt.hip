@@ -181,6 +181,8 @@ int build_powers(fe* d_out, size_t n, fe base, const fe* scale, hipStream_t stre
 
 }  // namespace
 
+fe ntt_root_of_unity(uint32_t log_n) { return host_root_of_unity(log_n); }
+
 int ntt_build_small_tables(NttSmallTables* t, hipStream_t stream) {
   for (int s = 1; s <= kMaxLogTile; s++) {
     size_t n = (size_t)1 << (s - 1);

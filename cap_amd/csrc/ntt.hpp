@@ -36,6 +36,9 @@ int ntt_build_domain(NttDomain* d, uint32_t log_n, hipStream_t stream);
 void ntt_free_domain(NttDomain* d);
 void ntt_free_small_tables(NttSmallTables* t);
 
+// omega_{2^log_n} in Montgomery form (host)
+fe ntt_root_of_unity(uint32_t log_n);
+
 // In-place (from the caller's view) batched transform of `count` arrays of 2^log_n
 // elements, array b at data + b * stride_elems.  `scratch` must hold count * 2^log_n
 // elements.  dir: 0 forward, 1 inverse.  coset: 0/1.

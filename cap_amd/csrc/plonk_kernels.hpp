@@ -1,0 +1,385 @@
+// K7-K9 of SURVEY.md §8a: the O(n) element-wise / scan kernels of the TurboPlonk
+// prover (permutation grand product, fused quotient evaluation, polynomial
+// evaluation, linear combination, division by a linear factor).  Everything here
+// is batched over P independent proofs that share one proving key.
+//
+// Restates on the device the per-round loops of jf-plonk's prover
+// (`PlonkKzgSnark::prove`, call site src/proof/transfer.rs:181-186; algorithm as
+// recalled in SURVEY.md Appendix A.2-A.6).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "field.hpp"
+
+namespace cap {
+namespace pk {
+
+constexpr int NW = 5;    // wire types
+constexpr int NS = 13;   // selectors: q_lc x4, q_mul x2, q_hash x4, q_o, q_c, q_ecc
+constexpr int kThreads = 256;
+constexpr int kScanPerThread = 4;
+constexpr int kScanBlock = kThreads * kScanPerThread;  // 1024 elements per workgroup
+
+// per-proof challenges, device layout
+struct Chal {
+  fe beta, gamma, alpha, alpha2;
+};
+
+struct QuotConst {
+  fe g;           // coset generator 5 (Montgomery)
+  fe k[NW];       // wire-subset separators
+  fe zh_inv[8];   // 1 / ((g * w_m^i)^n - 1), i mod 8
+};
+
+// dst[(q/inner)*dst_outer + (q%inner)*dst_inner + k] = k < len ? src[(q/inner)*src_outer + (q%inner)*src_inner + k] : 0
+__global__ __launch_bounds__(kThreads) void k_pad_copy(fe* __restrict__ dst, size_t dst_outer, size_t dst_inner,
+                                                       const fe* __restrict__ src, size_t src_outer, size_t src_inner,
+                                                       uint32_t inner, size_t len, size_t total) {
+  size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= total) return;
+  uint32_t q = blockIdx.y;
+  size_t d = (size_t)(q / inner) * dst_outer + (size_t)(q % inner) * dst_inner + k;
+  fe v = Fr::zero();
+  if (k < len) v = src[(size_t)(q / inner) * src_outer + (size_t)(q % inner) * src_inner + k];
+  dst[d] = v;
+}
+
+// poly_q += (b_0 + b_1 X + ...)(X^n - 1); blinder index = (q/inner)*13 + bl_off + (q%inner)*nb + t
+__global__ void k_blind(fe* __restrict__ polys, size_t stride, size_t n, const fe* __restrict__ blinders,
+                        uint32_t inner, uint32_t bl_off, uint32_t nb, uint32_t count) {
+  uint32_t t = threadIdx.x, q = blockIdx.x;
+  if (q >= count || t >= nb) return;
+  fe b = blinders[(size_t)(q / inner) * 13 + bl_off + (size_t)(q % inner) * nb + t];
+  fe* p = polys + (size_t)q * stride;
+  p[t] = Fr::sub(p[t], b);
+  p[n + t] = Fr::add(p[n + t], b);
+}
+
+// round 2: per-row numerator / denominator of the permutation grand product
+__global__ __launch_bounds__(kThreads) void k_perm_numden(const fe* __restrict__ wires /*[P][5][n]*/,
+                                                          const fe* __restrict__ sig_eval /*[5][n]*/,
+                                                          const fe* __restrict__ tw_n, const Chal* __restrict__ chal,
+                                                          QuotConst qc, size_t n, fe* __restrict__ num,
+                                                          fe* __restrict__ den) {
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  uint32_t p = blockIdx.y;
+  fe beta = chal[p].beta, gamma = chal[p].gamma;
+  fe bx = Fr::mul(beta, tw_n[j]);
+  fe a = Fr::one(), b = Fr::one();
+#pragma unroll 1
+  for (int i = 0; i < NW; i++) {
+    fe w = Fr::add(wires[((size_t)p * NW + i) * n + j], gamma);
+    fe t1 = Fr::add(w, i == 0 ? bx : Fr::mul(qc.k[i], bx));
+    fe t2 = Fr::add(w, Fr::mul(beta, sig_eval[(size_t)i * n + j]));
+    a = i == 0 ? t1 : Fr::mul(a, t1);
+    b = i == 0 ? t2 : Fr::mul(b, t2);
+  }
+  num[(size_t)p * n + j] = a;
+  den[(size_t)p * n + j] = b;
+}
+
+// ---- exclusive scans over [batch][len] arrays (stride elements apart) --------------------------------
+// OP 0: field multiplication, 1: field addition.  REV: suffix scan (logical index len-1-k).
+template <int OP>
+__device__ __forceinline__ fe scan_op(const fe& a, const fe& b) {
+  return OP == 0 ? Fr::mul(a, b) : Fr::add(a, b);
+}
+template <int OP>
+__device__ __forceinline__ fe scan_identity() {
+  return OP == 0 ? Fr::one() : Fr::zero();
+}
+__device__ __forceinline__ fe shfl_up_fe(const fe& a, int d) {
+  fe r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.v[i] = __shfl_up(a.v[i], d);
+  return r;
+}
+
+// phase 1: block-local exclusive scan; block totals to tot[batch][nblocks]
+template <int OP, int REV>
+__global__ __launch_bounds__(kThreads) void k_scan_local(const fe* __restrict__ in, fe* __restrict__ out, size_t len,
+                                                         size_t stride, fe* __restrict__ tot, uint32_t nblocks) {
+  __shared__ fe wave_tot[kThreads / 64];
+  const uint32_t b = blockIdx.y, blk = blockIdx.x;
+  const fe* src = in + (size_t)b * stride;
+  fe* dst = out + (size_t)b * stride;
+  size_t k0 = (size_t)blk * kScanBlock + (size_t)threadIdx.x * kScanPerThread;
+  fe v[kScanPerThread];
+  fe run = scan_identity<OP>();
+#pragma unroll
+  for (int t = 0; t < kScanPerThread; t++) {
+    size_t k = k0 + t;
+    fe x = scan_identity<OP>();
+    if (k < len) x = src[REV ? (len - 1 - k) : k];
+    v[t] = run;                 // exclusive within the thread
+    run = t == 0 ? x : scan_op<OP>(run, x);
+  }
+  // inclusive scan of thread totals across the wavefront
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  fe inc = run;
+  for (int d = 1; d < 64; d <<= 1) {
+    fe o = shfl_up_fe(inc, d);
+    if ((int)lane >= d) inc = scan_op<OP>(o, inc);
+  }
+  if (lane == 63) wave_tot[wave] = inc;
+  fe excl = shfl_up_fe(inc, 1);
+  if (lane == 0) excl = scan_identity<OP>();
+  __syncthreads();
+  fe wpre = scan_identity<OP>();
+  for (uint32_t w = 0; w < wave; w++) wpre = scan_op<OP>(wpre, wave_tot[w]);
+  fe base = scan_op<OP>(wpre, excl);
+#pragma unroll
+  for (int t = 0; t < kScanPerThread; t++) {
+    size_t k = k0 + t;
+    if (k < len) dst[REV ? (len - 1 - k) : k] = t == 0 ? base : scan_op<OP>(base, v[t]);
+  }
+  if (threadIdx.x == kThreads - 1) tot[(size_t)b * nblocks + blk] = scan_op<OP>(wpre, inc);
+}
+
+// phase 2: exclusive scan of the block totals (one wavefront per batch entry, 64 blocks per step)
+template <int OP>
+__global__ __launch_bounds__(64) void k_scan_totals(fe* __restrict__ tot, uint32_t nblocks) {
+  fe* t = tot + (size_t)blockIdx.x * nblocks;
+  const uint32_t lane = threadIdx.x;
+  fe carry = scan_identity<OP>();
+  for (uint32_t base = 0; base < nblocks; base += 64) {
+    uint32_t i = base + lane;
+    fe x = i < nblocks ? t[i] : scan_identity<OP>();
+    fe inc = x;
+    for (int d = 1; d < 64; d <<= 1) {
+      fe o = shfl_up_fe(inc, d);
+      if ((int)lane >= d) inc = scan_op<OP>(o, inc);
+    }
+    fe excl = shfl_up_fe(inc, 1);
+    if (lane == 0) excl = scan_identity<OP>();
+    if (i < nblocks) t[i] = scan_op<OP>(carry, excl);
+    fe last;
+#pragma unroll
+    for (int w = 0; w < 8; w++) last.v[w] = __shfl(inc.v[w], 63);
+    carry = scan_op<OP>(carry, last);
+  }
+}
+
+// phase 3: fold the block prefix in
+template <int OP, int REV>
+__global__ __launch_bounds__(kThreads) void k_scan_apply(fe* __restrict__ out, size_t len, size_t stride,
+                                                         const fe* __restrict__ tot, uint32_t nblocks) {
+  const uint32_t b = blockIdx.y, blk = blockIdx.x;
+  if (blk == 0) return;
+  fe pre = tot[(size_t)b * nblocks + blk];
+  fe* dst = out + (size_t)b * stride;
+  for (int t = 0; t < kScanPerThread; t++) {
+    size_t k = (size_t)blk * kScanBlock + (size_t)t * kThreads + threadIdx.x;
+    if (k < len) {
+      size_t idx = REV ? (len - 1 - k) : k;
+      dst[idx] = scan_op<OP>(pre, dst[idx]);
+    }
+  }
+}
+
+// inv_total[p] = 1 / (sfx[p][0] * den[p][0])
+__global__ void k_perm_inv_total(const fe* __restrict__ sfx, const fe* __restrict__ den, size_t n,
+                                 fe* __restrict__ inv_total, uint32_t count) {
+  uint32_t p = blockIdx.x * blockDim.x + threadIdx.x;
+  if (p >= count) return;
+  inv_total[p] = Fr::inv(Fr::mul(sfx[(size_t)p * n], den[(size_t)p * n]));
+}
+
+// z[j] = prefix_num[j] * (suffix_den_excl[j] * den[j]) / prod(den); zero padding up to stride
+__global__ __launch_bounds__(kThreads) void k_perm_finish(const fe* __restrict__ pre, const fe* __restrict__ sfx,
+                                                          const fe* __restrict__ den,
+                                                          const fe* __restrict__ inv_total, size_t n,
+                                                          fe* __restrict__ z, size_t zstride) {
+  size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  uint32_t p = blockIdx.y;
+  if (j >= zstride) return;
+  fe v = Fr::zero();
+  if (j < n) {
+    size_t o = (size_t)p * n + j;
+    v = Fr::mul(Fr::mul(pre[o], sfx[o]), Fr::mul(den[o], inv_total[p]));
+  }
+  z[(size_t)p * zstride + j] = v;
+}
+
+// ---- round 3: fused quotient evaluation on the coset of size m = 8n ----------------------------------
+// pkc: [18][m] coset evaluations of 13 selectors then 5 sigmas (shared by all proofs)
+// cos: [P][7][m] coset evaluations of 5 wires, z, pi
+__global__ __launch_bounds__(kThreads) void k_quotient(const fe* __restrict__ pkc, const fe* __restrict__ cos,
+                                                       const fe* __restrict__ tw_m,
+                                                       const fe* __restrict__ inv_nx1,
+                                                       const Chal* __restrict__ chal, QuotConst qc, size_t m,
+                                                       fe* __restrict__ t_out) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  const uint32_t p = blockIdx.y;
+  const fe* c = cos + (size_t)p * 7 * m;
+  const Chal ch = chal[p];
+  fe w[NW];
+#pragma unroll
+  for (int j = 0; j < NW; j++) w[j] = c[(size_t)j * m + i];
+  const fe zx = c[(size_t)5 * m + i];
+  const fe zwx = c[(size_t)5 * m + ((i + 8) & (m - 1))];
+  const fe pi = c[(size_t)6 * m + i];
+  // gate constraint (spec eq. (1); selector order q_lc, q_mul, q_hash, q_o, q_c, q_ecc)
+  fe acc = Fr::add(pkc[(size_t)11 * m + i], pi);
+#pragma unroll 1
+  for (int j = 0; j < 4; j++) {
+    acc = Fr::add(acc, Fr::mul(pkc[(size_t)j * m + i], w[j]));
+    fe w2 = Fr::sqr(w[j]);
+    fe w5 = Fr::mul(Fr::sqr(w2), w[j]);
+    acc = Fr::add(acc, Fr::mul(pkc[(size_t)(6 + j) * m + i], w5));
+  }
+  fe w01 = Fr::mul(w[0], w[1]);
+  fe w23 = Fr::mul(w[2], w[3]);
+  acc = Fr::add(acc, Fr::mul(pkc[(size_t)4 * m + i], w01));
+  acc = Fr::add(acc, Fr::mul(pkc[(size_t)5 * m + i], w23));
+  acc = Fr::add(acc, Fr::mul(pkc[(size_t)12 * m + i], Fr::mul(Fr::mul(w01, w23), w[4])));
+  acc = Fr::sub(acc, Fr::mul(pkc[(size_t)10 * m + i], w[4]));
+  // permutation part
+  fe x = Fr::mul(qc.g, tw_m[i]);
+  fe bx = Fr::mul(ch.beta, x);
+  fe a = zx, b = zwx;
+#pragma unroll 1
+  for (int j = 0; j < NW; j++) {
+    fe wg = Fr::add(w[j], ch.gamma);
+    a = Fr::mul(a, Fr::add(wg, j == 0 ? bx : Fr::mul(qc.k[j], bx)));
+    b = Fr::mul(b, Fr::add(wg, Fr::mul(ch.beta, pkc[(size_t)(NS + j) * m + i])));
+  }
+  acc = Fr::add(acc, Fr::mul(ch.alpha, Fr::sub(a, b)));
+  acc = Fr::mul(acc, qc.zh_inv[i & 7]);
+  fe l1 = Fr::mul(Fr::mul(ch.alpha2, Fr::sub(zx, Fr::one())), inv_nx1[i]);
+  t_out[(size_t)p * m + i] = Fr::add(acc, l1);
+}
+
+// out[i] = 1 / (n * (g * w_m^i - 1))   (one-time table of the proving key)
+__global__ __launch_bounds__(kThreads) void k_inv_nx1(fe* __restrict__ out, const fe* __restrict__ tw_m, fe g,
+                                                      fe n_mont, size_t m) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= m) return;
+  fe x = Fr::mul(g, tw_m[i]);
+  out[i] = Fr::inv(Fr::mul(n_mont, Fr::sub(x, Fr::one())));
+}
+
+// flags[p] |= 1 if any coefficient at index >= lo is non-zero; |= 2 if coefficient lo-1 is zero
+__global__ __launch_bounds__(kThreads) void k_check_degree(const fe* __restrict__ t, size_t m, size_t lo,
+                                                           uint32_t* __restrict__ flags) {
+  size_t k = lo - 1 + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m) return;
+  uint32_t p = blockIdx.y;
+  bool zero = Fr::is_zero(t[(size_t)p * m + k]);
+  if (k == lo - 1) {
+    if (zero) atomicOr(&flags[p], 2u);
+  } else if (!zero) {
+    atomicOr(&flags[p], 1u);
+  }
+}
+
+// ---- round 4/5 helpers ---------------------------------------------------------------------------------
+// tables[q][k] = base_q^k, k < len;  pw[q][b] = base_q^(2^b), b < 24
+__global__ __launch_bounds__(kThreads) void k_powers(fe* __restrict__ tables, size_t stride, size_t len,
+                                                     const fe* __restrict__ pw) {
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= len) return;
+  uint32_t q = blockIdx.y;
+  const fe* b = pw + (size_t)q * 24;
+  fe r = Fr::one();
+  bool started = false;
+  for (int i = 0; (e >> i) != 0; i++) {
+    if ((e >> i) & 1) {
+      r = started ? Fr::mul(r, b[i]) : b[i];
+      started = true;
+    }
+  }
+  tables[(size_t)q * stride + e] = r;
+}
+
+struct EvalDesc {
+  const fe* poly;
+  const fe* pows;
+  uint32_t len;
+  uint32_t pad;
+};
+
+__device__ __forceinline__ fe wave_sum(fe v) {
+  for (int d = 32; d >= 1; d >>= 1) {
+    fe o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.v[i] = __shfl_down(v.v[i], d);
+    v = Fr::add(v, o);
+  }
+  return v;
+}
+
+// partial[e][chunk] = sum over the chunk of poly[k] * pows[k]
+__global__ __launch_bounds__(kThreads) void k_eval_partial(const EvalDesc* __restrict__ desc, fe* __restrict__ partial,
+                                                           uint32_t chunks, uint32_t per_chunk) {
+  __shared__ fe sh[kThreads / 64];
+  const uint32_t e = blockIdx.y, chunk = blockIdx.x;
+  const EvalDesc d = desc[e];
+  fe acc = Fr::zero();
+  uint32_t lo = chunk * per_chunk, hi = lo + per_chunk;
+  if (hi > d.len) hi = d.len;
+  for (uint32_t k = lo + threadIdx.x; k < hi; k += kThreads) acc = Fr::add(acc, Fr::mul(d.poly[k], d.pows[k]));
+  acc = wave_sum(acc);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    fe r = sh[0];
+    for (int w = 1; w < kThreads / 64; w++) r = Fr::add(r, sh[w]);
+    partial[(size_t)e * chunks + chunk] = r;
+  }
+}
+__global__ __launch_bounds__(64) void k_eval_final(const fe* __restrict__ partial, uint32_t chunks,
+                                                   fe* __restrict__ out) {
+  const uint32_t e = blockIdx.x;
+  fe acc = Fr::zero();
+  for (uint32_t k = threadIdx.x; k < chunks; k += 64) acc = Fr::add(acc, partial[(size_t)e * chunks + k]);
+  acc = wave_sum(acc);
+  if (threadIdx.x == 0) out[e] = acc;
+}
+
+struct LinTerm {
+  const fe* poly;
+  fe scalar;
+  uint32_t len;
+  uint32_t pad[3];
+};
+
+// out[p][k] = sum_t terms[p][t].scalar * terms[p][t].poly[k]   (k < terms[p][t].len), k < out_len
+__global__ __launch_bounds__(kThreads) void k_lincomb(const LinTerm* __restrict__ terms, uint32_t nterms,
+                                                      fe* __restrict__ out, size_t out_stride, size_t out_len) {
+  size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= out_len) return;
+  uint32_t p = blockIdx.y;
+  const LinTerm* T = terms + (size_t)p * nterms;
+  fe acc = Fr::zero();
+  for (uint32_t t = 0; t < nterms; t++) {
+    if (k < T[t].len) acc = Fr::add(acc, Fr::mul(T[t].scalar, T[t].poly[k]));
+  }
+  out[(size_t)p * out_stride + k] = acc;
+}
+
+// h[q][k] = f[q][k] * pows[tab(q)][k];  tab(q) = (q/2)*4 + (q%2)      (q = proof*2 + {zeta, zeta*omega})
+__global__ __launch_bounds__(kThreads) void k_div_prepare(const fe* __restrict__ f, const fe* __restrict__ pows,
+                                                          size_t stride, size_t len, fe* __restrict__ h) {
+  size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= len) return;
+  uint32_t q = blockIdx.y;
+  size_t tab = (size_t)(q / 2) * 4 + (q % 2);
+  h[(size_t)q * stride + k] = Fr::mul(f[(size_t)q * stride + k], pows[tab * stride + k]);
+}
+// quot[q][i] = sfx[q][i] * ainv^(i+1), i < len-1 (sfx = exclusive suffix sum of h); quot[q][len-1..stride) = 0
+__global__ __launch_bounds__(kThreads) void k_div_finish(const fe* __restrict__ sfx, const fe* __restrict__ pows,
+                                                         size_t stride, size_t len, fe* __restrict__ quot) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= stride) return;
+  uint32_t q = blockIdx.y;
+  size_t tab = (size_t)(q / 2) * 4 + 2 + (q % 2);
+  fe v = Fr::zero();
+  if (i + 1 < len) v = Fr::mul(sfx[(size_t)q * stride + i], pows[tab * stride + i + 1]);
+  quot[(size_t)q * stride + i] = v;
+}
+
+}  // namespace pk
+}  // namespace cap

@@ -234,3 +234,70 @@ def profile_stats() -> dict:
         name, ms, cnt = line.split()
         out[name] = (float(ms), int(cnt))
     return out
+
+
+# ---- PLONK ---------------------------------------------------------------------------------------
+def plonk_preprocess(srs_handle: int, n: int, num_inputs: int, selectors: np.ndarray, sigma_evals: np.ndarray):
+    """selectors (13, n, 4), sigma_evals (5, n, 4) Montgomery -> (pk handle, VerifyingKey)."""
+    selectors = np.ascontiguousarray(selectors, dtype=np.uint64)
+    sigma_evals = np.ascontiguousarray(sigma_evals, dtype=np.uint64)
+    assert selectors.size == NUM_SELECTORS * n * 4 and sigma_evals.size == NUM_WIRE_TYPES * n * 4
+    h = ctypes.c_uint64()
+    vk = VerifyingKey()
+    check(load().capgpu_plonk_preprocess(ctypes.c_uint64(srs_handle), ctypes.c_size_t(n), ctypes.c_size_t(num_inputs),
+                                         _p(selectors.reshape(-1)), _p(sigma_evals.reshape(-1)), ctypes.byref(h),
+                                         ctypes.byref(vk)))
+    return h.value, vk
+
+
+def plonk_free_key(pk_handle: int):
+    check(load().capgpu_plonk_free_key(ctypes.c_uint64(pk_handle)))
+
+
+def _bytes_arg(b):
+    if b is None:
+        return None, 0
+    buf = (ctypes.c_uint8 * len(b)).from_buffer_copy(bytes(b)) if len(b) else None
+    return buf, len(b)
+
+
+def plonk_prove_batch(pk_handle: int, wires: np.ndarray, pub_inputs: np.ndarray, blinders: np.ndarray,
+                      ext_msg: bytes | None = None, count: int = 1):
+    """wires (count, 5, n, 4), pub_inputs (count, l, 4), blinders (count, 13, 4), all Montgomery."""
+    wires = np.ascontiguousarray(wires, dtype=np.uint64)
+    pub_inputs = np.ascontiguousarray(pub_inputs, dtype=np.uint64).reshape(-1)
+    blinders = np.ascontiguousarray(blinders, dtype=np.uint64).reshape(-1)
+    num_inputs = pub_inputs.size // 4 // count
+    proofs = (Proof * count)()
+    mbuf, mlen = _bytes_arg(ext_msg)
+    pub_ptr = _p(pub_inputs) if pub_inputs.size else None
+    check(load().capgpu_plonk_prove_batch(ctypes.c_uint64(pk_handle), count, _p(wires.reshape(-1)), pub_ptr,
+                                          ctypes.c_size_t(num_inputs), mbuf, ctypes.c_size_t(mlen), _p(blinders),
+                                          proofs))
+    return list(proofs)
+
+
+def plonk_prove_batch_dev(pk_handle: int, d_wires: DevBuf, pub_inputs: np.ndarray, blinders: np.ndarray,
+                          ext_msg: bytes | None = None, count: int = 1):
+    pub_inputs = np.ascontiguousarray(pub_inputs, dtype=np.uint64).reshape(-1)
+    blinders = np.ascontiguousarray(blinders, dtype=np.uint64).reshape(-1)
+    num_inputs = pub_inputs.size // 4 // count
+    proofs = (Proof * count)()
+    mbuf, mlen = _bytes_arg(ext_msg)
+    pub_ptr = _p(pub_inputs) if pub_inputs.size else None
+    check(load().capgpu_plonk_prove_batch_dev(ctypes.c_uint64(pk_handle), count, d_wires.ptr, pub_ptr,
+                                              ctypes.c_size_t(num_inputs), mbuf, ctypes.c_size_t(mlen), _p(blinders),
+                                              proofs))
+    return list(proofs)
+
+
+def proof_to_arrays(pr: Proof) -> dict:
+    """ctypes Proof -> dict of numpy arrays (Montgomery words)."""
+    def a(x):
+        return np.ctypeslib.as_array(x).copy()
+    return {
+        "wires_poly_comms": a(pr.wires_poly_comms), "prod_perm_poly_comm": a(pr.prod_perm_poly_comm),
+        "split_quot_poly_comms": a(pr.split_quot_poly_comms), "opening_proof": a(pr.opening_proof),
+        "shifted_opening_proof": a(pr.shifted_opening_proof), "wires_evals": a(pr.wires_evals),
+        "wire_sigma_evals": a(pr.wire_sigma_evals), "perm_next_eval": a(pr.perm_next_eval),
+    }
