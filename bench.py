@@ -1,0 +1,205 @@
+#!/usr/bin/env python3
+"""bench.py - transfer-note proofs/sec (2-in/2-out) on N MI355X, one process per GPU.
+
+    python bench.py --gpus 1 --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input: `--batch` independent 2-in/2-out
+transfer-note proofs (circuit shape n = 2^15, 27 public inputs - src/utils/mod.rs:149-153; random satisfiable
+TurboPlonk instance, SRS = powers of a known tau) proved by the device prover behind the capgpu C ABI.  The
+witnesses, the proving key and the SRS are resident in HBM when the timed region starts.  With N > 1 every rank
+proves its own batch (proofs are independent: replicas, no data-path collective) -> weak scaling;
+value = all proofs of all ranks / max-over-ranks time.
+
+Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the definition of every field.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def algorithmic_bytes_per_proof(n: int) -> dict:
+    """reference schedule, primitives only."""
+    msm_pairs = 4 * 0 + 5 * (n + 2) + (n + 3) + 5 * (n + 2) + 2 * (n + 2)
+    ntt_elems = 7 * n + 26 * 8 * n
+    return {"msm_pairs": msm_pairs, "msm_bytes": 96 * msm_pairs, "ntt_elems": ntt_elems, "ntt_bytes": 64 * ntt_elems,
+            "total_bytes": 96 * msm_pairs + 64 * ntt_elems}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=16, help="proofs per step per GPU")
+    ap.add_argument("--log-n", type=int, default=15, help="evaluation domain (15: pinned for depth 10; 16: upper bound)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-schedule", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from cap_amd import bench_utils as bu
+    from cap_amd import lib as cg
+
+    cg.init(local_rank)                       # raises (no fallback) when the HIP library / a gfx950 device is missing
+    torch.cuda.set_device(local_rank)
+    P, log_n = args.batch, args.log_n
+    n = 1 << log_n
+    num_inputs = 27
+    tau = bu.SplitMix64(0xCA9).field()
+
+    # ---- setup (untimed): SRS, circuit, proving key, resident witnesses ------------------------------------
+    t_setup = time.time()
+    srs = cg.srs_generate(tau, n + 3)
+    sc = bu.synthetic_circuit(log_n, num_inputs, seed=2)
+    sel, sig = sc.selectors_mont(), sc.sigma_mont()
+    pk, _vk = cg.plonk_preprocess(srs, n, num_inputs, sel, sig)
+    n_wit = min(P, 4)
+    wit = [sc.witness(1000 * rank + 3 + i) for i in range(n_wit)]
+    wires = np.stack([sc.wires_mont(wit[i % n_wit][0]) for i in range(P)])
+    pubs = np.stack([bu.to_mont_array(wit[i % n_wit][1]) for i in range(P)])
+    blind = np.stack([bu.to_mont_array(bu.blinders(7000 + 100 * rank + i)) for i in range(P)])
+    d_wires = cg.DevBuf.from_numpy(wires)
+    ext_msg = bytes(range(32))                # stands for the serialised txn-memo verification key
+    t_setup = time.time() - t_setup
+
+    def sync_all():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    def step(key):
+        return cg.plonk_prove_batch_dev(key, d_wires, pubs, blind, ext_msg, P)
+
+    def timed(key, steps, warmup, profile):
+        for _ in range(warmup):
+            step(key)
+        if profile:
+            cg.profile_reset()
+            cg.profile_enable(True)
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            proofs = step(key)
+        sync_all()
+        dt = time.perf_counter() - t0
+        stats = cg.profile_stats() if profile else {}
+        cg.profile_enable(False)
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt, stats, proofs
+
+    dt, stats, proofs = timed(pk, args.steps, args.warmup, profile=True)
+    total_proofs = P * args.steps * world
+    value = total_proofs / dt
+
+    # ---- roofline of the dominant kernel (HIP events on the launch stream, timed region itself) -------------
+    ab = algorithmic_bytes_per_proof(n)
+    kern_ms = {k: v[0] for k, v in stats.items()}
+    dom = max(kern_ms, key=kern_ms.get) if kern_ms else None
+    per_step_bytes = {
+        # K5: 96 B per (point, scalar) pair handled by the launch (64 B affine base + 32 B scalar)
+        "msm_accumulate": ab["msm_bytes"] * P,
+        # K2: 64 B per element per transform; a transform of 2^11..2^20 elements is one column + one row pass
+        "ntt_col_pass": 0.5 * (64 * (7 * n + 8 * 8 * n)) * P,
+        "ntt_row_pass": 0.5 * (64 * (7 * n + 8 * 8 * n)) * P,
+        # K8: 26 arrays of 8n elements (25 in, 1 out) x 32 B
+        "k_quotient": 26 * 8 * n * 32 * P,
+    }
+    roofline = None
+    if dom is not None:
+        launches = stats[dom][1]
+        avg_ms = stats[dom][0] / max(launches, 1)
+        if dom in per_step_bytes:
+            bytes_per_launch = per_step_bytes[dom] * args.steps / max(launches, 1)
+            achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
+        else:
+            bytes_per_launch, achieved = None, None
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
+                    "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
+                    "share_of_kernel_time": kern_ms[dom] / sum(kern_ms.values())}
+    top = sorted(kern_ms.items(), key=lambda kv: -kv[1])[:8]
+    whole_gbps = ab["total_bytes"] * total_proofs / dt / 1e9
+
+    out = {
+        "metric": "transfer-note proofs/sec (2-in/2-out)", "value": value, "unit": "proofs/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery integers)", "data": "synthetic",
+        "config": {"workload": f"full 2-in/2-out transfer-note PLONK proof (13 MSM + 33 NTT), n=2^{log_n}, 27 public inputs, "
+                               f"batch {P} proofs/step/GPU, device-resident witness + key + SRS",
+                   "domain_size": n, "batch_per_gpu": P, "parallelism": f"replicas x{world} (independent proofs)",
+                   "pk_coset_cache": "18 fixed selector/sigma coset NTTs cached in the proving key (see "
+                                     "reference_schedule for the per-proof recompute number)"},
+        "roofline": roofline,
+        "proof_hbm_roofline": {"algorithmic_bytes_per_proof": ab["total_bytes"], "achieved_GBps": whole_gbps,
+                               "frac_of_peak": whole_gbps / HBM_PEAK_GBPS},
+        "top_kernels_ms": {k: round(v, 3) for k, v in top},
+        "setup_s": round(t_setup, 2),
+    }
+
+    if world == 1 and not args.no_reference_schedule:
+        os.environ["CAPGPU_RECOMPUTE_PK_COSET"] = "1"
+        pk_ref, _ = cg.plonk_preprocess(srs, n, num_inputs, sel, sig)
+        os.environ.pop("CAPGPU_RECOMPUTE_PK_COSET")
+    if not args.no_reference_schedule:
+        # every rank must take part (barriers); only rank 0 built the key when world == 1
+        if world == 1:
+            rs = max(2, args.steps // 2)
+            dt_ref, _, proofs_ref = timed(pk_ref, rs, 1, profile=False)
+            a, b = cg.proof_to_arrays(proofs_ref[0]), cg.proof_to_arrays(proofs[0])
+            same = all(np.array_equal(a[k], b[k]) for k in a)
+            out["reference_schedule"] = {"proofs_per_s": P * rs / dt_ref, "steps": rs,
+                                         "note": "all 25 coset NTTs re-run per proof as jf-plonk does",
+                                         "proof_identical_to_cached_mode": bool(same)}
+            cg.plonk_free_key(pk_ref)
+
+    # ---- CPU baseline: the C restatement of the arkworks/jf-plonk algorithm, 1 thread, rank 0, N = 1 ----------
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import capref as cr        # cpu_baseline leg: the only place bench.py touches oracle/
+        key = cr.PlonkKey(cg.srs_download(srs, 0, n + 3), n, num_inputs, sel, sig)
+        t0 = time.perf_counter()
+        rc, comms, evals = key.prove(wires[0], pubs[0], blind[0], ext_msg)
+        t_cpu = time.perf_counter() - t0
+        a = cg.proof_to_arrays(proofs[0])
+        got_comms = np.concatenate([a["wires_poly_comms"], a["prod_perm_poly_comm"][None], a["split_quot_poly_comms"],
+                                    a["opening_proof"][None], a["shifted_opening_proof"][None]])
+        got_evals = np.concatenate([a["wires_evals"], a["wire_sigma_evals"], a["perm_next_eval"][None]])
+        parity = bool(rc == 0 and np.array_equal(got_comms, comms) and np.array_equal(got_evals, evals))
+        out["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "proofs/s", "cores": 1, "kind": "port",
+                               "sample": f"1 proof of the same workload (n=2^{log_n}), {t_cpu:.1f} s, single-thread C "
+                                         "restatement of the arkworks/jf-plonk algorithm (reference schedule, no asm)",
+                               "gpu_proof_bit_exact_vs_cpu": parity}
+        out["speedup_vs_cpu_1core"] = value / (1.0 / t_cpu)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

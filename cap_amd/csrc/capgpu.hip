@@ -116,6 +116,36 @@ __global__ void fq_to_mont_kernel(fe* data, size_t count) {
   if (i < count) data[i] = Fq::to_mont(data[i]);
 }
 
+// sum of n Jacobian points (one wavefront; n is tiny: the G partial sums of a sharded MSM)
+__global__ __launch_bounds__(64) void g1_sum_kernel(const g1_jac* __restrict__ in, size_t n, g1_jac* __restrict__ out) {
+  g1_xyzz acc = G1::inf();
+  for (size_t i = threadIdx.x; i < n; i += 64) {
+    g1_jac p = in[i];
+    g1_xyzz q;
+    if (Fq::is_zero(p.z)) {
+      q = G1::inf();
+    } else {
+      q.x = p.x;
+      q.y = p.y;
+      q.zz = Fq::sqr(p.z);
+      q.zzz = Fq::mul(q.zz, p.z);
+    }
+    acc = G1::add(acc, q);
+  }
+  for (int d = 32; d >= 1; d >>= 1) {
+    g1_xyzz o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      o.x.v[i] = __shfl_down(acc.x.v[i], d);
+      o.y.v[i] = __shfl_down(acc.y.v[i], d);
+      o.zz.v[i] = __shfl_down(acc.zz.v[i], d);
+      o.zzz.v[i] = __shfl_down(acc.zzz.v[i], d);
+    }
+    acc = G1::add(acc, o);
+  }
+  if (threadIdx.x == 0) *out = G1::to_jac(acc);
+}
+
 fe fe_from_u64x4(const uint64_t v[4]) {
   fe r;
   for (int i = 0; i < 4; i++) {
@@ -429,6 +459,21 @@ int capgpu_msm_g1_batch(uint64_t srs_handle, const size_t* offsets, const uint64
 int capgpu_msm_g1(uint64_t srs_handle, size_t offset, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]) {
   const uint64_t* sp[1] = {scalars};
   return capgpu_msm_g1_batch(srs_handle, &offset, sp, &n, 1, out_xyz);
+}
+
+int capgpu_g1_sum(const uint64_t* points_xyz, size_t n, uint64_t out_xyz[12]) {
+  CAP_CHECK_INIT();
+  if ((!points_xyz && n) || !out_xyz) return CAPGPU_ERR_INVALID_ARG;
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  int rc = scratch_reserve(c.stage_a, sizeof(g1_jac) * (n + 1));
+  if (rc) return rc;
+  g1_jac* d = (g1_jac*)c.stage_a.p;
+  if (n) CAP_HIP(hipMemcpyAsync(d + 1, points_xyz, sizeof(g1_jac) * n, hipMemcpyHostToDevice, c.stream));
+  launch("g1_sum_kernel", g1_sum_kernel, dim3(1), dim3(64), 0, c.stream, (const g1_jac*)(d + 1), n, d);
+  CAP_HIP(hipMemcpyAsync(out_xyz, d, sizeof(g1_jac), hipMemcpyDeviceToHost, c.stream));
+  CAP_HIP(hipStreamSynchronize(c.stream));
+  return CAPGPU_OK;
 }
 
 // ---- NTT ------------------------------------------------------------------------------------------

@@ -196,6 +196,14 @@ def msm_g1_dev(handle: int, d_scalars: DevBuf, n: int, count: int = 1, stride: i
     return d_out
 
 
+def g1_sum(points: np.ndarray) -> np.ndarray:
+    """(k, 12) Jacobian points -> their group sum (12,)."""
+    points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 12)
+    out = np.zeros(12, dtype=np.uint64)
+    check(load().capgpu_g1_sum(_p(points.reshape(-1)), ctypes.c_size_t(points.shape[0]), _p(out)))
+    return out
+
+
 # ---- NTT -----------------------------------------------------------------------------------------
 def ntt_fr(data: np.ndarray, log_n: int, inverse: bool = False, coset: bool = False) -> np.ndarray:
     data = np.ascontiguousarray(data, dtype=np.uint64).copy()

@@ -1,0 +1,50 @@
+"""Multi-GPU sharding of the hot path: one process per GPU, torch.distributed.
+
+* Whole proofs are independent -> replicas, no data-path collective (`shard_proofs`).
+* One MSM shards by contiguous point range: rank g owns bases[g*N/G, (g+1)*N/G) resident on its GPU
+  and receives the matching scalar slice; every rank runs the full Pippenger locally and the single
+  exchange step is an all-gather of one 96-byte Jacobian point per rank (RCCL has no elliptic-curve
+  reduction op, so no all-reduce), followed by G-1 group additions (`sharded_msm`).
+
+The local MSM engine and the point-combine are passed in, so the same code path runs on RCCL with the
+HIP kernels (bench.py) and on gloo in the CPU tests.
+"""
+from __future__ import annotations
+
+from typing import Callable, Sequence
+
+import numpy as np
+
+
+def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
+    """contiguous [lo, hi) of rank; sizes differ by at most one."""
+    base, rem = divmod(n, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def shard_proofs(count: int, rank: int, world: int) -> list[int]:
+    """proof i -> rank i mod world (the reference's par_iter over notes, params_builder.rs:194-226)."""
+    return [i for i in range(count) if i % world == rank]
+
+
+def all_gather_points(local_point: np.ndarray, device=None) -> np.ndarray:
+    """all-gather one Jacobian point (12 x u64) per rank -> (world, 12).  uint64 travels as int64."""
+    import torch
+    import torch.distributed as dist
+
+    world = dist.get_world_size()
+    t = torch.from_numpy(np.ascontiguousarray(local_point, dtype=np.uint64).view(np.int64).copy())
+    if device is not None:
+        t = t.to(device)
+    out = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(out, t)
+    return np.stack([o.cpu().numpy().view(np.uint64) for o in out])
+
+
+def sharded_msm(local_msm: Callable[[], np.ndarray], combine: Callable[[Sequence[np.ndarray]], np.ndarray],
+                device=None) -> np.ndarray:
+    """local_msm() -> this rank's partial sum (Jacobian, 12 words); combine(points) -> their group sum.
+    Every rank returns the full result."""
+    parts = all_gather_points(local_msm(), device)
+    return combine(list(parts))

@@ -1,0 +1,87 @@
+"""Host-side mirror of the reference's proof API on top of the capgpu C ABI.
+
+Same names and argument meaning as `/root/reference/src/proof/`:
+  universal_setup       src/proof/mod.rs:59-69     (SRS = powers of tau in G1; synthetic tau here)
+  preprocess            src/proof/transfer.rs:124-155, mint.rs:69-93, freeze.rs:93-121
+  prove                 src/proof/transfer.rs:159-188, mint.rs:97-120, freeze.rs:125-158
+Errors surface as `TxnApiError.FailedSnark(str)` like the reference maps every SNARK failure
+(src/errors.rs:25-63, src/proof/transfer.rs:187).
+
+The circuit builders of the reference (src/circuit/*.rs) stay on the CPU and are out of scope
+(SURVEY §8); `prove` therefore takes what they produce: the finalised wire assignment (5 columns
+of n field elements), the public inputs and the transcript init message.  All heavy work happens
+in libcapgpu.so - there is no CPU fallback.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import lib as _lib
+
+
+class TxnApiError(Exception):
+    """src/errors.rs:25-63 (only the variant the proof API produces)."""
+
+    @classmethod
+    def FailedSnark(cls, msg: str) -> "TxnApiError":
+        return cls(f"FailedSnark: {msg}")
+
+
+@dataclass
+class UniversalSrs:
+    handle: int
+    max_degree: int
+
+
+@dataclass
+class ProvingKey:
+    handle: int
+    n: int
+    num_inputs: int
+    srs: UniversalSrs
+
+
+@dataclass
+class VerifyingKey:
+    raw: _lib.VerifyingKey
+    n: int
+    num_inputs: int
+
+
+def universal_setup(max_degree: int, tau: int) -> UniversalSrs:
+    """SRS [tau^i] G for i <= max_degree, generated and kept on the device.
+    (The reference samples tau from its rng; benches use test_rng, benches/transfer.rs:71.)"""
+    try:
+        _lib.init()
+        return UniversalSrs(_lib.srs_generate(tau, max_degree + 1), max_degree)
+    except _lib.CapGpuError as e:
+        raise TxnApiError.FailedSnark(f"Failed to generate universal SRS: {e}") from e
+
+
+def preprocess(srs: UniversalSrs, n: int, num_inputs: int, selectors: np.ndarray, sigma_evals: np.ndarray):
+    """-> (ProvingKey, VerifyingKey, n_constraints).  selectors (13, n, 4) / sigma_evals (5, n, 4), Montgomery."""
+    try:
+        h, vk = _lib.plonk_preprocess(srs.handle, n, num_inputs, selectors, sigma_evals)
+    except _lib.CapGpuError as e:
+        raise TxnApiError.FailedSnark(f"Preprocessing circuit of domain size {n} failed: {e}") from e
+    return ProvingKey(h, n, num_inputs, srs), VerifyingKey(vk, n, num_inputs), n
+
+
+def prove(proving_key: ProvingKey, wires: np.ndarray, public_inputs: np.ndarray, blinders: np.ndarray,
+          ext_msg: bytes | None = None):
+    """One proof.  wires (5, n, 4), public_inputs (l, 4), blinders (13, 4): Montgomery words."""
+    return prove_batch(proving_key, np.asarray(wires)[None], np.asarray(public_inputs)[None],
+                       np.asarray(blinders)[None], ext_msg)[0]
+
+
+def prove_batch(proving_key: ProvingKey, wires: np.ndarray, public_inputs: np.ndarray, blinders: np.ndarray,
+                ext_msg: bytes | None = None):
+    """`count` independent proofs under one key (the rayon par_iter of
+    src/utils/params_builder.rs:194-226 becomes one device batch)."""
+    count = int(np.asarray(wires).shape[0])
+    try:
+        return _lib.plonk_prove_batch(proving_key.handle, wires, public_inputs, blinders, ext_msg, count)
+    except _lib.CapGpuError as e:
+        raise TxnApiError.FailedSnark(f"Proof Creation failure: {e}") from e

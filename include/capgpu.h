@@ -108,6 +108,10 @@ int capgpu_msm_g1_batch(uint64_t srs_handle, const size_t* offsets, const uint64
 int capgpu_msm_g1_dev(uint64_t srs_handle, size_t offset, const void* d_scalars, size_t scalar_stride, size_t n,
                       int count, int scalars_montgomery, void* d_out_xyz);
 
+/* out = sum of n Jacobian points (96 B each, host memory): the combine step after the all-gather of a
+ * point-range-sharded MSM (replaces the G-1 `GroupProjective::add_assign` a multi-GPU caller would do). */
+int capgpu_g1_sum(const uint64_t* points_xyz, size_t n, uint64_t out_xyz[12]);
+
 /* ---- NTT: replaces Radix2EvaluationDomain::{fft, ifft, coset_fft, coset_ifft}_in_place -------- */
 /* in place, natural order in/out, Montgomery Fr; dir: 0 forward, 1 inverse (includes n^-1);
  * coset: 0/1 (generator 5: scale by 5^i before the forward transform / by 5^-i after the inverse). */

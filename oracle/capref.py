@@ -159,3 +159,53 @@ def points_to_array(points) -> np.ndarray:
         else:
             vals += [bn254.to_mont(pt[0], bn254.P), bn254.to_mont(pt[1], bn254.P)]
     return ints_to_array(vals).reshape(-1, 8)
+
+
+# ---- PLONK prover restatement (oracle/capref_plonk.c) ----------------------------------------------
+PROOF_WORDS = 13 * 8 + 10 * 4
+
+
+class PlonkKey:
+    def __init__(self, srs_bases: np.ndarray, n: int, num_inputs: int, selectors: np.ndarray, sigma_evals: np.ndarray):
+        L = lib()
+        L.capref_plonk_preprocess.restype = ctypes.c_void_p
+        srs_bases = np.ascontiguousarray(srs_bases, dtype=np.uint64).reshape(-1)
+        assert srs_bases.size >= 8 * (n + 3)
+        selectors = np.ascontiguousarray(selectors, dtype=np.uint64).reshape(-1)
+        sigma_evals = np.ascontiguousarray(sigma_evals, dtype=np.uint64).reshape(-1)
+        self.vk_comms = np.zeros((18, 8), dtype=np.uint64)
+        self.n, self.num_inputs = n, num_inputs
+        self.h = ctypes.c_void_p(L.capref_plonk_preprocess(_p(srs_bases), ctypes.c_size_t(n), ctypes.c_size_t(num_inputs),
+                                                           _p(selectors), _p(sigma_evals), _p(self.vk_comms)))
+
+    def prove(self, wires: np.ndarray, pub_inputs: np.ndarray, blinders: np.ndarray, ext_msg: bytes | None = None):
+        """all Montgomery; returns (rc, comms (13,8), evals (10,4))."""
+        L = lib()
+        wires = np.ascontiguousarray(wires, dtype=np.uint64).reshape(-1)
+        pub = np.ascontiguousarray(pub_inputs, dtype=np.uint64).reshape(-1)
+        if pub.size == 0:
+            pub = np.zeros(4, dtype=np.uint64)
+        bl = np.ascontiguousarray(blinders, dtype=np.uint64).reshape(-1)
+        out = np.zeros(PROOF_WORDS, dtype=np.uint64)
+        msg = ext_msg or b""
+        buf = (ctypes.c_uint8 * max(len(msg), 1)).from_buffer_copy(msg + (b"\0" if not msg else b""))
+        rc = L.capref_plonk_prove(self.h, _p(wires), _p(pub), buf, ctypes.c_size_t(len(msg)), _p(bl), _p(out))
+        return rc, out[:104].reshape(13, 8).copy(), out[104:].reshape(10, 4).copy()
+
+    def free(self):
+        if self.h:
+            lib().capref_plonk_free(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def keccak256(data: bytes) -> bytes:
+    out = (ctypes.c_uint8 * 32)()
+    buf = (ctypes.c_uint8 * max(len(data), 1)).from_buffer_copy(data + (b"\0" if not data else b""))
+    lib().capref_keccak256(buf, ctypes.c_size_t(len(data)), out)
+    return bytes(out)

@@ -1,0 +1,50 @@
+"""Host-side workload synthesis (cap_amd/bench_utils.py) produces satisfiable TurboPlonk instances with the
+note shapes the reference pins (src/utils/mod.rs:136-193).  (`-m "not gpu"`)"""
+import numpy as np
+import pytest
+
+from cap_amd import bench_utils as bu
+from cap_amd import parallel as par
+from oracle import bn254 as bn
+from oracle import plonk as pl
+
+
+def test_note_shapes_match_reference_pins():
+    # Transfer(2,2,depth 10) -> domain 32768; Mint(26) / Freeze(2,5) -> 16384 (src/utils/mod.rs:149-177)
+    assert bu.NOTE_SHAPES["transfer_2x2"] == (15, 27)
+    assert bu.NOTE_SHAPES["mint"][0] == 14 and bu.NOTE_SHAPES["freeze_2"][0] == 14
+    assert bu.K == pl.K and bu.R == bn.R
+
+
+@pytest.mark.parametrize("log_n,nin", [(3, 1), (5, 3), (7, 0), (9, 27)])
+def test_synthetic_circuit_is_satisfiable(log_n, nin):
+    sc = bu.synthetic_circuit(log_n, nin, seed=log_n)
+    for wseed in (1, 2):
+        w, pubs = sc.witness(wseed)
+        assert len(pubs) == nin
+        pl.check_circuit_satisfiability(pl.Circuit(n=sc.n, num_inputs=nin, selectors=sc.selectors, sigma=sc.sigma,
+                                                   wires=w, pub_inputs=pubs))
+    # every selector column is exercised and the permutation is non-trivial
+    assert all(any(col) for col in sc.selectors)
+    om = bn.root_of_unity(log_n)
+    ident = sum(1 for i in range(5) for j in range(sc.n) if sc.sigma[i][j] == bu.K[i] * pow(om, j, bn.R) % bn.R)
+    assert ident < 5 * sc.n // 2
+
+
+def test_mont_array_roundtrip():
+    vals = [0, 1, bn.R - 1, 12345678901234567890123]
+    a = bu.to_mont_array(vals)
+    assert a.shape == (4, 4) and a.dtype == np.uint64
+    assert bu.from_mont_array(a) == vals
+    assert [bn.from_mont(int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192, bn.R) for r in a] == vals
+
+
+def test_shard_ranges_partition():
+    for n in (0, 1, 7, 1 << 17, (1 << 24) + 3):
+        for world in (1, 2, 3, 8):
+            spans = [par.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert sorted(sum((par.shard_proofs(64, r, 8) for r in range(8)), [])) == list(range(64))

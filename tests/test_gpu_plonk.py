@@ -1,0 +1,132 @@
+"""Parity tests for the device prover (A6 / K7-K9): every element of the proof - 13 commitments in affine
+form and 10 evaluations - must equal the oracle's on the same inputs, bit for bit."""
+import numpy as np
+import pytest
+
+from cap_amd import bench_utils as bu
+from cap_amd import proof as capproof
+from oracle import bn254 as bn
+from oracle import capref as cr
+from oracle import plonk as pl
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+def gpu_key(cg, tau, sc):
+    h = cg.srs_generate(tau, sc.n + 3)
+    pkh, vk = cg.plonk_preprocess(h, sc.n, sc.num_inputs, sc.selectors_mont(), sc.sigma_mont())
+    return h, pkh, vk
+
+
+def pubs_arr(pubs):
+    return bu.to_mont_array(pubs) if pubs else np.zeros((0, 4), np.uint64)
+
+
+def test_golden_proof_log5(cg, tau):
+    g = H.load_golden("proof_log5.json")
+    sc = bu.synthetic_circuit(g["log_n"], g["num_inputs"], seed=g["circuit_seed"])
+    w, pubs = sc.witness(g["witness_seed"])
+    bl = bu.blinders(g["blinder_seed"])
+    h, pkh, vk = gpu_key(cg, tau, sc)
+    vk_pts = [cr.affine_to_ints(np.ctypeslib.as_array(vk.selector_comms[i])) for i in range(13)] + \
+             [cr.affine_to_ints(np.ctypeslib.as_array(vk.sigma_comms[i])) for i in range(5)]
+    assert vk_pts == [H.unhex_pt(p) for p in g["selector_comms"] + g["sigma_comms"]]
+    assert vk.domain_size == sc.n and vk.num_inputs == g["num_inputs"]
+    pr = cg.plonk_prove_batch(pkh, sc.wires_mont(w)[None], pubs_arr(pubs)[None], bu.to_mont_array(bl)[None],
+                              g["ext_msg"].encode(), 1)[0]
+    pts, ev = H.proof_points(pr)
+    exp_pts = [H.unhex_pt(p) for p in g["wires_poly_comms"]] + [H.unhex_pt(g["prod_perm_poly_comm"])] + \
+        [H.unhex_pt(p) for p in g["split_quot_poly_comms"]] + [H.unhex_pt(g["opening_proof"]),
+                                                              H.unhex_pt(g["shifted_opening_proof"])]
+    assert pts == exp_pts
+    assert ev == [int(x, 16) for x in g["wires_evals"] + g["wire_sigma_evals"] + [g["perm_next_eval"]]]
+    # the oracle's verifier accepts the device proof, and rejects it under a wrong public input
+    o = pl.Proof(pts[0:5], pts[5], pts[6:11], pts[11], pts[12], ev[0:5], ev[5:9], ev[9])
+    sel, sig = vk_pts[:13], vk_pts[13:]
+    assert pl.verify(sc.n, sc.num_inputs, sel, sig, pubs, o, tau, ext_msg=g["ext_msg"].encode())
+    bad = list(pubs); bad[0] = (bad[0] + 1) % bn.R
+    assert not pl.verify(sc.n, sc.num_inputs, sel, sig, bad, o, tau, ext_msg=g["ext_msg"].encode())
+    cg.plonk_free_key(pkh)
+    cg.srs_free(h)
+
+
+@pytest.mark.parametrize("log_n,nin,P", [(4, 1, 1), (6, 0, 3), (9, 27, 2), (11, 5, 4)])
+def test_batch_vs_c_oracle(cg, tau, log_n, nin, P):
+    sc = bu.synthetic_circuit(log_n, nin, seed=log_n)
+    h, pkh, vk = gpu_key(cg, tau, sc)
+    key = cr.PlonkKey(cg.srs_download(h, 0, sc.n + 3), sc.n, nin, sc.selectors_mont(), sc.sigma_mont())
+    ws, ps, bls = [], [], []
+    for p in range(P):
+        w, pubs = sc.witness(100 + p)
+        ws.append(sc.wires_mont(w)); ps.append(pubs_arr(pubs)); bls.append(bu.to_mont_array(bu.blinders(200 + p)))
+    msg = b"txn-memo-ver-key" if log_n != 6 else None
+    proofs = cg.plonk_prove_batch(pkh, np.stack(ws), np.stack(ps), np.stack(bls), msg, P)
+    for p in range(P):
+        rc, comms, evals = key.prove(ws[p], ps[p], bls[p], msg)
+        assert rc == 0
+        assert H.proof_points(proofs[p]) == H.cref_proof_points(comms, evals), f"proof {p}"
+    # the host-side API mirror gives the same object
+    pk = capproof.ProvingKey(pkh, sc.n, nin, capproof.UniversalSrs(h, sc.n + 2))
+    single = capproof.prove(pk, ws[0], ps[0], bls[0], msg)
+    assert H.proof_points(single) == H.proof_points(proofs[0])
+    cg.plonk_free_key(pkh)
+    cg.srs_free(h)
+
+
+def test_transfer_note_shape_full_size(cg, tau):
+    """BASELINE config 3: the full 2-in/2-out transfer-note proof (n = 2^15, 27 public inputs, 13 MSM of
+    ~n+2 points, 7 iNTT(n), 26 coset (i)NTT(8n)) on one MI355X, bit-exact vs the CPU restatement."""
+    sc = bu.note_circuit("transfer_2x2", seed=2)
+    assert sc.n == 1 << 15 and sc.num_inputs == 27
+    h, pkh, vk = gpu_key(cg, tau, sc)
+    key = cr.PlonkKey(cg.srs_download(h, 0, sc.n + 3), sc.n, 27, sc.selectors_mont(), sc.sigma_mont())
+    vk_c = [cr.affine_to_ints(c) for c in key.vk_comms]
+    vk_g = [cr.affine_to_ints(np.ctypeslib.as_array(vk.selector_comms[i])) for i in range(13)] + \
+           [cr.affine_to_ints(np.ctypeslib.as_array(vk.sigma_comms[i])) for i in range(5)]
+    assert vk_g == vk_c
+    w, pubs = sc.witness(3)
+    wm, pm, bm = sc.wires_mont(w), pubs_arr(pubs), bu.to_mont_array(bu.blinders(3))
+    w2, pubs2 = sc.witness(4)
+    proofs = cg.plonk_prove_batch(pkh, np.stack([wm, sc.wires_mont(w2)]), np.stack([pm, pubs_arr(pubs2)]),
+                                  np.stack([bm, bu.to_mont_array(bu.blinders(4))]), b"memo", 2)
+    rc, comms, evals = key.prove(wm, pm, bm, b"memo")
+    assert rc == 0
+    assert H.proof_points(proofs[0]) == H.cref_proof_points(comms, evals)
+    assert H.proof_points(proofs[1]) != H.proof_points(proofs[0])
+    cg.plonk_free_key(pkh)
+    cg.srs_free(h)
+
+
+def test_unsatisfied_witness_and_bad_arguments(cg, tau):
+    sc = bu.synthetic_circuit(6, 2, seed=9)
+    h, pkh, vk = gpu_key(cg, tau, sc)
+    w, pubs = sc.witness(1)
+    wm = sc.wires_mont(w)
+    bl = bu.to_mont_array(bu.blinders(1))
+    bad = wm.copy(); bad[4, 20, 0] ^= 1
+    with pytest.raises(cg.CapGpuError) as e:
+        cg.plonk_prove_batch(pkh, bad[None], pubs_arr(pubs)[None], bl[None], None, 1)
+    assert e.value.code == -7
+    with pytest.raises(capproof.TxnApiError) as e2:      # reference: TxnApiError::FailedSnark
+        capproof.prove(capproof.ProvingKey(pkh, sc.n, 2, capproof.UniversalSrs(h, sc.n + 2)), bad, pubs_arr(pubs), bl)
+    assert "FailedSnark" in str(e2.value)
+    with pytest.raises(cg.CapGpuError) as e:             # wrong number of public inputs
+        cg.plonk_prove_batch(pkh, wm[None], pubs_arr(pubs[:1])[None], bl[None], None, 1)
+    assert e.value.code == -1
+    with pytest.raises(cg.CapGpuError) as e:             # unknown key
+        cg.plonk_prove_batch(424242, wm[None], pubs_arr(pubs)[None], bl[None], None, 1)
+    assert e.value.code == -4
+    small = cg.srs_generate(tau, 10)                      # SRS too small for the circuit
+    with pytest.raises(cg.CapGpuError) as e:
+        cg.plonk_preprocess(small, sc.n, 2, sc.selectors_mont(), sc.sigma_mont())
+    assert e.value.code == -1
+    # a good proof still goes through after the failures (no poisoned state)
+    ok = cg.plonk_prove_batch(pkh, wm[None], pubs_arr(pubs)[None], bl[None], None, 1)[0]
+    key = cr.PlonkKey(cg.srs_download(h, 0, sc.n + 3), sc.n, 2, sc.selectors_mont(), sc.sigma_mont())
+    rc, comms, evals = key.prove(wm, pubs_arr(pubs), bl, None)
+    assert H.proof_points(ok) == H.cref_proof_points(comms, evals)
+    for x in (small,):
+        cg.srs_free(x)
+    cg.plonk_free_key(pkh)
+    cg.srs_free(h)
