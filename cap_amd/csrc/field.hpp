@@ -187,6 +187,18 @@ struct Fp {
   // -- Montgomery multiplication (CIOS, 32-bit limbs) -----------------------
   // r = a * b * 2^-256 mod p, inputs < p, output < p.
   static CAP_HD fe mul(const fe& a, const fe& b) {
+#if defined(CAP_NOINLINE_MUL) && defined(__HIP_DEVICE_COMPILE__)
+    return mul_call(a, b);
+#else
+    return mul_inline(a, b);
+#endif
+  }
+#if defined(__HIPCC__) || defined(__HIP__)
+  // One shared copy of the multiplication per kernel: keeps the hot loops of the curve kernels inside the
+  // instruction cache (an inlined mixed addition is ~35 KB of code).
+  static __device__ __noinline__ fe mul_call(const fe& a, const fe& b) { return mul_inline(a, b); }
+#endif
+  static CAP_HD fe mul_inline(const fe& a, const fe& b) {
     // Row i: 8 independent 32x32+32 products (v_mad_u64_u32), then one
     // add-with-carry chain (v_addc_co_u32) folds hi(r[j-1]) into lo(r[j]).
     uint32_t t[9];

@@ -3,7 +3,8 @@
 //   msm_digits_hist   K3  scalar -> signed base-2^c digits, histogram rank per (digit, bucket)
 //   msm_scan          K4  exclusive scan of bucket counts
 //   msm_scatter       K4  counting-sort scatter of table indices into bucket lists
-//   msm_accumulate    K5  S lanes per bucket: mixed adds of gathered 64 B points, shuffle merge
+//   msm_accumulate    K5  one thread per work item (<= 32 list entries): mixed adds of gathered 64 B points
+//   msm_combine       K5  bucket = sum of its work items
 //   msm_reduce_bits   K6  T_b = sum of buckets whose weight has bit b set (log-depth trees)
 //   msm_reduce_final  K6  sum_b 2^b T_b  ->  one Jacobian point per MSM
 #include "msm.hpp"
@@ -19,6 +20,7 @@ namespace {
 constexpr uint32_t kSkip = 0xFFFFFFFFu;
 constexpr int kThreads = 256;
 constexpr uint32_t kReduceChunk = 1024;  // buckets per msm_reduce_bits workgroup
+constexpr uint32_t kItemLen = 32;        // list entries per msm_accumulate work item
 
 __device__ __forceinline__ fe shfl_down_fe(const fe& a, int d) {
   fe r;
@@ -97,8 +99,11 @@ __global__ __launch_bounds__(kThreads) void msm_digits_hist(const fe* __restrict
 }
 
 // ---- K4: exclusive scan, one workgroup per batch entry ------------------------------------------
+// ITEMS == 0: scans the bucket counts (-> list offsets).  ITEMS == 1: scans ceil(count / kItemLen), the number of
+// work items of each bucket (-> item offsets inside the batch entry); the per-entry total goes to totals[].
+template <int ITEMS>
 __global__ __launch_bounds__(1024) void msm_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
-                                                 uint32_t nb) {
+                                                 uint32_t nb, uint32_t* __restrict__ totals) {
   __shared__ uint32_t sh[1024];
   __shared__ uint32_t carry_s;
   const uint32_t* cnt = counts + (size_t)blockIdx.x * nb;
@@ -108,6 +113,7 @@ __global__ __launch_bounds__(1024) void msm_scan(const uint32_t* __restrict__ co
   for (uint32_t base = 0; base < nb; base += 1024) {
     uint32_t idx = base + threadIdx.x;
     uint32_t v = idx < nb ? cnt[idx] : 0;
+    if (ITEMS) v = (v + kItemLen - 1) / kItemLen;
     sh[threadIdx.x] = v;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
@@ -123,6 +129,30 @@ __global__ __launch_bounds__(1024) void msm_scan(const uint32_t* __restrict__ co
     if (threadIdx.x == 1023) carry_s = carry + incl;
     __syncthreads();
   }
+  if (totals && threadIdx.x == 0) totals[blockIdx.x] = carry_s;
+}
+
+// item_base[b] = sum of totals[0..b), item_base[batch] = number of work items of the whole launch
+__global__ void msm_item_bases(const uint32_t* __restrict__ totals, uint32_t batch, uint32_t* __restrict__ item_base) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  uint32_t acc = 0;
+  for (uint32_t b = 0; b < batch; b++) {
+    item_base[b] = acc;
+    acc += totals[b];
+  }
+  item_base[batch] = acc;
+}
+
+// item -> global bucket map
+__global__ __launch_bounds__(kThreads) void msm_fill_items(const uint32_t* __restrict__ counts,
+                                                           const uint32_t* __restrict__ item_off,
+                                                           const uint32_t* __restrict__ item_base, uint32_t half,
+                                                           uint32_t total_buckets, uint32_t* __restrict__ item_bucket) {
+  uint32_t gb = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gb >= total_buckets) return;
+  uint32_t items = (counts[gb] + kItemLen - 1) / kItemLen;
+  uint32_t first = item_base[gb / half] + item_off[gb];
+  for (uint32_t j = 0; j < items; j++) item_bucket[first + j] = gb;
 }
 
 __global__ __launch_bounds__(kThreads) void msm_scatter(const uint32_t* __restrict__ keys,
@@ -148,35 +178,52 @@ __global__ __launch_bounds__(kThreads) void msm_scatter(const uint32_t* __restri
 }
 
 // ---- K5: bucket accumulation --------------------------------------------------------------------
-// thread -> (global bucket, slice); slices of one bucket are adjacent lanes of one wavefront.
+// A bucket's list is cut into work items of at most kItemLen entries; one thread per item.  Every lane of a
+// wavefront therefore runs (almost) the same number of mixed additions whatever the bucket sizes are - a
+// thread-per-bucket mapping loses ~40 % to wave quantisation and the Poisson spread of list lengths, and
+// degrades without bound on skewed scalars (one giant bucket = one serial chain).
 __global__ __launch_bounds__(kThreads) void msm_accumulate(const g1_affine* __restrict__ ext,
                                                            const uint32_t* __restrict__ sorted,
                                                            const uint32_t* __restrict__ counts,
-                                                           const uint32_t* __restrict__ offsets, size_t per,
-                                                           uint32_t half, uint32_t total_buckets, uint32_t log_s,
-                                                           g1_xyzz* __restrict__ buckets) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  uint32_t gb = (uint32_t)(t >> log_s);
-  uint32_t slice = (uint32_t)t & ((1u << log_s) - 1);
-  const uint32_t S = 1u << log_s;
+                                                           const uint32_t* __restrict__ offsets,
+                                                           const uint32_t* __restrict__ item_off,
+                                                           const uint32_t* __restrict__ item_base,
+                                                           const uint32_t* __restrict__ item_bucket, size_t per,
+                                                           uint32_t half, uint32_t batch,
+                                                           g1_xyzz* __restrict__ item_pts) {
+  uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
+  if (it >= item_base[batch]) return;
+  uint32_t gb = item_bucket[it];
+  uint32_t b = gb / half;
+  uint32_t j = it - (item_base[b] + item_off[gb]);
+  uint32_t cnt = counts[gb];
+  uint32_t lo = j * kItemLen, hi = lo + kItemLen;
+  if (hi > cnt) hi = cnt;
+  const uint32_t* lst = sorted + (size_t)b * per + offsets[gb];
   g1_xyzz acc = G1::inf();
-  bool live = gb < total_buckets;
-  if (live) {
-    uint32_t b = gb / half;
-    uint32_t cnt = counts[gb];
-    const uint32_t* lst = sorted + (size_t)b * per + offsets[gb];
-    for (uint32_t e = slice; e < cnt; e += S) {
-      uint32_t v = lst[e];
-      g1_affine p = ext[v & 0x7FFFFFFFu];
-      if (v >> 31) p.y = Fq::neg(p.y);
-      acc = G1::add_mixed(acc, p);
-    }
+  for (uint32_t e = lo; e < hi; e++) {
+    uint32_t v = lst[e];
+    g1_affine p = ext[v & 0x7FFFFFFFu];
+    if (v >> 31) p.y = Fq::neg(p.y);
+    acc = G1::add_mixed(acc, p);
   }
-  for (uint32_t d = S >> 1; d >= 1; d >>= 1) {
-    g1_xyzz o = shfl_down_pt(acc, (int)d);
-    if (slice < d) acc = G1::add(acc, o);
-  }
-  if (live && slice == 0) buckets[gb] = acc;
+  item_pts[it] = acc;
+}
+
+// bucket = sum of its work items (a handful of full additions per bucket)
+__global__ __launch_bounds__(kThreads) void msm_combine(const g1_xyzz* __restrict__ item_pts,
+                                                        const uint32_t* __restrict__ counts,
+                                                        const uint32_t* __restrict__ item_off,
+                                                        const uint32_t* __restrict__ item_base, uint32_t half,
+                                                        uint32_t total_buckets, g1_xyzz* __restrict__ buckets) {
+  uint32_t gb = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gb >= total_buckets) return;
+  uint32_t items = (counts[gb] + kItemLen - 1) / kItemLen;
+  uint32_t first = item_base[gb / half] + item_off[gb];
+  g1_xyzz acc = G1::inf();
+  if (items) acc = item_pts[first];
+  for (uint32_t j = 1; j < items; j++) acc = G1::add(acc, item_pts[first + j]);
+  buckets[gb] = acc;
 }
 
 // ---- K6a: bit-plane sums ---------------------------------------------------------------------------
@@ -231,7 +278,8 @@ __global__ __launch_bounds__(64) void msm_reduce_final(const g1_xyzz* __restrict
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
-  size_t counts, offsets, keys, ranks, sorted, buckets, partial, total;
+  size_t counts, offsets, keys, ranks, sorted, buckets, partial, item_off, item_base, totals, item_bucket, item_pts,
+      max_items, total;
 };
 WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t batch) {
   WsLayout L{};
@@ -246,6 +294,12 @@ WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t batch) {
   L.sorted = o;  o = align_up(o + sizeof(uint32_t) * per * batch, 256);
   L.buckets = o; o = align_up(o + sizeof(g1_xyzz) * half * batch, 256);
   L.partial = o; o = align_up(o + sizeof(g1_xyzz) * c * chunks * batch, 256);
+  L.max_items = per * batch / kItemLen + half * batch;  // sum ceil(cnt/L) <= entries/L + non-empty buckets
+  L.item_off = o;    o = align_up(o + sizeof(uint32_t) * half * batch, 256);
+  L.item_base = o;   o = align_up(o + sizeof(uint32_t) * (batch + 1), 256);
+  L.totals = o;      o = align_up(o + sizeof(uint32_t) * batch, 256);
+  L.item_bucket = o; o = align_up(o + sizeof(uint32_t) * L.max_items, 256);
+  L.item_pts = o;    o = align_up(o + sizeof(g1_xyzz) * L.max_items, 256);
   L.total = o;
   return L;
 }
@@ -323,23 +377,33 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
     launch("msm_digits_hist", msm_digits_hist, dim3((unsigned)((nt + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
                        d_scalars, outer_stride, inner, inner_stride, n, batch, montgomery, c, W, counts, keys, ranks);
   }
-  launch("msm_scan", msm_scan, dim3(batch), dim3(1024), 0, stream, counts, offsets, half);
+  launch("msm_scan", msm_scan<0>, dim3(batch), dim3(1024), 0, stream, (const uint32_t*)counts, offsets, half,
+         (uint32_t*)nullptr);
   if (n > 0) {
     size_t ne = per * batch;
     launch("msm_scatter", msm_scatter, dim3((unsigned)((ne + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, keys,
                        ranks, offsets, n, batch, c, W, bases.n, offset, sorted);
   }
-  // lanes per bucket: aim at >= ~128K lanes in flight, never more than the mean list length / 2
-  uint32_t log_s = 0;
-  {
-    size_t mean = total_buckets ? (per * batch) / total_buckets : 0;
-    while (log_s < 6 && ((size_t)total_buckets << log_s) < (size_t)131072 && ((size_t)2 << log_s) <= mean) log_s++;
+  uint32_t* item_off = reinterpret_cast<uint32_t*>(base + L.item_off);
+  uint32_t* item_base = reinterpret_cast<uint32_t*>(base + L.item_base);
+  uint32_t* totals = reinterpret_cast<uint32_t*>(base + L.totals);
+  uint32_t* item_bucket = reinterpret_cast<uint32_t*>(base + L.item_bucket);
+  g1_xyzz* item_pts = reinterpret_cast<g1_xyzz*>(base + L.item_pts);
+  launch("msm_scan_items", msm_scan<1>, dim3(batch), dim3(1024), 0, stream, (const uint32_t*)counts, item_off, half,
+         totals);
+  launch("msm_item_bases", msm_item_bases, dim3(1), dim3(64), 0, stream, (const uint32_t*)totals, batch, item_base);
+  launch("msm_fill_items", msm_fill_items, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0, stream,
+         (const uint32_t*)counts, (const uint32_t*)item_off, (const uint32_t*)item_base, half, total_buckets,
+         item_bucket);
+  if (L.max_items > 0) {
+    launch("msm_accumulate", msm_accumulate, dim3((unsigned)((L.max_items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+           stream, bases.ext, (const uint32_t*)sorted, (const uint32_t*)counts, (const uint32_t*)offsets,
+           (const uint32_t*)item_off, (const uint32_t*)item_base, (const uint32_t*)item_bucket, per, half, batch,
+           item_pts);
   }
-  {
-    size_t nt = (size_t)total_buckets << log_s;
-    launch("msm_accumulate", msm_accumulate, dim3((unsigned)((nt + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
-                       bases.ext, sorted, counts, offsets, per, half, total_buckets, log_s, buckets);
-  }
+  launch("msm_combine", msm_combine, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0, stream,
+         (const g1_xyzz*)item_pts, (const uint32_t*)counts, (const uint32_t*)item_off, (const uint32_t*)item_base, half,
+         total_buckets, buckets);
   launch("msm_reduce_bits", msm_reduce_bits, dim3(chunks, c, batch), dim3(kThreads), 0, stream, buckets, half, c, chunks,
                      partial);
   launch("msm_reduce_final", msm_reduce_final, dim3(batch), dim3(64), 0, stream, partial, c, chunks, d_out);

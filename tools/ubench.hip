@@ -84,7 +84,7 @@ template <int OP>
 void run_inst(uint32_t* d_out, int waves_per_simd) {
   int block = 256;                      // 4 waves: one per SIMD
   int grid = 256 * waves_per_simd;      // 256 CUs
-  int iters = 4096;
+  int iters = 262144;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   hipLaunchKernelGGL(k_inst<OP>, dim3(grid), dim3(block), 0, 0, d_out, 64);
