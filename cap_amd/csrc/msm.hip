@@ -19,7 +19,8 @@ namespace {
 
 constexpr uint32_t kSkip = 0xFFFFFFFFu;
 constexpr int kThreads = 256;
-constexpr uint32_t kReduceChunk = 1024;  // buckets per msm_reduce_bits workgroup
+constexpr uint32_t kReduceChunk = 4096;  // buckets per msm_reduce_bits workgroup
+constexpr uint32_t kDigitTile = 2048;    // scalars per msm_digits_local workgroup
 constexpr uint32_t kItemLen = 32;        // list entries per msm_accumulate work item
 
 __device__ __forceinline__ fe shfl_down_fe(const fe& a, int d) {
@@ -98,23 +99,125 @@ __global__ __launch_bounds__(kThreads) void msm_digits_hist(const fe* __restrict
   }
 }
 
+// K3, LDS form (used whenever the bucket set fits LDS): a workgroup owns a tile of kDigitTile scalars of one batch
+// entry, histograms their digits in LDS (rank inside the tile = returned LDS atomic) and writes one row of the
+// [bucket][tile] table.  A scan of that table (bucket-major) then gives every (bucket, tile) its list position:
+// no global atomics, and the sorted order - hence the bit pattern of the Jacobian result - is deterministic.
+__global__ __launch_bounds__(kThreads) void msm_digits_local(const fe* __restrict__ scalars, size_t outer_stride,
+                                                             uint32_t inner, size_t inner_stride, size_t n,
+                                                             int montgomery, uint32_t c, uint32_t windows,
+                                                             uint32_t nblk, uint32_t* __restrict__ table,
+                                                             uint32_t* __restrict__ keys,
+                                                             uint32_t* __restrict__ ranks) {
+  extern __shared__ uint32_t hist[];
+  const uint32_t b = blockIdx.y, blk = blockIdx.x;
+  const uint32_t half = 1u << (c - 1);
+  const uint32_t mask = (1u << c) - 1;
+  for (uint32_t j = threadIdx.x; j < half; j += kThreads) hist[j] = 0;
+  __syncthreads();
+  const fe* sc = scalars + (size_t)(b / inner) * outer_stride + (size_t)(b % inner) * inner_stride;
+  for (uint32_t q = 0; q < kDigitTile / kThreads; q++) {
+    size_t i = (size_t)blk * kDigitTile + q * kThreads + threadIdx.x;
+    if (i >= n) break;
+    fe k = sc[i];
+    if (montgomery) k = Fr::from_mont(k);
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < windows; w++) {
+      uint32_t bit = w * c;
+      uint32_t limb = bit >> 5, off = bit & 31;
+      uint32_t v = 0;
+      if (limb < 8) {
+        uint64_t two = (uint64_t)k.v[limb] | (limb + 1 < 8 ? ((uint64_t)k.v[limb + 1] << 32) : 0);
+        v = (uint32_t)(two >> off) & mask;
+      }
+      v += carry;
+      uint32_t neg = 0;
+      if (v > half) {
+        v = (1u << c) - v;
+        neg = 1;
+        carry = 1;
+      } else {
+        carry = 0;
+      }
+      size_t e = ((size_t)b * windows + w) * n + i;
+      if (v == 0) {
+        keys[e] = kSkip;
+      } else {
+        uint32_t bucket = v - 1;
+        uint32_t r = atomicAdd(&hist[bucket], 1u);
+        keys[e] = bucket | (neg << 31);
+        ranks[e] = r;
+      }
+    }
+  }
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < half; j += kThreads) table[((size_t)b * half + j) * nblk + blk] = hist[j];
+}
+
+// bucket list ranges from the scanned [bucket][tile] table
+__global__ __launch_bounds__(kThreads) void msm_bucket_ranges(const uint32_t* __restrict__ table,
+                                                              const uint32_t* __restrict__ off2, uint32_t half,
+                                                              uint32_t nblk, uint32_t total_buckets,
+                                                              uint32_t* __restrict__ counts,
+                                                              uint32_t* __restrict__ offsets) {
+  uint32_t gb = blockIdx.x * blockDim.x + threadIdx.x;
+  if (gb >= total_buckets) return;
+  uint32_t bucket = gb % half;
+  size_t row = (size_t)gb * nblk;
+  uint32_t o = off2[row];
+  uint32_t next = bucket + 1 < half ? off2[row + nblk] : off2[row + nblk - 1] + table[row + nblk - 1];
+  offsets[gb] = o;
+  counts[gb] = next - o;
+}
+
+__global__ __launch_bounds__(kThreads) void msm_scatter_local(const uint32_t* __restrict__ keys,
+                                                              const uint32_t* __restrict__ ranks,
+                                                              const uint32_t* __restrict__ off2, size_t n,
+                                                              uint32_t batch, uint32_t c, uint32_t windows,
+                                                              uint32_t nblk, size_t srs_n, size_t base_offset,
+                                                              uint32_t* __restrict__ sorted) {
+  size_t per = (size_t)windows * n;
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= per * batch) return;
+  uint32_t key = keys[e];
+  if (key == kSkip) return;
+  uint32_t b = (uint32_t)(e / per);
+  size_t rem = e - (size_t)b * per;
+  uint32_t w = (uint32_t)(rem / n);
+  size_t i = rem - (size_t)w * n;
+  const uint32_t half = 1u << (c - 1);
+  uint32_t bucket = key & 0x7FFFFFFFu;
+  uint32_t blk = (uint32_t)(i / kDigitTile);
+  uint32_t pos = off2[((size_t)b * half + bucket) * nblk + blk] + ranks[e];
+  uint32_t tidx = (uint32_t)((size_t)w * srs_n + base_offset + i);
+  sorted[(size_t)b * per + pos] = tidx | (key & 0x80000000u);
+}
+
 // ---- K4: exclusive scan, one workgroup per batch entry ------------------------------------------
 // ITEMS == 0: scans the bucket counts (-> list offsets).  ITEMS == 1: scans ceil(count / kItemLen), the number of
 // work items of each bucket (-> item offsets inside the batch entry); the per-entry total goes to totals[].
 template <int ITEMS>
 __global__ __launch_bounds__(1024) void msm_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
                                                  uint32_t nb, uint32_t* __restrict__ totals) {
+  constexpr uint32_t E = 8;  // consecutive elements per thread
   __shared__ uint32_t sh[1024];
   __shared__ uint32_t carry_s;
   const uint32_t* cnt = counts + (size_t)blockIdx.x * nb;
   uint32_t* off = offsets + (size_t)blockIdx.x * nb;
   if (threadIdx.x == 0) carry_s = 0;
   __syncthreads();
-  for (uint32_t base = 0; base < nb; base += 1024) {
-    uint32_t idx = base + threadIdx.x;
-    uint32_t v = idx < nb ? cnt[idx] : 0;
-    if (ITEMS) v = (v + kItemLen - 1) / kItemLen;
-    sh[threadIdx.x] = v;
+  for (uint32_t base = 0; base < nb; base += 1024 * E) {
+    uint32_t idx0 = base + threadIdx.x * E;
+    uint32_t v[E];
+    uint32_t run = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < E; t++) {
+      uint32_t x = idx0 + t < nb ? cnt[idx0 + t] : 0;
+      if (ITEMS) x = (x + kItemLen - 1) / kItemLen;
+      v[t] = run;
+      run += x;
+    }
+    sh[threadIdx.x] = run;
     __syncthreads();
     for (uint32_t d = 1; d < 1024; d <<= 1) {
       uint32_t add = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
@@ -124,7 +227,10 @@ __global__ __launch_bounds__(1024) void msm_scan(const uint32_t* __restrict__ co
     }
     uint32_t incl = sh[threadIdx.x];
     uint32_t carry = carry_s;
-    if (idx < nb) off[idx] = carry + incl - v;
+    uint32_t pre = carry + incl - run;
+#pragma unroll
+    for (uint32_t t = 0; t < E; t++)
+      if (idx0 + t < nb) off[idx0 + t] = pre + v[t];
     __syncthreads();
     if (threadIdx.x == 1023) carry_s = carry + incl;
     __syncthreads();
@@ -279,8 +385,13 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
   size_t counts, offsets, keys, ranks, sorted, buckets, partial, item_off, item_base, totals, item_bucket, item_pts,
-      max_items, total;
+      max_items, table, off2, nblk, total;
 };
+bool use_local_digits(uint32_t c, size_t n, uint32_t batch) {
+  size_t half = (size_t)1 << (c - 1);
+  size_t nblk = (n + kDigitTile - 1) / kDigitTile;
+  return half <= 8192 && n > 0 && half * nblk * batch <= ((size_t)1 << 26);
+}
 WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t batch) {
   WsLayout L{};
   size_t half = (size_t)1 << (c - 1);
@@ -300,6 +411,9 @@ WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t batch) {
   L.totals = o;      o = align_up(o + sizeof(uint32_t) * batch, 256);
   L.item_bucket = o; o = align_up(o + sizeof(uint32_t) * L.max_items, 256);
   L.item_pts = o;    o = align_up(o + sizeof(g1_xyzz) * L.max_items, 256);
+  L.nblk = use_local_digits(c, n, batch) ? (n + kDigitTile - 1) / kDigitTile : 0;
+  L.table = o;       o = align_up(o + sizeof(uint32_t) * half * L.nblk * batch, 256);
+  L.off2 = o;        o = align_up(o + sizeof(uint32_t) * half * L.nblk * batch, 256);
   L.total = o;
   return L;
 }
@@ -370,19 +484,35 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
   const uint32_t chunks = (half + kReduceChunk - 1) / kReduceChunk;
   const uint32_t total_buckets = half * batch;
 
-  hipError_t e = hipMemsetAsync(counts, 0, sizeof(uint32_t) * (size_t)half * batch, stream);
-  if (e != hipSuccess) return (int)e;
-  if (n > 0) {
-    size_t nt = n * batch;
-    launch("msm_digits_hist", msm_digits_hist, dim3((unsigned)((nt + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
-                       d_scalars, outer_stride, inner, inner_stride, n, batch, montgomery, c, W, counts, keys, ranks);
-  }
-  launch("msm_scan", msm_scan<0>, dim3(batch), dim3(1024), 0, stream, (const uint32_t*)counts, offsets, half,
-         (uint32_t*)nullptr);
-  if (n > 0) {
+  if (L.nblk) {
+    const uint32_t nblk = (uint32_t)L.nblk;
+    uint32_t* table = reinterpret_cast<uint32_t*>(base + L.table);
+    uint32_t* off2 = reinterpret_cast<uint32_t*>(base + L.off2);
+    launch("msm_digits_local", msm_digits_local, dim3(nblk, batch), dim3(kThreads), sizeof(uint32_t) * half, stream,
+           d_scalars, outer_stride, inner, inner_stride, n, montgomery, c, W, nblk, table, keys, ranks);
+    launch("msm_scan", msm_scan<0>, dim3(batch), dim3(1024), 0, stream, (const uint32_t*)table, off2, half * nblk,
+           (uint32_t*)nullptr);
+    launch("msm_bucket_ranges", msm_bucket_ranges, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0,
+           stream, (const uint32_t*)table, (const uint32_t*)off2, half, nblk, total_buckets, counts, offsets);
     size_t ne = per * batch;
-    launch("msm_scatter", msm_scatter, dim3((unsigned)((ne + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream, keys,
-                       ranks, offsets, n, batch, c, W, bases.n, offset, sorted);
+    launch("msm_scatter", msm_scatter_local, dim3((unsigned)((ne + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
+           (const uint32_t*)keys, (const uint32_t*)ranks, (const uint32_t*)off2, n, batch, c, W, nblk, bases.n, offset,
+           sorted);
+  } else {
+    hipError_t e = hipMemsetAsync(counts, 0, sizeof(uint32_t) * (size_t)half * batch, stream);
+    if (e != hipSuccess) return (int)e;
+    if (n > 0) {
+      size_t nt = n * batch;
+      launch("msm_digits_hist", msm_digits_hist, dim3((unsigned)((nt + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+             stream, d_scalars, outer_stride, inner, inner_stride, n, batch, montgomery, c, W, counts, keys, ranks);
+    }
+    launch("msm_scan", msm_scan<0>, dim3(batch), dim3(1024), 0, stream, (const uint32_t*)counts, offsets, half,
+           (uint32_t*)nullptr);
+    if (n > 0) {
+      size_t ne = per * batch;
+      launch("msm_scatter", msm_scatter, dim3((unsigned)((ne + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
+             keys, ranks, offsets, n, batch, c, W, bases.n, offset, sorted);
+    }
   }
   uint32_t* item_off = reinterpret_cast<uint32_t*>(base + L.item_off);
   uint32_t* item_base = reinterpret_cast<uint32_t*>(base + L.item_base);
