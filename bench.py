@@ -37,6 +37,86 @@ def algorithmic_bytes_per_proof(n: int) -> dict:
             "total_bytes": 96 * msm_pairs + 64 * ntt_elems}
 
 
+P_FQ = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+
+
+def _weighted_sums(sc: np.ndarray, lo: int):
+    """sum k_i and sum (lo + i) k_i for canonical scalars (n, 4) uint64, exactly, with numpy on 16-bit pieces."""
+    n = sc.shape[0]
+    pieces = sc.view(np.uint16).reshape(n, 16).astype(np.uint64)
+    idx = (np.arange(n, dtype=np.uint64) + np.uint64(lo))
+    s0 = s1 = 0
+    for start in range(0, n, 1 << 18):
+        blk = pieces[start:start + (1 << 18)]
+        col = blk.sum(axis=0)
+        wcol = (blk * idx[start:start + (1 << 18), None]).sum(axis=0)
+        s0 += sum(int(col[j]) << (16 * j) for j in range(16))
+        s1 += sum(int(wcol[j]) << (16 * j) for j in range(16))
+    return s0, s1
+
+
+def msm_leg(cg, bu, torch, dist, rank, world, log_n, iters=5):
+    """Point-range-sharded MSM: bases P_i = [a + i b]G generated on each rank's GPU for its range,
+    scalars resident, local Pippenger, ONE exchange step (all-gather of a 96-byte Jacobian point per rank) and
+    G-1 group additions.  Checked against [sum k_i (a + i b)] G."""
+    from cap_amd import parallel as par
+    n_total = 1 << log_n
+    lo, hi = par.shard_range(n_total, rank, world)
+    n = hi - lo
+    a, b = 0x1234567890ABCDEF1234567890ABCDEF % bu.R, 0xFEDCBA0987654321FEDCBA % bu.R
+    srs = cg.srs_generate_affine_seq((a + lo * b) % bu.R, b, n)
+    rng = np.random.default_rng(5)
+    sc = rng.integers(0, 1 << 63, size=(n_total, 4), dtype=np.uint64)
+    sc[:, 3] &= np.uint64((1 << 61) - 1)          # < 2^253 < r : canonical
+    mine = np.ascontiguousarray(sc[lo:hi])
+    d_sc = cg.DevBuf.from_numpy(mine)
+    d_out = cg.DevBuf(96)
+    cg.msm_g1_dev(srs, d_sc, n, d_out=d_out)       # warm-up
+    cg.sync()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        cg.msm_g1_dev(srs, d_sc, n, d_out=d_out)
+    cg.sync()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / iters
+    part = d_out.to_numpy()
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        parts = par.all_gather_points(part, device="cuda")
+        total = cg.g1_sum(parts)
+    else:
+        total = part
+    ok = None
+    if rank == 0:
+        s0, s1 = _weighted_sums(sc, 0)
+        expect_scalar = (a * s0 + b * s1) % bu.R
+        h1 = cg.srs_generate_affine_seq(expect_scalar, 0, 1)
+        rinv = pow(1 << 256, -1, P_FQ)
+        ex, ey = [v * rinv % P_FQ for v in _words_to_ints(cg.srs_download(h1, 0, 1))]
+        cg.srs_free(h1)
+        X, Y, Z = [v * rinv % P_FQ for v in _words_to_ints(total)]
+        if Z == 0:
+            ok = False
+        else:
+            zi = pow(Z, -1, P_FQ)
+            ok = bool((X * zi * zi % P_FQ, Y * zi * zi * zi % P_FQ) == (ex, ey))
+    cg.srs_free(srs)
+    gbps = 96.0 * n_total / dt / 1e9
+    return {"log_n": log_n, "points": n_total, "ms": dt * 1e3, "GBps_algorithmic": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS,
+            "sharding": f"point range x{world} + all_gather(96 B) + g1_sum" if world > 1 else "single GPU",
+            "identity_check": ok}
+
+
+def _words_to_ints(words):
+    w = np.asarray(words, dtype=np.uint64).reshape(-1, 4)
+    return [int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192 for r in w]
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -46,6 +126,8 @@ def main():
     ap.add_argument("--log-n", type=int, default=15, help="evaluation domain (15: pinned for depth 10; 16: upper bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-schedule", action="store_true")
+    ap.add_argument("--no-msm", action="store_true")
+    ap.add_argument("--msm-log-n", type=int, default=20, help="size of the sharded MSM leg (24 = BASELINE config 5)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -129,6 +211,12 @@ def main():
         # K8: 26 arrays of 8n elements (25 in, 1 out) x 32 B
         "k_quotient": 26 * 8 * n * 32 * P,
     }
+    traffic_tab = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_r01.json")) as f:
+            traffic_tab = json.load(f).get("per_launch_bytes", {})
+    except OSError:
+        pass
     roofline = None
     if dom is not None:
         launches = stats[dom][1]
@@ -139,7 +227,9 @@ def main():
         else:
             bytes_per_launch, achieved = None, None
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                    "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": None,
+                    "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
+                    # HBM bytes per launch from the committed PMC pass (profiles/traffic_r01.json, batch 16) or null
+                    "traffic": traffic_tab.get(dom) if P == 16 and log_n == 15 else None,
                     "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
                     "share_of_kernel_time": kern_ms[dom] / sum(kern_ms.values())}
     top = sorted(kern_ms.items(), key=lambda kv: -kv[1])[:8]
@@ -194,6 +284,13 @@ def main():
                                          "restatement of the arkworks/jf-plonk algorithm (reference schedule, no asm)",
                                "gpu_proof_bit_exact_vs_cpu": parity}
         out["speedup_vs_cpu_1core"] = value / (1.0 / t_cpu)
+    # ---- MSM leg: BASELINE config 2 (2^17 points) on one GPU, and a point-range-sharded MSM over all ranks ------
+    if not args.no_msm:
+        legs = []
+        if world == 1:
+            legs.append(msm_leg(cg, bu, torch, dist, rank, world, 17))
+        legs.append(msm_leg(cg, bu, torch, dist, rank, world, args.msm_log_n))
+        out["msm"] = legs
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist is not None:

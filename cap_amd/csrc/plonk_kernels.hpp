@@ -223,7 +223,7 @@ __global__ __launch_bounds__(kThreads) void k_quotient(const fe* __restrict__ pk
   const fe pi = c[(size_t)6 * m + i];
   // gate constraint (spec eq. (1); selector order q_lc, q_mul, q_hash, q_o, q_c, q_ecc)
   fe acc = Fr::add(pkc[(size_t)11 * m + i], pi);
-#pragma unroll 1
+#pragma unroll
   for (int j = 0; j < 4; j++) {
     acc = Fr::add(acc, Fr::mul(pkc[(size_t)j * m + i], w[j]));
     fe w2 = Fr::sqr(w[j]);
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kThreads) void k_quotient(const fe* __restrict__ pk
   fe x = Fr::mul(qc.g, tw_m[i]);
   fe bx = Fr::mul(ch.beta, x);
   fe a = zx, b = zwx;
-#pragma unroll 1
+#pragma unroll
   for (int j = 0; j < NW; j++) {
     fe wg = Fr::add(w[j], ch.gamma);
     a = Fr::mul(a, Fr::add(wg, j == 0 ? bx : Fr::mul(qc.k[j], bx)));
