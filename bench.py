@@ -27,6 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+TRAFFIC_BATCH = 16       # batch size of the committed PMC pass (profiles/traffic_r01.json)
 
 
 def algorithmic_bytes_per_proof(n: int) -> dict:
@@ -122,10 +123,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="proofs per step per GPU")
+    ap.add_argument("--batch", type=int, default=64, help="proofs per step per GPU")
     ap.add_argument("--log-n", type=int, default=15, help="evaluation domain (15: pinned for depth 10; 16: upper bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-schedule", action="store_true")
+    ap.add_argument("--workload", default="transfer", choices=["transfer", "mixed64"],
+                    help="transfer: P identical-shape 2-in/2-out transfer proofs per GPU (weak scaling, the headline); "
+                         "mixed64: BASELINE config 4 - 32 transfer(2x3) + 13 mint + 19 freeze(3) proofs in total, "
+                         "proof i on rank i mod N (strong scaling)")
     ap.add_argument("--no-msm", action="store_true")
     ap.add_argument("--msm-log-n", type=int, default=20, help="size of the sharded MSM leg (24 = BASELINE config 5)")
     args = ap.parse_args()
@@ -150,19 +155,40 @@ def main():
     num_inputs = 27
     tau = bu.SplitMix64(0xCA9).field()
 
-    # ---- setup (untimed): SRS, circuit, proving key, resident witnesses ------------------------------------
+    # ---- setup (untimed): SRS, circuit(s), proving key(s), resident witnesses -----------------------------
     t_setup = time.time()
-    srs = cg.srs_generate(tau, n + 3)
-    sc = bu.synthetic_circuit(log_n, num_inputs, seed=2)
-    sel, sig = sc.selectors_mont(), sc.sigma_mont()
-    pk, _vk = cg.plonk_preprocess(srs, n, num_inputs, sel, sig)
-    n_wit = min(P, 4)
-    wit = [sc.witness(1000 * rank + 3 + i) for i in range(n_wit)]
-    wires = np.stack([sc.wires_mont(wit[i % n_wit][0]) for i in range(P)])
-    pubs = np.stack([bu.to_mont_array(wit[i % n_wit][1]) for i in range(P)])
-    blind = np.stack([bu.to_mont_array(bu.blinders(7000 + 100 * rank + i)) for i in range(P)])
-    d_wires = cg.DevBuf.from_numpy(wires)
     ext_msg = bytes(range(32))                # stands for the serialised txn-memo verification key
+    if args.workload == "transfer":
+        plan = [("transfer_2x2", log_n, num_inputs, P)]
+    else:
+        from cap_amd import parallel as par
+        mix = [("transfer_2x3", 32), ("mint", 13), ("freeze_3", 19)]       # src/lib.rs:734-736 ratio 5:2:3
+        plan, gi = [], 0
+        for kind, cnt in mix:
+            mine = [i for i in range(gi, gi + cnt) if i % world == rank]
+            gi += cnt
+            ln, ni = bu.NOTE_SHAPES[kind]
+            plan.append((kind, ln, ni, len(mine)))
+        log_n = max(ln for _, ln, _, _ in plan)
+        n = 1 << log_n
+    srs = cg.srs_generate(tau, n + 3)
+    groups = []
+    for kind, ln, ni, cnt in plan:
+        sc = bu.synthetic_circuit(ln, ni, seed=2 + ln + ni)
+        sel, sig = sc.selectors_mont(), sc.sigma_mont()
+        pk, _vk = cg.plonk_preprocess(srs, 1 << ln, ni, sel, sig)
+        n_wit = max(1, min(cnt, 4))
+        wit = [sc.witness(1000 * rank + 3 + i) for i in range(n_wit)]
+        g = {"kind": kind, "n": 1 << ln, "num_inputs": ni, "count": cnt, "pk": pk, "sel": sel, "sig": sig}
+        if cnt:
+            g["wires"] = np.stack([sc.wires_mont(wit[i % n_wit][0]) for i in range(cnt)])
+            g["pubs"] = np.stack([bu.to_mont_array(wit[i % n_wit][1]) for i in range(cnt)])
+            g["blind"] = np.stack([bu.to_mont_array(bu.blinders(7000 + 100 * rank + i)) for i in range(cnt)])
+            g["d_wires"] = cg.DevBuf.from_numpy(g["wires"])
+        groups.append(g)
+    g0 = groups[0]
+    pk, sel, sig = g0["pk"], g0["sel"], g0["sig"]
+    wires, pubs, blind = g0.get("wires"), g0.get("pubs"), g0.get("blind")
     t_setup = time.time() - t_setup
 
     def sync_all():
@@ -172,7 +198,12 @@ def main():
             torch.cuda.synchronize()
 
     def step(key):
-        return cg.plonk_prove_batch_dev(key, d_wires, pubs, blind, ext_msg, P)
+        out_proofs = []
+        for g in groups:
+            if g["count"]:
+                k = key if (key is not None and g is g0) else g["pk"]
+                out_proofs += cg.plonk_prove_batch_dev(k, g["d_wires"], g["pubs"], g["blind"], ext_msg, g["count"])
+        return out_proofs
 
     def timed(key, steps, warmup, profile):
         for _ in range(warmup):
@@ -195,7 +226,8 @@ def main():
         return dt, stats, proofs
 
     dt, stats, proofs = timed(pk, args.steps, args.warmup, profile=True)
-    total_proofs = P * args.steps * world
+    per_step_all_ranks = P * world if args.workload == "transfer" else 64
+    total_proofs = per_step_all_ranks * args.steps
     value = total_proofs / dt
 
     # ---- roofline of the dominant kernel (HIP events on the launch stream, timed region itself) -------------
@@ -221,7 +253,7 @@ def main():
     if dom is not None:
         launches = stats[dom][1]
         avg_ms = stats[dom][0] / max(launches, 1)
-        if dom in per_step_bytes:
+        if dom in per_step_bytes and args.workload == "transfer":
             bytes_per_launch = per_step_bytes[dom] * args.steps / max(launches, 1)
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         else:
@@ -229,7 +261,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                     # HBM bytes per launch from the committed PMC pass (profiles/traffic_r01.json, batch 16) or null
-                    "traffic": traffic_tab.get(dom) if P == 16 and log_n == 15 else None,
+                    "traffic": traffic_tab.get(dom) if P == TRAFFIC_BATCH and log_n == 15 else None,
                     "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
                     "share_of_kernel_time": kern_ms[dom] / sum(kern_ms.values())}
     top = sorted(kern_ms.items(), key=lambda kv: -kv[1])[:8]
@@ -238,9 +270,11 @@ def main():
     out = {
         "metric": "transfer-note proofs/sec (2-in/2-out)", "value": value, "unit": "proofs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery integers)", "data": "synthetic",
-        "config": {"workload": f"full 2-in/2-out transfer-note PLONK proof (13 MSM + 33 NTT), n=2^{log_n}, 27 public inputs, "
-                               f"batch {P} proofs/step/GPU, device-resident witness + key + SRS",
+        "scaling": "weak" if args.workload == "transfer" else "strong", "vs_baseline": None, "dtype": "u32x8 (254-bit Montgomery integers)", "data": "synthetic",
+        "config": {"workload": (f"full 2-in/2-out transfer-note PLONK proof (13 MSM + 33 NTT), n=2^{log_n}, 27 public inputs, "
+                                f"batch {P} proofs/step/GPU, device-resident witness + key + SRS") if args.workload == "transfer"
+                   else "BASELINE config 4: 64 mixed proofs per step = 32 transfer(2-in/3-out, n=2^15) + 13 mint (n=2^14) + "
+                        "19 freeze(3 inputs, n=2^15), one SRS, three keys, proof i on rank i mod N",
                    "domain_size": n, "batch_per_gpu": P, "parallelism": f"replicas x{world} (independent proofs)",
                    "pk_coset_cache": "18 fixed selector/sigma coset NTTs cached in the proving key (see "
                                      "reference_schedule for the per-proof recompute number)"},
@@ -251,11 +285,11 @@ def main():
         "setup_s": round(t_setup, 2),
     }
 
-    if world == 1 and not args.no_reference_schedule:
+    if world == 1 and not args.no_reference_schedule and args.workload == "transfer":
         os.environ["CAPGPU_RECOMPUTE_PK_COSET"] = "1"
         pk_ref, _ = cg.plonk_preprocess(srs, n, num_inputs, sel, sig)
         os.environ.pop("CAPGPU_RECOMPUTE_PK_COSET")
-    if not args.no_reference_schedule:
+    if not args.no_reference_schedule and args.workload == "transfer":
         # every rank must take part (barriers); only rank 0 built the key when world == 1
         if world == 1:
             rs = max(2, args.steps // 2)
@@ -268,7 +302,7 @@ def main():
             cg.plonk_free_key(pk_ref)
 
     # ---- CPU baseline: the C restatement of the arkworks/jf-plonk algorithm, 1 thread, rank 0, N = 1 ----------
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "transfer":
         from oracle import capref as cr        # cpu_baseline leg: the only place bench.py touches oracle/
         key = cr.PlonkKey(cg.srs_download(srs, 0, n + 3), n, num_inputs, sel, sig)
         t0 = time.perf_counter()

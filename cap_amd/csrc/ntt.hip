@@ -12,6 +12,8 @@
 #include "ntt.hpp"
 #include "launch.hpp"
 
+#include <stdlib.h>
+
 #include <vector>
 
 namespace cap {
@@ -19,7 +21,15 @@ namespace cap {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr uint32_t kMaxTileLog = 11;  // 2048 elements * 32 B = 64 KiB of LDS
+constexpr uint32_t kMaxTileLogDefault = 11;  // 2048 elements * 32 B = 64 KiB of LDS
+uint32_t max_tile_log() {
+  static uint32_t v = [] {
+    const char* e = getenv("CAPGPU_NTT_TILE_LOG");
+    int x = e ? atoi(e) : (int)kMaxTileLogDefault;
+    return (uint32_t)(x >= 8 && x <= 11 ? x : (int)kMaxTileLogDefault);
+  }();
+  return v;
+}
 
 struct PassParams {
   const fe* in;
@@ -276,7 +286,7 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
   for (int d = 0; d < passes - 1; d++) {
     uint32_t log_len = lg[d];
     uint32_t log_s = log_m - log_len;
-    uint32_t log_c = kMaxTileLog - log_len;
+    uint32_t log_c = max_tile_log() > log_len ? max_tile_log() - log_len : 0;
     if (log_c > log_s) log_c = log_s;
     if (log_c > 4) log_c = 4;
     p.in = cur_in;
@@ -299,7 +309,7 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
     uint32_t log_len = lg[2];
     uint32_t log_n1 = passes >= 2 ? lg[0] : 0;
     uint32_t log_n2 = passes == 3 ? lg[1] : 0;
-    uint32_t log_c = kMaxTileLog - log_len;
+    uint32_t log_c = max_tile_log() > log_len ? max_tile_log() - log_len : 0;
     if (log_c > log_n1) log_c = log_n1;
     if (log_c > 4) log_c = 4;
     p.in = cur_in;

@@ -98,6 +98,49 @@ def test_transfer_note_shape_full_size(cg, tau):
     cg.srs_free(h)
 
 
+@pytest.mark.parametrize("kind", ["mint", "freeze_2"])
+def test_mint_and_freeze_note_shapes_full_size(cg, tau, kind):
+    """A2 / A3: mint (n = 2^14, 22 public inputs: src/proof/mint.rs:262-277) and freeze (2 inputs, n = 2^14,
+    3 + 2k public inputs: src/proof/freeze.rs:331-344) go through the same prover; bit-exact vs the CPU restatement."""
+    sc = bu.note_circuit(kind, seed=5)
+    assert sc.n == 1 << 14
+    h, pkh, vk = gpu_key(cg, tau, sc)
+    key = cr.PlonkKey(cg.srs_download(h, 0, sc.n + 3), sc.n, sc.num_inputs, sc.selectors_mont(), sc.sigma_mont())
+    w, pubs = sc.witness(8)
+    wm, pm, bm = sc.wires_mont(w), pubs_arr(pubs), bu.to_mont_array(bu.blinders(8))
+    pr = cg.plonk_prove_batch(pkh, wm[None], pm[None], bm[None], None, 1)[0]   # mint has no extra bound data
+    rc, comms, evals = key.prove(wm, pm, bm, None)
+    assert rc == 0 and H.proof_points(pr) == H.cref_proof_points(comms, evals)
+    cg.plonk_free_key(pkh)
+    cg.srs_free(h)
+
+
+def test_mixed_batch_shares_one_srs(cg, tau):
+    """TxnsParams::generate_txns (src/utils/params_builder.rs:64-241): one SRS sized for the largest circuit, one
+    proving key per note type, proofs of different types interleaved.  Small domains here; the full-size mixed
+    batch is bench.py --workload mixed64."""
+    shapes = {"transfer": (9, 27), "mint": (8, 22), "freeze": (8, 7)}
+    h = cg.srs_generate(tau, (1 << 9) + 3)
+    keys, circs = {}, {}
+    for name, (log_n, nin) in shapes.items():
+        sc = bu.synthetic_circuit(log_n, nin, seed=log_n + nin)
+        circs[name] = sc
+        keys[name] = cg.plonk_preprocess(h, sc.n, nin, sc.selectors_mont(), sc.sigma_mont())[0]
+    srs_host = cg.srs_download(h, 0, (1 << 9) + 3)
+    order = ["transfer", "mint", "transfer", "freeze", "freeze", "transfer"]
+    for i, name in enumerate(order):
+        sc = circs[name]
+        w, pubs = sc.witness(50 + i)
+        wm, pm, bm = sc.wires_mont(w), pubs_arr(pubs), bu.to_mont_array(bu.blinders(60 + i))
+        pr = cg.plonk_prove_batch(keys[name], wm[None], pm[None], bm[None], b"m", 1)[0]
+        ck = cr.PlonkKey(srs_host, sc.n, sc.num_inputs, sc.selectors_mont(), sc.sigma_mont())
+        rc, comms, evals = ck.prove(wm, pm, bm, b"m")
+        assert rc == 0 and H.proof_points(pr) == H.cref_proof_points(comms, evals), name
+    for k in keys.values():
+        cg.plonk_free_key(k)
+    cg.srs_free(h)
+
+
 def test_unsatisfied_witness_and_bad_arguments(cg, tau):
     sc = bu.synthetic_circuit(6, 2, seed=9)
     h, pkh, vk = gpu_key(cg, tau, sc)
