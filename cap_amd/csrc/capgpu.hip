@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "context.hpp"
+#include "curve29.hpp"
 #include "launch.hpp"
 
 namespace cap {
@@ -118,32 +119,31 @@ __global__ void fq_to_mont_kernel(fe* data, size_t count) {
 
 // sum of n Jacobian points (one wavefront; n is tiny: the G partial sums of a sharded MSM)
 __global__ __launch_bounds__(64) void g1_sum_kernel(const g1_jac* __restrict__ in, size_t n, g1_jac* __restrict__ out) {
-  g1_xyzz acc = G1::inf();
+  g1x acc = G1L::inf();
   for (size_t i = threadIdx.x; i < n; i += 64) {
     g1_jac p = in[i];
-    g1_xyzz q;
-    if (Fq::is_zero(p.z)) {
-      q = G1::inf();
-    } else {
-      q.x = p.x;
-      q.y = p.y;
-      q.zz = Fq::sqr(p.z);
-      q.zzz = Fq::mul(q.zz, p.z);
+    g1x q = G1L::inf();
+    if (!Fq::is_zero(p.z)) {
+      fl z = Fq29::from_ext(p.z);
+      q.zz = Fq29::sqr(z);
+      q.zzz = Fq29::mul(q.zz, z);
+      q.x = Fq29::weak_reduce(Fq29::from_ext(p.x));
+      q.y = Fq29::weak_reduce(Fq29::from_ext(p.y));
     }
-    acc = G1::add(acc, q);
+    acc = G1L::add(acc, q);
   }
   for (int d = 32; d >= 1; d >>= 1) {
-    g1_xyzz o;
+    g1x o;
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < 9; i++) {
       o.x.v[i] = __shfl_down(acc.x.v[i], d);
       o.y.v[i] = __shfl_down(acc.y.v[i], d);
       o.zz.v[i] = __shfl_down(acc.zz.v[i], d);
       o.zzz.v[i] = __shfl_down(acc.zzz.v[i], d);
     }
-    acc = G1::add(acc, o);
+    acc = G1L::add(acc, o);
   }
-  if (threadIdx.x == 0) *out = G1::to_jac(acc);
+  if (threadIdx.x == 0) *out = G1L::to_jac_ext(acc);
 }
 
 fe fe_from_u64x4(const uint64_t v[4]) {
@@ -385,6 +385,13 @@ int capgpu_srs_download(uint64_t handle, size_t offset, size_t n, void* out) {
   if (offset + n > it->second.bases.n || !out) return CAPGPU_ERR_INVALID_ARG;
   CAP_HIP(hipMemcpyAsync(out, it->second.bases.ext + offset, sizeof(g1_affine) * n, hipMemcpyDeviceToHost, c.stream));
   CAP_HIP(hipStreamSynchronize(c.stream));
+  // the resident table is in the internal Montgomery form (x * 2^261); hand back arkworks' form (x * 2^256)
+  g1_affine* pts = reinterpret_cast<g1_affine*>(out);
+  for (size_t i = 0; i < n; i++) {
+    if (G1::is_inf(pts[i])) continue;
+    pts[i].x = Fq29::to_ext(Fq29::load(pts[i].x));
+    pts[i].y = Fq29::to_ext(Fq29::load(pts[i].y));
+  }
   return CAPGPU_OK;
 }
 int capgpu_srs_free(uint64_t handle) {

@@ -1,0 +1,275 @@
+// Lazy-carry BN254 field arithmetic for gfx950: 9 limbs of 29 bits, Montgomery radix R' = 2^261.
+//
+// Why a second representation (measured on MI355X, profiles/ubench_r01.txt, tools/ubench_mul29.hip):
+// with saturated 32-bit limbs (field.hpp) every row of a multiplication needs a v_addc_co_u32 carry chain,
+// and v_addc costs nearly as much as v_mad_u64_u32.  With 29-bit limbs the 81 + 81 partial products of a
+// Montgomery multiplication accumulate in 64-bit columns by v_mad_u64_u32 alone - no carry instruction in
+// the product phase - which is 1.2x (saturated) to 1.7x (one wave per SIMD) faster, and because
+// 2^261 >> p no conditional subtraction is ever needed: values stay "lazy" (a few multiples of p).
+//
+// Contract (all bounds are checked by tests/host tools with CAP_FL_CHECK):
+//   * "normalized": limbs 0..7 < 2^29, limb 8 < 2^29  (value < 2^261).
+//   * mul / sqr:  operands with limbs < 2^30 (a normalized value or one lazy sum of two); returns a
+//     normalized value < p * (1 + A*B/169) for operands < A*p, B*p.
+//   * add: limb-wise, no carry; sub(a, b) = a + 16p - b for b < 15.9 p with limbs < 2^30, normalized result.
+//   * weak_reduce: any normalized value -> normalized value < 2p.   canonical: -> the unique value < p.
+// Memory format: 8 x u32 (the same 32 bytes as `fe`), any value < 2^256.
+#pragma once
+#include "field.hpp"
+
+namespace cap {
+
+struct fl {
+  uint32_t v[9];
+};
+
+struct FqP29 {
+  using Base = FqP;
+  static constexpr uint32_t MOD[9] = {0x187cfd47u, 0x010460b6u, 0x1c72a34fu, 0x02d522d0u, 0x1585d978u,
+                                      0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+  static constexpr uint32_t NINV = 0x04866389u;  // -p^-1 mod 2^29
+  static constexpr uint32_t ONE[9] = {0x157ccc21u, 0x141c2758u, 0x185230d3u, 0x014c0419u, 0x0aa36fb9u,
+                                      0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};  // 2^261 mod p
+  static constexpr uint32_t C256[9] = {0x058f0d9du, 0x1aea1c6eu, 0x11c2cf74u, 0x11d651ebu, 0x1462c0a7u,
+                                       0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u};  // 2^256 mod p (plain)
+  static constexpr uint32_t R522[9] = {0x059bac10u, 0x0d1503a3u, 0x018016b8u, 0x10ab0ca8u, 0x02632639u,
+                                       0x02c0169fu, 0x169bfd53u, 0x11869d4cu, 0x002a11a6u};  // 2^522 mod p
+  // 16p with limbs 0..7 inflated into [2^30, 2^31)
+  static constexpr uint32_t SUB16P[9] = {0x47cfd470u, 0x50460b6au, 0x472a34eeu, 0x4d522d0cu, 0x585d977fu,
+                                         0x4db40c08u, 0x4a6e140fu, 0x45c2633eu, 0x030644e5u};
+  static constexpr uint32_t MU = 0x54a47u;  // floor(2^272 / p)
+  static constexpr uint32_t K266[9] = {0x13349ca1u, 0x1a5d84a8u, 0x0a3e5cacu, 0x100249e0u, 0x12b951e8u, 0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u};  // 2^266 mod p
+};
+struct FrP29 {
+  using Base = FrP;
+  static constexpr uint32_t MOD[9] = {0x10000001u, 0x1f0fac9fu, 0x0e5c2450u, 0x07d090f3u, 0x1585d283u,
+                                      0x02db40c0u, 0x00a6e141u, 0x0e5c2634u, 0x0030644eu};
+  static constexpr uint32_t NINV = 0x0fffffffu;
+  static constexpr uint32_t ONE[9] = {0x0fffff57u, 0x1ea70ab4u, 0x052c068bu, 0x17504f49u, 0x0aa8075bu,
+                                      0x1d4240ceu, 0x11d54c07u, 0x052ac7a8u, 0x000dc836u};
+  static constexpr uint32_t C256[9] = {0x0ffffffbu, 0x04b1a0e2u, 0x18334a6bu, 0x18ed2b3eu, 0x1462e36fu,
+                                       0x11b7bc3cu, 0x1cbd99bau, 0x183340fbu, 0x000e0a77u};
+  static constexpr uint32_t R522[9] = {0x05b69bd4u, 0x06170a5au, 0x020cddceu, 0x1db6310bu, 0x0e54d0ffu,
+                                       0x1cf855e3u, 0x1c15e103u, 0x07d09161u, 0x000a054au};
+  static constexpr uint32_t SUB16P[9] = {0x40000010u, 0x50fac9f6u, 0x45c2450du, 0x5d090f35u, 0x585d2831u,
+                                         0x4db40c08u, 0x4a6e140fu, 0x45c2633eu, 0x030644e5u};
+  static constexpr uint32_t MU = 0x54a47u;
+  static constexpr uint32_t K266[9] = {0x0fffead7u, 0x1d5444f4u, 0x04438aa5u, 0x03b4d096u, 0x134c84dau, 0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u};
+};
+
+#ifdef CAP_FL_CHECK
+#include <assert.h>
+#define CAP_FL_ASSERT(x) assert(x)
+#else
+#define CAP_FL_ASSERT(x) ((void)0)
+#endif
+
+template <class PR>
+struct Fl {
+  static constexpr uint32_t M29 = 0x1fffffffu;
+
+  // ---- constants / conversions ---------------------------------------------------------------------
+  static CAP_HD fl zero() {
+    fl r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = 0;
+    return r;
+  }
+  static CAP_HD fl one() {  // Montgomery (R' = 2^261) form of 1
+    fl r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = PR::ONE[i];
+    return r;
+  }
+  // 8 x 32-bit words (any value < 2^256) -> 9 x 29-bit limbs, same integer
+  static CAP_HD fl unpack(const fe& a) {
+    fl r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      const int bit = 29 * i, w = bit >> 5, off = bit & 31;
+      uint32_t lo = a.v[w] >> off;
+      if (off > 3 && w + 1 < 8) lo |= a.v[w + 1] << (32 - off);
+      r.v[i] = i < 8 ? (lo & M29) : lo;  // limb 8 = bits 232..255 (24 bits)
+    }
+    return r;
+  }
+  // normalized value < 2^256 -> 8 x 32-bit words
+  static CAP_HD fe pack(const fl& a) {
+    fe r;
+#pragma unroll
+    for (int w = 0; w < 8; w++) {
+      const int bit = 32 * w, i = bit / 29, off = bit - 29 * i;
+      uint32_t x = a.v[i] >> off;
+      if (i + 1 < 9) x |= a.v[i + 1] << (29 - off);
+      if (off > 26 && i + 2 < 9) x |= a.v[i + 2] << (58 - off);
+      r.v[w] = x;
+    }
+    return r;
+  }
+
+  // ---- carries -----------------------------------------------------------------------------------------
+  // limbs up to < 2^32 - 8 -> normalized (same integer; limb 8 absorbs the top carry)
+  static CAP_HD fl normalize(const fl& a) {
+    fl r;
+    uint32_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      uint32_t t = a.v[i] + c;
+      r.v[i] = t & M29;
+      c = t >> 29;
+    }
+    r.v[8] = a.v[8] + c;
+    CAP_FL_ASSERT(r.v[8] < (1u << 29));
+    return r;
+  }
+
+  // ---- additive ops ------------------------------------------------------------------------------------
+  static CAP_HD fl add(const fl& a, const fl& b) {  // lazy: limbs add, no carry
+    fl r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = a.v[i] + b.v[i];
+    return r;
+  }
+  static CAP_HD fl add_norm(const fl& a, const fl& b) { return normalize(add(a, b)); }
+  // a - b + 16p, normalized.  Requires limbs(a) < 2^30, limbs(b) < 2^30 (i < 8), b < 15.9 p.
+  static CAP_HD fl sub(const fl& a, const fl& b) {
+    fl r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      CAP_FL_ASSERT(i == 8 ? b.v[i] <= PR::SUB16P[i] : (b.v[i] < (1u << 30) && a.v[i] < (1u << 30)));
+      r.v[i] = a.v[i] + (PR::SUB16P[i] - b.v[i]);
+    }
+    return normalize(r);
+  }
+  static CAP_HD fl neg(const fl& b) { return sub(zero(), b); }
+
+  // ---- weak reduction: normalized x -> normalized value in [0, 2p) ------------------------------------
+  static CAP_HD fl weak_reduce(const fl& x) {
+    // q <= floor(x / p) <= q + 1 from the top limb: q = (x_8 * floor(2^272/p)) >> 40
+    uint32_t q = (uint32_t)(((uint64_t)x.v[8] * PR::MU) >> 40);
+    fl r;
+    int64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      int64_t t = (int64_t)x.v[i] - (int64_t)((uint64_t)q * PR::MOD[i]) + c;
+      r.v[i] = (uint32_t)t & M29;
+      c = t >> 29;
+    }
+    int64_t t = (int64_t)x.v[8] - (int64_t)((uint64_t)q * PR::MOD[8]) + c;
+    CAP_FL_ASSERT(t >= 0 && t < (1 << 26));
+    r.v[8] = (uint32_t)t;
+    return r;
+  }
+  // the unique representative < p (exact; used at the ABI boundary and in rare-path comparisons)
+  static CAP_HD fl canonical(const fl& x) {
+    fl r = weak_reduce(x);
+#pragma unroll 1
+    for (int k = 0; k < 2; k++) {  // r < 2p: at most one subtraction needed; the second pass is a no-op guard
+      fl d;
+      int64_t c = 0;
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        int64_t t = (int64_t)r.v[i] - (int64_t)PR::MOD[i] + c;
+        d.v[i] = i < 8 ? ((uint32_t)t & M29) : (uint32_t)t;
+        c = t >> 29;
+      }
+      if (c == 0) r = d;  // no borrow: r >= p
+    }
+    return r;
+  }
+  // x == 0 (mod p)?  x normalized.  Fast path: one multiplication by p^-1 mod 2^29 decides almost always.
+  static CAP_HD bool is_zero(const fl& x) {
+    // x = k p  =>  k = x_0 * p^-1 mod 2^29 ; a multiple of p below 2^261 has k < 169
+    uint32_t k = (x.v[0] * (0u - PR::NINV)) & M29;  // p^-1 = -NINV mod 2^29
+    if (k >= 256) return false;
+    fl c = canonical(x);
+    uint32_t o = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++) o |= c.v[i];
+    return o == 0;
+  }
+  static CAP_HD bool eq(const fl& a, const fl& b) { return is_zero(sub(a, weak_reduce(b))); }
+
+  // ---- Montgomery multiplication: a * b * 2^-261 mod p (lazy) --------------------------------------
+  static CAP_HD fl reduce_cols(uint64_t c[18]) {
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      uint32_t m = ((uint32_t)c[k] * PR::NINV) & M29;
+#pragma unroll
+      for (int j = 0; j < 9; j++) c[k + j] += (uint64_t)m * PR::MOD[j];
+      c[k + 1] += c[k] >> 29;
+    }
+    fl r;
+#pragma unroll
+    for (int k = 9; k < 17; k++) {
+      r.v[k - 9] = (uint32_t)c[k] & M29;
+      c[k + 1] += c[k] >> 29;
+    }
+    CAP_FL_ASSERT(c[17] < (1ull << 29));
+    r.v[8] = (uint32_t)c[17];
+    return r;
+  }
+  static CAP_HD fl mul(const fl& a, const fl& b) {
+    uint64_t c[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+      for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)a.v[i] * b.v[j];
+    return reduce_cols(c);
+  }
+  static CAP_HD fl sqr(const fl& a) {
+    uint64_t c[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) c[k] = 0;
+    uint32_t d[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;  // limbs < 2^30 -> < 2^31
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      c[2 * i] += (uint64_t)a.v[i] * a.v[i];
+#pragma unroll
+      for (int j = i + 1; j < 9; j++) c[i + j] += (uint64_t)d[i] * a.v[j];
+    }
+    return reduce_cols(c);
+  }
+  // a*b + c*d with one reduction (operands normalized)
+  static CAP_HD fl mul_add_mul(const fl& a, const fl& b, const fl& c2, const fl& d) {
+    uint64_t c[18];
+#pragma unroll
+    for (int k = 0; k < 18; k++) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+      for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)a.v[i] * b.v[j] + (uint64_t)c2.v[i] * d.v[j];
+    return reduce_cols(c);
+  }
+
+  // ---- forms ---------------------------------------------------------------------------------------------
+  static CAP_HD fl konst(const uint32_t (&k)[9]) {
+    fl r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) r.v[i] = k[i];
+    return r;
+  }
+  // external Montgomery form (x * 2^256 mod p, what arkworks keeps in memory) -> internal (x * 2^261)
+  static CAP_HD fl from_ext(const fe& a) { return mul(unpack(a), konst(PR::K266)); }
+  // internal -> external Montgomery form, canonical (< p)
+  static CAP_HD fe to_ext(const fl& a) { return pack(canonical(mul(a, konst(PR::C256)))); }
+  // plain integer (< 2^256) <-> internal Montgomery form
+  static CAP_HD fl to_mont(const fe& a) { return mul(unpack(a), konst(PR::R522)); }
+  static CAP_HD fe from_mont(const fl& a) {
+    fl o = zero();
+    o.v[0] = 1;
+    return pack(canonical(mul(a, o)));
+  }
+  // lazy value (normalized, < 2^256 after the weak reduction) <-> its 32-byte memory image
+  static CAP_HD fe store(const fl& a) { return pack(weak_reduce(a)); }
+  static CAP_HD fl load(const fe& a) { return unpack(a); }
+};
+
+using Fq29 = Fl<FqP29>;
+using Fr29 = Fl<FrP29>;
+
+}  // namespace cap

@@ -8,6 +8,7 @@
 //   msm_reduce_bits   K6  T_b = sum of buckets whose weight has bit b set (log-depth trees)
 //   msm_reduce_final  K6  sum_b 2^b T_b  ->  one Jacobian point per MSM
 #include "msm.hpp"
+#include "curve29.hpp"
 #include "launch.hpp"
 
 #include <stdio.h>
@@ -23,18 +24,18 @@ constexpr uint32_t kReduceChunk = 4096;  // buckets per msm_reduce_bits workgrou
 constexpr uint32_t kDigitTile = 2048;    // scalars per msm_digits_local workgroup
 constexpr uint32_t kItemLen = 32;        // list entries per msm_accumulate work item
 
-__device__ __forceinline__ fe shfl_down_fe(const fe& a, int d) {
-  fe r;
+__device__ __forceinline__ fl shfl_down_fl(const fl& a, int d) {
+  fl r;
 #pragma unroll
-  for (int i = 0; i < 8; i++) r.v[i] = __shfl_down(a.v[i], d);
+  for (int i = 0; i < 9; i++) r.v[i] = __shfl_down(a.v[i], d);
   return r;
 }
-__device__ __forceinline__ g1_xyzz shfl_down_pt(const g1_xyzz& a, int d) {
-  g1_xyzz r;
-  r.x = shfl_down_fe(a.x, d);
-  r.y = shfl_down_fe(a.y, d);
-  r.zz = shfl_down_fe(a.zz, d);
-  r.zzz = shfl_down_fe(a.zzz, d);
+__device__ __forceinline__ g1x shfl_down_pt(const g1x& a, int d) {
+  g1x r;
+  r.x = shfl_down_fl(a.x, d);
+  r.y = shfl_down_fl(a.y, d);
+  r.zz = shfl_down_fl(a.zz, d);
+  r.zzz = shfl_down_fl(a.zzz, d);
   return r;
 }
 
@@ -44,12 +45,22 @@ __global__ __launch_bounds__(kThreads) void msm_precompute_kernel(g1_affine* __r
                                                                   uint32_t c, uint32_t windows) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  g1_affine p = bases[i];
-  ext[i] = p;
-  g1_xyzz acc = G1::from_affine(p);
+  // caller bases are in arkworks' Montgomery form (x * 2^256); the table is kept in the internal form
+  // (x * 2^261, canonical) of the lazy 29-bit field
+  g1_affine b = bases[i];
+  g1a p;
+  if (G1::is_inf(b)) {
+    p.x = Fq29::zero();
+    p.y = Fq29::zero();
+  } else {
+    p.x = Fq29::canonical(Fq29::from_ext(b.x));
+    p.y = Fq29::canonical(Fq29::from_ext(b.y));
+  }
+  ext[i] = G1L::store_affine(p);
+  g1x acc = G1L::from_affine(p);
   for (uint32_t w = 1; w < windows; w++) {
-    for (uint32_t k = 0; k < c; k++) acc = G1::dbl(acc);
-    ext[(size_t)w * n + i] = G1::to_affine(acc);
+    for (uint32_t k = 0; k < c; k++) acc = G1L::dbl(acc);
+    ext[(size_t)w * n + i] = G1L::store_affine(G1L::to_affine(acc));
   }
 }
 
@@ -306,14 +317,13 @@ __global__ __launch_bounds__(kThreads) void msm_accumulate(const g1_affine* __re
   uint32_t lo = j * kItemLen, hi = lo + kItemLen;
   if (hi > cnt) hi = cnt;
   const uint32_t* lst = sorted + (size_t)b * per + offsets[gb];
-  g1_xyzz acc = G1::inf();
+  g1x acc = G1L::inf();
   for (uint32_t e = lo; e < hi; e++) {
     uint32_t v = lst[e];
-    g1_affine p = ext[v & 0x7FFFFFFFu];
-    if (v >> 31) p.y = Fq::neg(p.y);
-    acc = G1::add_mixed(acc, p);
+    g1a p = G1L::load(ext[v & 0x7FFFFFFFu]);
+    acc = G1L::add_mixed(acc, p, (v >> 31) != 0);
   }
-  item_pts[it] = acc;
+  item_pts[it] = G1L::store(acc);
 }
 
 // bucket = sum of its work items (a handful of full additions per bucket)
@@ -326,10 +336,10 @@ __global__ __launch_bounds__(kThreads) void msm_combine(const g1_xyzz* __restric
   if (gb >= total_buckets) return;
   uint32_t items = (counts[gb] + kItemLen - 1) / kItemLen;
   uint32_t first = item_base[gb / half] + item_off[gb];
-  g1_xyzz acc = G1::inf();
-  if (items) acc = item_pts[first];
-  for (uint32_t j = 1; j < items; j++) acc = G1::add(acc, item_pts[first + j]);
-  buckets[gb] = acc;
+  g1x acc = G1L::inf();
+  if (items) acc = G1L::load(item_pts[first]);
+  for (uint32_t j = 1; j < items; j++) acc = G1L::add(acc, G1L::load(item_pts[first + j]));
+  buckets[gb] = G1L::store(acc);
 }
 
 // ---- K6a: bit-plane sums ---------------------------------------------------------------------------
@@ -341,22 +351,22 @@ __global__ __launch_bounds__(kThreads) void msm_reduce_bits(const g1_xyzz* __res
   __shared__ g1_xyzz sh[kThreads / 64];
   const uint32_t chunk = blockIdx.x, bit = blockIdx.y, b = blockIdx.z;
   const g1_xyzz* bk = buckets + (size_t)b * half;
-  g1_xyzz acc = G1::inf();
+  g1x acc = G1L::inf();
   for (uint32_t q = 0; q < kReduceChunk / kThreads; q++) {
     uint32_t j = chunk * kReduceChunk + q * kThreads + threadIdx.x;
-    if (j < half && (((j + 1) >> bit) & 1)) acc = G1::add(acc, bk[j]);
+    if (j < half && (((j + 1) >> bit) & 1)) acc = G1L::add(acc, G1L::load(bk[j]));
   }
   for (int d = 32; d >= 1; d >>= 1) {
-    g1_xyzz o = shfl_down_pt(acc, d);
-    acc = G1::add(acc, o);
+    g1x o = shfl_down_pt(acc, d);
+    acc = G1L::add(acc, o);
   }
   uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if (lane == 0) sh[wave] = acc;
+  if (lane == 0) sh[wave] = G1L::store(acc);
   __syncthreads();
   if (threadIdx.x == 0) {
-    g1_xyzz r = sh[0];
-    for (uint32_t w = 1; w < kThreads / 64; w++) r = G1::add(r, sh[w]);
-    partial[((size_t)b * c + bit) * chunks + chunk] = r;
+    g1x r = G1L::load(sh[0]);
+    for (uint32_t w = 1; w < kThreads / 64; w++) r = G1L::add(r, G1L::load(sh[w]));
+    partial[((size_t)b * c + bit) * chunks + chunk] = G1L::store(r);
   }
 }
 
@@ -365,20 +375,20 @@ __global__ __launch_bounds__(kThreads) void msm_reduce_bits(const g1_xyzz* __res
 __global__ __launch_bounds__(64) void msm_reduce_final(const g1_xyzz* __restrict__ partial, uint32_t c,
                                                        uint32_t chunks, g1_jac* __restrict__ out) {
   const uint32_t b = blockIdx.x, lane = threadIdx.x;
-  g1_xyzz acc = G1::inf();
+  g1x acc = G1L::inf();
   if (lane < c) {
     const g1_xyzz* p = partial + ((size_t)b * c + lane) * chunks;
-    for (uint32_t k = 0; k < chunks; k++) acc = G1::add(acc, p[k]);
+    for (uint32_t k = 0; k < chunks; k++) acc = G1L::add(acc, G1L::load(p[k]));
   }
   for (uint32_t k = 0; k + 1 < c; k++) {
-    g1_xyzz d = G1::dbl(acc);
+    g1x d = G1L::dbl(acc);
     if (lane > k && lane < c) acc = d;
   }
   for (int d = 16; d >= 1; d >>= 1) {
-    g1_xyzz o = shfl_down_pt(acc, d);
-    acc = G1::add(acc, o);
+    g1x o = shfl_down_pt(acc, d);
+    acc = G1L::add(acc, o);
   }
-  if (lane == 0) out[b] = G1::to_jac(acc);
+  if (lane == 0) out[b] = G1L::to_jac_ext(acc);
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
