@@ -90,7 +90,7 @@ struct G1L {
     fl m = F::normalize(F::add(F::add(xx, xx), xx));
     g1x r;
     r.x = F::weak_reduce(F::sub(F::sqr(m), F::add(s, s)));
-    r.y = F::weak_reduce(F::sub(F::mul(m, F::sub(s, r.x)), F::mul(w, q.y)));
+    r.y = F::weak_reduce(F::mul_add_mul(m, F::sub(s, r.x), F::neg(w), q.y));
     r.zz = v;
     r.zzz = w;
     return r;
@@ -105,7 +105,7 @@ struct G1L {
     fl m = F::normalize(F::add(F::add(xx, xx), xx));
     g1x r;
     r.x = F::weak_reduce(F::sub(F::sqr(m), F::add(s, s)));
-    r.y = F::weak_reduce(F::sub(F::mul(m, F::sub(s, r.x)), F::mul(w, p.y)));
+    r.y = F::weak_reduce(F::mul_add_mul(m, F::sub(s, r.x), F::neg(w), p.y));
     r.zz = F::mul(v, p.zz);
     r.zzz = F::mul(w, p.zzz);
     return r;
@@ -141,7 +141,7 @@ struct G1L {
     fl qq = F::mul(a.x, pp);
     g1x o;
     o.x = F::weak_reduce(F::sub(F::sub(F::sqr(r), ppp), F::add(qq, qq)));
-    o.y = F::weak_reduce(F::sub(F::mul(r, F::sub(qq, o.x)), F::mul(a.y, ppp)));
+    o.y = F::weak_reduce(F::mul_add_mul(r, F::sub(qq, o.x), F::neg(a.y), ppp));  // one reduction for both products
     o.zz = F::mul(a.zz, pp);
     o.zzz = F::mul(a.zzz, ppp);
     return o;
@@ -164,7 +164,7 @@ struct G1L {
     fl qq = F::mul(u1, pp);
     g1x o;
     o.x = F::weak_reduce(F::sub(F::sub(F::sqr(r), ppp), F::add(qq, qq)));
-    o.y = F::weak_reduce(F::sub(F::mul(r, F::sub(qq, o.x)), F::mul(s1, ppp)));
+    o.y = F::weak_reduce(F::mul_add_mul(r, F::sub(qq, o.x), F::neg(s1), ppp));
     o.zz = F::mul(F::mul(a.zz, b.zz), pp);
     o.zzz = F::mul(F::mul(a.zzz, b.zzz), ppp);
     return o;

@@ -39,6 +39,9 @@ struct FqP29 {
                                          0x4db40c08u, 0x4a6e140fu, 0x45c2633eu, 0x030644e5u};
   static constexpr uint32_t MU = 0x54a47u;  // floor(2^272 / p)
   static constexpr uint32_t K266[9] = {0x13349ca1u, 0x1a5d84a8u, 0x0a3e5cacu, 0x100249e0u, 0x12b951e8u, 0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u};  // 2^266 mod p
+  // 2p with limbs 0..7 inflated into [2^29, 2^30)
+  static constexpr uint32_t SUB2P[9] = {0x30f9fa8eu, 0x2208c16cu, 0x38e5469du, 0x25aa45a0u, 0x2b0bb2efu,
+                                        0x25b68180u, 0x214dc281u, 0x3cb84c67u, 0x0060c89bu};
 };
 struct FrP29 {
   using Base = FrP;
@@ -55,6 +58,8 @@ struct FrP29 {
                                          0x4db40c08u, 0x4a6e140fu, 0x45c2633eu, 0x030644e5u};
   static constexpr uint32_t MU = 0x54a47u;
   static constexpr uint32_t K266[9] = {0x0fffead7u, 0x1d5444f4u, 0x04438aa5u, 0x03b4d096u, 0x134c84dau, 0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u};
+  static constexpr uint32_t SUB2P[9] = {0x20000002u, 0x3e1f593eu, 0x3cb848a0u, 0x2fa121e5u, 0x2b0ba505u,
+                                        0x25b68180u, 0x214dc281u, 0x3cb84c67u, 0x0060c89bu};
 };
 
 #ifdef CAP_FL_CHECK
@@ -142,6 +147,16 @@ struct Fl {
     return normalize(r);
   }
   static CAP_HD fl neg(const fl& b) { return sub(zero(), b); }
+  // a - b + 2p, normalized, for a normalized b < 1.9 p (a product); limbs(a) < 2^31
+  static CAP_HD fl sub2p(const fl& a, const fl& b) {
+    fl r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      CAP_FL_ASSERT(i == 8 ? b.v[i] <= PR::SUB2P[i] : (b.v[i] < (1u << 29) && a.v[i] < (1u << 31)));
+      r.v[i] = a.v[i] + (PR::SUB2P[i] - b.v[i]);
+    }
+    return normalize(r);
+  }
 
   // ---- weak reduction: normalized x -> normalized value in [0, 2p) ------------------------------------
   static CAP_HD fl weak_reduce(const fl& x) {
@@ -234,7 +249,7 @@ struct Fl {
     }
     return reduce_cols(c);
   }
-  // a*b + c*d with one reduction (operands normalized)
+  // a*b + c*d with one reduction (all four operands normalized: 18 products of < 2^58 per column)
   static CAP_HD fl mul_add_mul(const fl& a, const fl& b, const fl& c2, const fl& d) {
     uint64_t c[18];
 #pragma unroll

@@ -299,7 +299,7 @@ __global__ __launch_bounds__(kThreads) void msm_scatter(const uint32_t* __restri
 // wavefront therefore runs (almost) the same number of mixed additions whatever the bucket sizes are - a
 // thread-per-bucket mapping loses ~40 % to wave quantisation and the Poisson spread of list lengths, and
 // degrades without bound on skewed scalars (one giant bucket = one serial chain).
-__global__ __launch_bounds__(kThreads) void msm_accumulate(const g1_affine* __restrict__ ext,
+__global__ __launch_bounds__(kThreads, 4) void msm_accumulate(const g1_affine* __restrict__ ext,
                                                            const uint32_t* __restrict__ sorted,
                                                            const uint32_t* __restrict__ counts,
                                                            const uint32_t* __restrict__ offsets,

@@ -10,6 +10,7 @@
 // log2(len) radix-2 stages there; HBM sees one read + one write of the array per
 // pass.  All arithmetic is 254-bit modular integer work (no MFMA).
 #include "ntt.hpp"
+#include "field29.hpp"
 #include "launch.hpp"
 
 #include <stdlib.h>
@@ -21,7 +22,7 @@ namespace cap {
 namespace {
 
 constexpr int kThreads = 256;
-constexpr uint32_t kMaxTileLogDefault = 11;  // 2048 elements * 32 B = 64 KiB of LDS
+constexpr uint32_t kMaxTileLogDefault = 10;  // 1024 elements * 36 B = 36 KiB of LDS (4 workgroups per CU)
 uint32_t max_tile_log() {
   static uint32_t v = [] {
     const char* e = getenv("CAPGPU_NTT_TILE_LOG");
@@ -50,11 +51,14 @@ struct PassParams {
 
 __device__ __forceinline__ uint32_t bitrev32(uint32_t x, uint32_t bits) { return __brev(x) >> (32 - bits); }
 
-// radix-2 DIF stages on sh[len][C]; result in bit-reversed row order
-__device__ __forceinline__ void lds_ntt(fe* sh, const fe* __restrict__ tw_small, uint32_t log_len, uint32_t log_c) {
+// radix-2 DIT stages on sh[len][C] (rows were written bit-reversed): natural order out.
+// Lazy 29-bit field: per butterfly  t = v * w (one Montgomery product, < 1.2p),  (u + t, u + 2p - t); values
+// grow by at most 2p per stage (<= 2p * 11 stages + input), far below the 169p capacity of 9 x 29-bit limbs.
+// Twiddles are stored in the internal Montgomery form (w * 2^261), so data keeps whatever form it came in.
+__device__ __forceinline__ void lds_ntt(fl* sh, const fe* __restrict__ tw_small, uint32_t log_len, uint32_t log_c) {
   const uint32_t half_tile = 1u << (log_len + log_c - 1);
   const uint32_t cmask = (1u << log_c) - 1;
-  for (int s = (int)log_len - 1; s >= 0; s--) {
+  for (uint32_t s = 0; s < log_len; s++) {
     const uint32_t half = 1u << s;
     for (uint32_t b = threadIdx.x; b < half_tile; b += kThreads) {
       uint32_t c = b & cmask;
@@ -62,11 +66,11 @@ __device__ __forceinline__ void lds_ntt(fe* sh, const fe* __restrict__ tw_small,
       uint32_t pos = bb & (half - 1);
       uint32_t j = ((bb >> s) << (s + 1)) + pos;
       uint32_t i0 = (j << log_c) + c, i1 = ((j + half) << log_c) + c;
-      fe u = sh[i0], v = sh[i1];
-      sh[i0] = Fr::add(u, v);
-      fe d = Fr::sub(u, v);
+      fl u = sh[i0], v = sh[i1];
       uint32_t e = pos << (log_len - 1 - s);
-      sh[i1] = e ? Fr::mul(d, tw_small[e]) : d;
+      fl t = e ? Fr29::mul(v, Fr29::load(tw_small[e])) : Fr29::weak_reduce(v);
+      sh[i0] = Fr29::normalize(Fr29::add(u, t));
+      sh[i1] = Fr29::sub2p(u, t);
     }
     __syncthreads();
   }
@@ -75,7 +79,7 @@ __device__ __forceinline__ void lds_ntt(fe* sh, const fe* __restrict__ tw_small,
 // column pass: len rows at stride S = M/len, C adjacent columns per tile
 __global__ __launch_bounds__(kThreads) void ntt_col_pass(PassParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
-  fe* sh = reinterpret_cast<fe*>(smem);
+  fl* sh = reinterpret_cast<fl*>(smem);
   const uint32_t log_s = p.log_m - p.log_len;           // columns per segment (log)
   const uint32_t tiles_per_seg_log = log_s - p.log_c;
   const uint32_t t = blockIdx.x;
@@ -89,26 +93,26 @@ __global__ __launch_bounds__(kThreads) void ntt_col_pass(PassParams p) {
   for (uint32_t e = threadIdx.x; e < tile; e += kThreads) {
     uint32_t c = e & cmask, j = e >> p.log_c;
     size_t g = base + ((size_t)j << log_s) + c;
-    fe v = in[g];
-    if (p.pre_scale) v = Fr::mul(v, p.pre_scale[g]);
-    sh[e] = v;
+    fl v = Fr29::load(in[g]);
+    if (p.pre_scale) v = Fr29::mul(v, Fr29::load(p.pre_scale[g]));
+    sh[(bitrev32(j, p.log_len) << p.log_c) + c] = v;
   }
   __syncthreads();
   lds_ntt(sh, p.tw_small, p.log_len, p.log_c);
   const uint32_t tw_shift = p.log_n - p.log_m;  // omega_M^x = omega_N^(x << tw_shift)
   for (uint32_t e = threadIdx.x; e < tile; e += kThreads) {
     uint32_t c = e & cmask, k = e >> p.log_c;
-    fe v = sh[(bitrev32(k, p.log_len) << p.log_c) + c];
+    fl v = sh[e];
     size_t ex = ((size_t)(col0 + c) * k) << tw_shift;
-    if (ex) v = Fr::mul(v, p.tw_full[ex]);
-    out[base + ((size_t)k << log_s) + c] = v;
+    v = ex ? Fr29::mul(v, Fr29::load(p.tw_full[ex])) : Fr29::weak_reduce(v);
+    out[base + ((size_t)k << log_s) + c] = Fr29::pack(v);   // < 2p: fits the 32-byte image
   }
 }
 
 // row pass: contiguous rows of len elements; C rows with adjacent k1 per tile; digit-reversed store
 __global__ __launch_bounds__(kThreads) void ntt_row_pass(PassParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
-  fe* sh = reinterpret_cast<fe*>(smem);
+  fl* sh = reinterpret_cast<fl*>(smem);
   const uint32_t t = blockIdx.x;
   const uint32_t k2 = t & ((1u << p.log_n2) - 1);
   const uint32_t r0 = (t >> p.log_n2) << p.log_c;
@@ -120,20 +124,27 @@ __global__ __launch_bounds__(kThreads) void ntt_row_pass(PassParams p) {
   for (uint32_t e = threadIdx.x; e < tile; e += kThreads) {
     uint32_t j = e & lmask, c = e >> p.log_len;
     size_t g = ((((size_t)(r0 + c) << p.log_n2) + k2) << p.log_len) + j;
-    fe v = in[g];
-    if (p.pre_scale) v = Fr::mul(v, p.pre_scale[g]);
-    sh[(j << p.log_c) + c] = v;
+    fl v = Fr29::load(in[g]);
+    if (p.pre_scale) v = Fr29::mul(v, Fr29::load(p.pre_scale[g]));
+    sh[(bitrev32(j, p.log_len) << p.log_c) + c] = v;
   }
   __syncthreads();
   lds_ntt(sh, p.tw_small, p.log_len, p.log_c);
   for (uint32_t e = threadIdx.x; e < tile; e += kThreads) {
     uint32_t c = e & cmask, k = e >> p.log_c;
-    fe v = sh[(bitrev32(k, p.log_len) << p.log_c) + c];
+    fl v = sh[e];
     size_t g = (size_t)(r0 + c) + ((size_t)k2 << p.log_n1) + ((size_t)k << (p.log_n1 + p.log_n2));
-    if (p.post_scale) v = Fr::mul(v, p.post_scale[g]);
-    else if (p.use_post_scalar) v = Fr::mul(v, p.post_scalar);
-    out[g] = v;
+    if (p.post_scale) v = Fr29::mul(v, Fr29::load(p.post_scale[g]));
+    else if (p.use_post_scalar) v = Fr29::mul(v, Fr29::load(p.post_scalar));
+    out[g] = Fr29::pack(Fr29::canonical(v));   // results leave the transform canonical (< r), as arkworks stores them
   }
+}
+
+// internal-form table: out[e] = pack(canonical(in_ext[e] * 2^5))  (x * 2^256 -> x * 2^261)
+__global__ void table_to_internal(fe* __restrict__ out, const fe* __restrict__ in, size_t n) {
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  out[e] = Fr29::pack(Fr29::canonical(Fr29::from_ext(in[e])));
 }
 
 // out[e] = base^e * scale for e < n; pw[b] = base^(2^b)
@@ -205,6 +216,12 @@ int ntt_build_small_tables(NttSmallTables* t, hipStream_t stream) {
     if (rc) return rc;
     rc = build_powers(t->inv[s], n, Fr::inv(w), nullptr, stream);
     if (rc) return rc;
+    launch("table_to_internal", table_to_internal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t->fwd[s],
+           (const fe*)t->fwd[s], n);
+    launch("table_to_internal", table_to_internal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t->inv[s],
+           (const fe*)t->inv[s], n);
+    hipError_t es = hipStreamSynchronize(stream);
+    if (es != hipSuccess) return (int)es;
   }
   return 0;
 }
@@ -233,6 +250,20 @@ int ntt_build_domain(NttDomain* d, uint32_t log_n, hipStream_t stream) {
   if ((rc = build_powers(d->tw_inv, n, Fr::inv(w), nullptr, stream))) return rc;
   if ((rc = build_powers(d->coset_fwd, n, g, nullptr, stream))) return rc;
   if ((rc = build_powers(d->coset_inv, n, Fr::inv(g), &d->n_inv, stream))) return rc;
+  fe* src[4] = {d->tw_fwd, d->tw_inv, d->coset_fwd, d->coset_inv};
+  fe** dst[4] = {&d->tw29_fwd, &d->tw29_inv, &d->coset29_fwd, &d->coset29_inv};
+  for (int k = 0; k < 4; k++) {
+    if ((e = hipMalloc(dst[k], sizeof(fe) * n)) != hipSuccess) return (int)e;
+    launch("table_to_internal", table_to_internal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, *dst[k],
+           (const fe*)src[k], n);
+  }
+  d->n_inv29 = Fr29::pack(Fr29::canonical(Fr29::from_ext(d->n_inv)));
+  if ((e = hipStreamSynchronize(stream)) != hipSuccess) return (int)e;
+  // only omega^j (tw_fwd) is still read in arkworks' form by other kernels
+  hipFree(d->tw_inv);
+  hipFree(d->coset_fwd);
+  hipFree(d->coset_inv);
+  d->tw_inv = d->coset_fwd = d->coset_inv = nullptr;
   return 0;
 }
 
@@ -241,7 +272,10 @@ void ntt_free_domain(NttDomain* d) {
   if (d->tw_inv) hipFree(d->tw_inv);
   if (d->coset_fwd) hipFree(d->coset_fwd);
   if (d->coset_inv) hipFree(d->coset_inv);
+  for (fe* t : {d->tw29_fwd, d->tw29_inv, d->coset29_fwd, d->coset29_inv})
+    if (t) hipFree(t);
   d->tw_fwd = d->tw_inv = d->coset_fwd = d->coset_inv = nullptr;
+  d->tw29_fwd = d->tw29_inv = d->coset29_fwd = d->coset29_inv = nullptr;
 }
 
 int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scratch, size_t stride_elems,
@@ -270,7 +304,7 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
   }
   if (lg[0] > 10 || lg[1] > 10 || lg[2] > 10) return (int)hipErrorInvalidValue;
   const fe* const* tws = dir ? small.inv : small.fwd;
-  const fe* tw_full = dir ? dom.tw_inv : dom.tw_fwd;
+  const fe* tw_full = dir ? dom.tw29_inv : dom.tw29_fwd;
 
   PassParams p{};
   p.batch_stride = stride_elems;
@@ -278,7 +312,7 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
   p.tw_full = tw_full;
   p.use_post_scalar = 0;
 
-  const fe* pre = (!dir && coset) ? dom.coset_fwd : nullptr;
+  const fe* pre = (!dir && coset) ? dom.coset29_fwd : nullptr;
   bool first = true;
   const fe* cur_in = data;
   // column passes
@@ -298,7 +332,7 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
     p.log_c = log_c;
     p.log_m = log_m;
     size_t tiles = (size_t)1 << (log_n - log_len - log_c);
-    size_t lds = sizeof(fe) << (log_len + log_c);
+    size_t lds = sizeof(fl) << (log_len + log_c);
     launch("ntt_col_pass", ntt_col_pass, dim3((unsigned)tiles, count), dim3(kThreads), lds, stream, p);
     cur_in = scratch;
     first = false;
@@ -316,15 +350,15 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
     p.out = data;
     p.tw_small = tws[log_len];
     p.pre_scale = first ? pre : nullptr;
-    p.post_scale = (dir && coset) ? dom.coset_inv : nullptr;
+    p.post_scale = (dir && coset) ? dom.coset29_inv : nullptr;
     p.use_post_scalar = (dir && !coset) ? 1 : 0;
-    p.post_scalar = dom.n_inv;
+    p.post_scalar = dom.n_inv29;
     p.log_len = log_len;
     p.log_c = log_c;
     p.log_n1 = log_n1;
     p.log_n2 = log_n2;
     size_t tiles = (size_t)1 << (log_n - log_len - log_c);
-    size_t lds = sizeof(fe) << (log_len + log_c);
+    size_t lds = sizeof(fl) << (log_len + log_c);
     launch("ntt_row_pass", ntt_row_pass, dim3((unsigned)tiles, count), dim3(kThreads), lds, stream, p);
   }
   return (int)hipGetLastError();

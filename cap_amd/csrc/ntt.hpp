@@ -21,9 +21,16 @@ struct NttDomain {
   fe* coset_fwd = nullptr;  // 5^i,           i in [0, n)
   fe* coset_inv = nullptr;  // n^-1 * 5^-i,   i in [0, n)
   fe n_inv;                 // n^-1 (Montgomery)
+  // the same tables in the internal Montgomery form of the lazy 29-bit field (x * 2^261, canonical): what the
+  // NTT kernels multiply by.  (tw_fwd above stays in arkworks' form for the kernels that have not moved yet.)
+  fe* tw29_fwd = nullptr;
+  fe* tw29_inv = nullptr;
+  fe* coset29_fwd = nullptr;
+  fe* coset29_inv = nullptr;
+  fe n_inv29;
 };
 
-// Small-size twiddles shared by every domain: small_fwd[s] -> omega_{2^s}^i, i < 2^(s-1), s <= kMaxLogTile
+// Small-size twiddles shared by every domain (internal form): fwd[s] -> omega_{2^s}^i, i < 2^(s-1), s <= kMaxLogTile
 constexpr int kMaxLogTile = 11;
 struct NttSmallTables {
   fe* fwd[kMaxLogTile + 1] = {nullptr};

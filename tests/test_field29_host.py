@@ -1,0 +1,86 @@
+"""The lazy 29-bit field / curve code is host+device; these CPU tests compile it for the host with its bound
+assertions enabled (CAP_FL_CHECK) and check it against Python integers and against the 32-bit field code.
+(`-m "not gpu"`)"""
+import os
+import random
+import shutil
+import subprocess
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CPP = os.path.join(HERE, "cpp")
+P = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+R = 0x30644E72E131A029B85045B68181585D2833E84879B9709143E1F593F0000001
+RR = 1 << 261
+
+
+def _cxx():
+    for c in ("g++", "/opt/rocm/lib/llvm/bin/clang++", "clang++"):
+        if shutil.which(c) or os.path.exists(c):
+            return c
+    pytest.skip("no host C++ compiler")
+
+
+@pytest.fixture(scope="module")
+def binaries(tmp_path_factory):
+    out = tmp_path_factory.mktemp("f29")
+    cxx = _cxx()
+    bins = {}
+    for name in ("field29_check", "curve29_check"):
+        exe = str(out / name)
+        subprocess.check_call([cxx, "-O1", "-std=c++17", os.path.join(CPP, name + ".cpp"), "-o", exe])
+        bins[name] = exe
+    return bins
+
+
+def test_field29_against_python_integers(binaries):
+    random.seed(5)
+    lines, exp = [], []
+    for w, m in (("q", P), ("r", R)):
+        inv = pow(RR, -1, m)
+        for it in range(300):
+            ka, kb = random.choice([1, 2, 4, 17, 40]), random.choice([1, 2, 4, 15])
+            a = random.randrange(int(ka * m)) if it > 20 else random.choice([0, 1, m - 1, m, 2 * m - 1, int(16.9 * m)])
+            b = random.randrange(int(kb * m)) if it > 20 else random.choice([0, 1, m - 1, m, 2 * m, int(15.8 * m)])
+
+            def add(op, e):
+                lines.append(f"{w} {op} {a:x} {b:x}")
+                exp.append((op, e, m))
+            add("m", a * b * inv % m)
+            add("q", a * a * inv % m)
+            add("w", a % m)
+            add("c", a % m)
+            add("z", 1 if a % m == 0 else 0)
+            if b < 15.9 * m:
+                add("s", (a - b) % m)
+            add("a", (a + b) % m)
+            if a < (1 << 256):
+                add("p", a)
+                add("e", a * 32 % m)
+                add("t", a * RR % m)
+            add("x", a * pow(32, -1, m) % m)
+            add("f", a * inv % m)
+            if a < 8 * m and b < 8 * m:
+                add("M", 2 * a * b * inv % m)
+            add("E", 1 if (a - b) % m == 0 else 0)
+        for k in range(0, 160, 7):       # every multiple of p is recognised as zero
+            lines.append(f"{w} z {k * m:x} 0")
+            exp.append(("z", 1, m))
+    out = subprocess.run([binaries["field29_check"]], input="\n".join(lines) + "\n", capture_output=True, text=True)
+    assert out.returncode == 0, out.stderr[-500:]
+    res = out.stdout.split()
+    assert len(res) == len(exp)
+    for line, o, (op, e, m) in zip(lines, res, exp):
+        v = int(o, 16)
+        if op in "zEpcxf":
+            assert v == e, line
+        elif op == "w":
+            assert v % m == e and v < 2 * m, line
+        else:
+            assert v % m == e and v < (1 << 261), line
+
+
+def test_curve29_against_saturated_curve_code(binaries):
+    out = subprocess.run([binaries["curve29_check"]], capture_output=True, text=True)
+    assert out.returncode == 0 and "bad=0" in out.stdout, out.stdout[-500:] + out.stderr[-500:]
