@@ -21,7 +21,7 @@ namespace {
 constexpr uint32_t kSkip = 0xFFFFFFFFu;
 constexpr int kThreads = 256;
 constexpr uint32_t kReduceChunk = 4096;  // buckets per msm_reduce_bits workgroup
-constexpr uint32_t kDigitTile = 2048;    // scalars per msm_digits_local workgroup
+constexpr uint32_t kDigitTile = 1024;    // scalars per msm_digits_local workgroup (its entries are sorted in LDS)
 constexpr uint32_t kItemLen = 32;        // list entries per msm_accumulate work item
 
 __device__ __forceinline__ fl shfl_down_fl(const fl& a, int d) {
@@ -111,22 +111,47 @@ __global__ __launch_bounds__(kThreads) void msm_digits_hist(const fe* __restrict
 }
 
 // K3, LDS form (used whenever the bucket set fits LDS): a workgroup owns a tile of kDigitTile scalars of one batch
-// entry, histograms their digits in LDS (rank inside the tile = returned LDS atomic) and writes one row of the
-// [bucket][tile] table.  A scan of that table (bucket-major) then gives every (bucket, tile) its list position:
-// no global atomics, and the sorted order - hence the bit pattern of the Jacobian result - is deterministic.
+// entry and sorts that tile's (window, scalar) entries by bucket entirely in LDS: pass A histograms the digits,
+// a workgroup scan turns counts into tile-local offsets, pass B recomputes the digits and drops each table index
+// at its slot.  The tile-sorted chunk goes to HBM with coalesced stores together with one row of the
+// [bucket][tile] count table and of the tile-local offset table.  A scan of the count table (bucket-major) then
+// gives every (bucket, tile) run its final position: no global atomics, no per-entry scattered store.
+__device__ __forceinline__ uint32_t msm_digit(const fe& k, uint32_t w, uint32_t c, uint32_t& carry) {
+  const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1;
+  uint32_t bit = w * c;
+  uint32_t limb = bit >> 5, off = bit & 31;
+  uint32_t v = 0;
+  if (limb < 8) {
+    uint64_t two = (uint64_t)k.v[limb] | (limb + 1 < 8 ? ((uint64_t)k.v[limb + 1] << 32) : 0);
+    v = (uint32_t)(two >> off) & mask;
+  }
+  v += carry;
+  if (v > half) {
+    carry = 1;
+    return ((1u << c) - v) | 0x80000000u;  // magnitude | sign
+  }
+  carry = 0;
+  return v;
+}
+
 __global__ __launch_bounds__(kThreads) void msm_digits_local(const fe* __restrict__ scalars, size_t outer_stride,
                                                              uint32_t inner, size_t inner_stride, size_t n,
                                                              int montgomery, uint32_t c, uint32_t windows,
-                                                             uint32_t nblk, uint32_t* __restrict__ table,
-                                                             uint32_t* __restrict__ keys,
-                                                             uint32_t* __restrict__ ranks) {
-  extern __shared__ uint32_t hist[];
-  const uint32_t b = blockIdx.y, blk = blockIdx.x;
+                                                             uint32_t nblk, size_t srs_n, size_t base_offset,
+                                                             uint32_t* __restrict__ table,
+                                                             uint32_t* __restrict__ tloc,
+                                                             uint32_t* __restrict__ chunks) {
+  extern __shared__ uint32_t lds[];
   const uint32_t half = 1u << (c - 1);
-  const uint32_t mask = (1u << c) - 1;
+  uint32_t* hist = lds;              // [half]   counts, then running cursors
+  uint32_t* loff = lds + half;       // [half]   tile-local exclusive offsets
+  uint32_t* buf = lds + 2 * half;    // [kDigitTile * windows] sorted entries
+  __shared__ uint32_t wave_tot[kThreads / 64];
+  const uint32_t b = blockIdx.y, blk = blockIdx.x;
   for (uint32_t j = threadIdx.x; j < half; j += kThreads) hist[j] = 0;
   __syncthreads();
   const fe* sc = scalars + (size_t)(b / inner) * outer_stride + (size_t)(b % inner) * inner_stride;
+  // pass A: histogram
   for (uint32_t q = 0; q < kDigitTile / kThreads; q++) {
     size_t i = (size_t)blk * kDigitTile + q * kThreads + threadIdx.x;
     if (i >= n) break;
@@ -134,35 +159,62 @@ __global__ __launch_bounds__(kThreads) void msm_digits_local(const fe* __restric
     if (montgomery) k = Fr::from_mont(k);
     uint32_t carry = 0;
     for (uint32_t w = 0; w < windows; w++) {
-      uint32_t bit = w * c;
-      uint32_t limb = bit >> 5, off = bit & 31;
-      uint32_t v = 0;
-      if (limb < 8) {
-        uint64_t two = (uint64_t)k.v[limb] | (limb + 1 < 8 ? ((uint64_t)k.v[limb + 1] << 32) : 0);
-        v = (uint32_t)(two >> off) & mask;
-      }
-      v += carry;
-      uint32_t neg = 0;
-      if (v > half) {
-        v = (1u << c) - v;
-        neg = 1;
-        carry = 1;
-      } else {
-        carry = 0;
-      }
-      size_t e = ((size_t)b * windows + w) * n + i;
-      if (v == 0) {
-        keys[e] = kSkip;
-      } else {
-        uint32_t bucket = v - 1;
-        uint32_t r = atomicAdd(&hist[bucket], 1u);
-        keys[e] = bucket | (neg << 31);
-        ranks[e] = r;
+      uint32_t d = msm_digit(k, w, c, carry) & 0x7FFFFFFFu;
+      if (d) atomicAdd(&hist[d - 1], 1u);
+    }
+  }
+  __syncthreads();
+  // exclusive scan of hist -> loff (each thread owns half / kThreads consecutive buckets)
+  {
+    const uint32_t per_t = half / kThreads ? half / kThreads : 1;
+    uint32_t j0 = threadIdx.x * per_t;
+    uint32_t run = 0;
+    for (uint32_t t = 0; t < per_t && j0 + t < half; t++) run += hist[j0 + t];
+    uint32_t inc = run;
+    const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t o = __shfl_up(inc, d);
+      if ((int)lane >= d) inc += o;
+    }
+    if (lane == 63) wave_tot[wave] = inc;
+    __syncthreads();
+    uint32_t pre = inc - run;
+    for (uint32_t w = 0; w < wave; w++) pre += wave_tot[w];
+    for (uint32_t t = 0; t < per_t && j0 + t < half; t++) {
+      loff[j0 + t] = pre;
+      pre += hist[j0 + t];
+    }
+  }
+  __syncthreads();
+  // rows of the global tables; cursors start at the local offsets
+  for (uint32_t j = threadIdx.x; j < half; j += kThreads) {
+    size_t row = ((size_t)b * half + j) * nblk + blk;
+    table[row] = hist[j];
+    tloc[row] = loff[j];
+    hist[j] = loff[j];
+  }
+  __syncthreads();
+  // pass B: place the table indices
+  for (uint32_t q = 0; q < kDigitTile / kThreads; q++) {
+    size_t i = (size_t)blk * kDigitTile + q * kThreads + threadIdx.x;
+    if (i >= n) break;
+    fe k = sc[i];
+    if (montgomery) k = Fr::from_mont(k);
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < windows; w++) {
+      uint32_t d = msm_digit(k, w, c, carry);
+      uint32_t mag = d & 0x7FFFFFFFu;
+      if (mag) {
+        uint32_t slot = atomicAdd(&hist[mag - 1], 1u);
+        buf[slot] = (uint32_t)((size_t)w * srs_n + base_offset + i) | (d & 0x80000000u);
       }
     }
   }
   __syncthreads();
-  for (uint32_t j = threadIdx.x; j < half; j += kThreads) table[((size_t)b * half + j) * nblk + blk] = hist[j];
+  // coalesced store of the tile-sorted chunk
+  const uint32_t total = hist[half - 1];  // cursor of the last bucket after pass B = number of entries of the tile
+  uint32_t* dst = chunks + ((size_t)b * nblk + blk) * ((size_t)kDigitTile * windows);
+  for (uint32_t e = threadIdx.x; e < total; e += kThreads) dst[e] = buf[e];
 }
 
 // bucket list ranges from the scanned [bucket][tile] table
@@ -181,27 +233,23 @@ __global__ __launch_bounds__(kThreads) void msm_bucket_ranges(const uint32_t* __
   counts[gb] = next - o;
 }
 
-__global__ __launch_bounds__(kThreads) void msm_scatter_local(const uint32_t* __restrict__ keys,
-                                                              const uint32_t* __restrict__ ranks,
-                                                              const uint32_t* __restrict__ off2, size_t n,
-                                                              uint32_t batch, uint32_t c, uint32_t windows,
-                                                              uint32_t nblk, size_t srs_n, size_t base_offset,
-                                                              uint32_t* __restrict__ sorted) {
-  size_t per = (size_t)windows * n;
-  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= per * batch) return;
-  uint32_t key = keys[e];
-  if (key == kSkip) return;
-  uint32_t b = (uint32_t)(e / per);
-  size_t rem = e - (size_t)b * per;
-  uint32_t w = (uint32_t)(rem / n);
-  size_t i = rem - (size_t)w * n;
-  const uint32_t half = 1u << (c - 1);
-  uint32_t bucket = key & 0x7FFFFFFFu;
-  uint32_t blk = (uint32_t)(i / kDigitTile);
-  uint32_t pos = off2[((size_t)b * half + bucket) * nblk + blk] + ranks[e];
-  uint32_t tidx = (uint32_t)((size_t)w * srs_n + base_offset + i);
-  sorted[(size_t)b * per + pos] = tidx | (key & 0x80000000u);
+// K4: every (bucket, tile) run of a tile-sorted chunk is copied to its final place; runs of one bucket from
+// consecutive tiles are adjacent in the destination, so consecutive threads write consecutive bytes.
+__global__ __launch_bounds__(kThreads) void msm_scatter_runs(const uint32_t* __restrict__ chunks,
+                                                             const uint32_t* __restrict__ table,
+                                                             const uint32_t* __restrict__ tloc,
+                                                             const uint32_t* __restrict__ off2, size_t per,
+                                                             uint32_t half, uint32_t nblk, uint32_t windows,
+                                                             size_t total_rows, uint32_t* __restrict__ sorted) {
+  size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b * half + bucket) * nblk + blk
+  if (row >= total_rows) return;
+  uint32_t cnt = table[row];
+  if (cnt == 0) return;
+  uint32_t blk = (uint32_t)(row % nblk);
+  uint32_t b = (uint32_t)(row / ((size_t)half * nblk));
+  const uint32_t* src = chunks + ((size_t)b * nblk + blk) * ((size_t)kDigitTile * windows) + tloc[row];
+  uint32_t* dst = sorted + (size_t)b * per + off2[row];
+  for (uint32_t e = 0; e < cnt; e++) dst[e] = src[e];
 }
 
 // ---- K4: exclusive scan, one workgroup per batch entry ------------------------------------------
@@ -395,12 +443,13 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
   size_t counts, offsets, keys, ranks, sorted, buckets, partial, item_off, item_base, totals, item_bucket, item_pts,
-      max_items, table, off2, nblk, total;
+      max_items, table, off2, tloc, chunks, nblk, total;
 };
 bool use_local_digits(uint32_t c, size_t n, uint32_t batch) {
   size_t half = (size_t)1 << (c - 1);
   size_t nblk = (n + kDigitTile - 1) / kDigitTile;
-  return half <= 8192 && n > 0 && half * nblk * batch <= ((size_t)1 << 26);
+  // LDS: 2 * half counters + kDigitTile * W entries (<= 160 KiB with c <= 14)
+  return half <= 8192 && n > 0 && half * nblk * batch <= ((size_t)1 << 28);
 }
 WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t batch) {
   WsLayout L{};
@@ -424,6 +473,8 @@ WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t batch) {
   L.nblk = use_local_digits(c, n, batch) ? (n + kDigitTile - 1) / kDigitTile : 0;
   L.table = o;       o = align_up(o + sizeof(uint32_t) * half * L.nblk * batch, 256);
   L.off2 = o;        o = align_up(o + sizeof(uint32_t) * half * L.nblk * batch, 256);
+  L.tloc = o;        o = align_up(o + sizeof(uint32_t) * half * L.nblk * batch, 256);
+  L.chunks = o;      o = align_up(o + sizeof(uint32_t) * (size_t)kDigitTile * windows * L.nblk * batch, 256);
   L.total = o;
   return L;
 }
@@ -498,16 +549,25 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
     const uint32_t nblk = (uint32_t)L.nblk;
     uint32_t* table = reinterpret_cast<uint32_t*>(base + L.table);
     uint32_t* off2 = reinterpret_cast<uint32_t*>(base + L.off2);
-    launch("msm_digits_local", msm_digits_local, dim3(nblk, batch), dim3(kThreads), sizeof(uint32_t) * half, stream,
-           d_scalars, outer_stride, inner, inner_stride, n, montgomery, c, W, nblk, table, keys, ranks);
+    uint32_t* tloc = reinterpret_cast<uint32_t*>(base + L.tloc);
+    uint32_t* chunk_buf = reinterpret_cast<uint32_t*>(base + L.chunks);
+    size_t lds_bytes = sizeof(uint32_t) * (2 * (size_t)half + (size_t)kDigitTile * W);
+    static bool attr_set = false;
+    if (!attr_set) {
+      hipFuncSetAttribute(reinterpret_cast<const void*>(msm_digits_local), hipFuncAttributeMaxDynamicSharedMemorySize,
+                          160 * 1024 - 64);
+      attr_set = true;
+    }
+    launch("msm_digits_local", msm_digits_local, dim3(nblk, batch), dim3(kThreads), lds_bytes, stream, d_scalars,
+           outer_stride, inner, inner_stride, n, montgomery, c, W, nblk, bases.n, offset, table, tloc, chunk_buf);
     launch("msm_scan", msm_scan<0>, dim3(batch), dim3(1024), 0, stream, (const uint32_t*)table, off2, half * nblk,
            (uint32_t*)nullptr);
     launch("msm_bucket_ranges", msm_bucket_ranges, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0,
            stream, (const uint32_t*)table, (const uint32_t*)off2, half, nblk, total_buckets, counts, offsets);
-    size_t ne = per * batch;
-    launch("msm_scatter", msm_scatter_local, dim3((unsigned)((ne + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
-           (const uint32_t*)keys, (const uint32_t*)ranks, (const uint32_t*)off2, n, batch, c, W, nblk, bases.n, offset,
-           sorted);
+    size_t rows = (size_t)total_buckets * nblk;
+    launch("msm_scatter", msm_scatter_runs, dim3((unsigned)((rows + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
+           (const uint32_t*)chunk_buf, (const uint32_t*)table, (const uint32_t*)tloc, (const uint32_t*)off2, per, half,
+           nblk, W, rows, sorted);
   } else {
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(uint32_t) * (size_t)half * batch, stream);
     if (e != hipSuccess) return (int)e;
