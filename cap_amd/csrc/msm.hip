@@ -22,6 +22,7 @@ constexpr uint32_t kSkip = 0xFFFFFFFFu;
 constexpr int kThreads = 256;
 constexpr uint32_t kReduceChunk = 4096;  // buckets per msm_reduce_bits workgroup
 constexpr uint32_t kDigitTile = 1024;    // scalars per msm_digits_local workgroup (its entries are sorted in LDS)
+constexpr int kDigitThreads = 1024;       // one scalar per thread: 16 waves hide the LDS-atomic latency
 constexpr uint32_t kItemLen = 32;        // list entries per msm_accumulate work item
 
 __device__ __forceinline__ fl shfl_down_fl(const fl& a, int d) {
@@ -134,7 +135,7 @@ __device__ __forceinline__ uint32_t msm_digit(const fe& k, uint32_t w, uint32_t 
   return v;
 }
 
-__global__ __launch_bounds__(kThreads) void msm_digits_local(const fe* __restrict__ scalars, size_t outer_stride,
+__global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __restrict__ scalars, size_t outer_stride,
                                                              uint32_t inner, size_t inner_stride, size_t n,
                                                              int montgomery, uint32_t c, uint32_t windows,
                                                              uint32_t nblk, size_t srs_n, size_t base_offset,
@@ -146,14 +147,14 @@ __global__ __launch_bounds__(kThreads) void msm_digits_local(const fe* __restric
   uint32_t* hist = lds;              // [half]   counts, then running cursors
   uint32_t* loff = lds + half;       // [half]   tile-local exclusive offsets
   uint32_t* buf = lds + 2 * half;    // [kDigitTile * windows] sorted entries
-  __shared__ uint32_t wave_tot[kThreads / 64];
+  __shared__ uint32_t wave_tot[kDigitThreads / 64];
   const uint32_t b = blockIdx.y, blk = blockIdx.x;
-  for (uint32_t j = threadIdx.x; j < half; j += kThreads) hist[j] = 0;
+  for (uint32_t j = threadIdx.x; j < half; j += kDigitThreads) hist[j] = 0;
   __syncthreads();
   const fe* sc = scalars + (size_t)(b / inner) * outer_stride + (size_t)(b % inner) * inner_stride;
   // pass A: histogram
-  for (uint32_t q = 0; q < kDigitTile / kThreads; q++) {
-    size_t i = (size_t)blk * kDigitTile + q * kThreads + threadIdx.x;
+  for (uint32_t q = 0; q < kDigitTile / kDigitThreads; q++) {
+    size_t i = (size_t)blk * kDigitTile + q * kDigitThreads + threadIdx.x;
     if (i >= n) break;
     fe k = sc[i];
     if (montgomery) k = Fr::from_mont(k);
@@ -164,9 +165,9 @@ __global__ __launch_bounds__(kThreads) void msm_digits_local(const fe* __restric
     }
   }
   __syncthreads();
-  // exclusive scan of hist -> loff (each thread owns half / kThreads consecutive buckets)
+  // exclusive scan of hist -> loff (each thread owns half / kDigitThreads consecutive buckets)
   {
-    const uint32_t per_t = half / kThreads ? half / kThreads : 1;
+    const uint32_t per_t = half / kDigitThreads ? half / kDigitThreads : 1;
     uint32_t j0 = threadIdx.x * per_t;
     uint32_t run = 0;
     for (uint32_t t = 0; t < per_t && j0 + t < half; t++) run += hist[j0 + t];
@@ -187,7 +188,7 @@ __global__ __launch_bounds__(kThreads) void msm_digits_local(const fe* __restric
   }
   __syncthreads();
   // rows of the global tables; cursors start at the local offsets
-  for (uint32_t j = threadIdx.x; j < half; j += kThreads) {
+  for (uint32_t j = threadIdx.x; j < half; j += kDigitThreads) {
     size_t row = ((size_t)b * half + j) * nblk + blk;
     table[row] = hist[j];
     tloc[row] = loff[j];
@@ -195,8 +196,8 @@ __global__ __launch_bounds__(kThreads) void msm_digits_local(const fe* __restric
   }
   __syncthreads();
   // pass B: place the table indices
-  for (uint32_t q = 0; q < kDigitTile / kThreads; q++) {
-    size_t i = (size_t)blk * kDigitTile + q * kThreads + threadIdx.x;
+  for (uint32_t q = 0; q < kDigitTile / kDigitThreads; q++) {
+    size_t i = (size_t)blk * kDigitTile + q * kDigitThreads + threadIdx.x;
     if (i >= n) break;
     fe k = sc[i];
     if (montgomery) k = Fr::from_mont(k);
@@ -214,7 +215,7 @@ __global__ __launch_bounds__(kThreads) void msm_digits_local(const fe* __restric
   // coalesced store of the tile-sorted chunk
   const uint32_t total = hist[half - 1];  // cursor of the last bucket after pass B = number of entries of the tile
   uint32_t* dst = chunks + ((size_t)b * nblk + blk) * ((size_t)kDigitTile * windows);
-  for (uint32_t e = threadIdx.x; e < total; e += kThreads) dst[e] = buf[e];
+  for (uint32_t e = threadIdx.x; e < total; e += kDigitThreads) dst[e] = buf[e];
 }
 
 // bucket list ranges from the scanned [bucket][tile] table
@@ -347,7 +348,7 @@ __global__ __launch_bounds__(kThreads) void msm_scatter(const uint32_t* __restri
 // wavefront therefore runs (almost) the same number of mixed additions whatever the bucket sizes are - a
 // thread-per-bucket mapping loses ~40 % to wave quantisation and the Poisson spread of list lengths, and
 // degrades without bound on skewed scalars (one giant bucket = one serial chain).
-__global__ __launch_bounds__(kThreads, 4) void msm_accumulate(const g1_affine* __restrict__ ext,
+__global__ __launch_bounds__(kThreads) void msm_accumulate(const g1_affine* __restrict__ ext,
                                                            const uint32_t* __restrict__ sorted,
                                                            const uint32_t* __restrict__ counts,
                                                            const uint32_t* __restrict__ offsets,
@@ -558,7 +559,7 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
                           160 * 1024 - 64);
       attr_set = true;
     }
-    launch("msm_digits_local", msm_digits_local, dim3(nblk, batch), dim3(kThreads), lds_bytes, stream, d_scalars,
+    launch("msm_digits_local", msm_digits_local, dim3(nblk, batch), dim3(kDigitThreads), lds_bytes, stream, d_scalars,
            outer_stride, inner, inner_stride, n, montgomery, c, W, nblk, bases.n, offset, table, tloc, chunk_buf);
     launch("msm_scan", msm_scan<0>, dim3(batch), dim3(1024), 0, stream, (const uint32_t*)table, off2, half * nblk,
            (uint32_t*)nullptr);
