@@ -401,9 +401,12 @@ __global__ __launch_bounds__(kThreads) void msm_reduce_bits(const g1_xyzz* __res
   const uint32_t chunk = blockIdx.x, bit = blockIdx.y, b = blockIdx.z;
   const g1_xyzz* bk = buckets + (size_t)b * half;
   g1x acc = G1L::inf();
-  for (uint32_t q = 0; q < kReduceChunk / kThreads; q++) {
-    uint32_t j = chunk * kReduceChunk + q * kThreads + threadIdx.x;
-    if (j < half && (((j + 1) >> bit) & 1)) acc = G1L::add(acc, G1L::load(bk[j]));
+  // enumerate only the weights v = j + 1 in [1, half] that have `bit` set: v = idx with a 1 inserted at `bit`
+  // (every lane does useful work; a predicate on j would leave half the lanes idle for the low bits)
+  for (uint32_t q = 0; q < kReduceChunk / 2 / kThreads; q++) {
+    uint32_t idx = chunk * (kReduceChunk / 2) + q * kThreads + threadIdx.x;
+    uint32_t v = ((idx >> bit) << (bit + 1)) | (1u << bit) | (idx & ((1u << bit) - 1));
+    if (v <= half) acc = G1L::add(acc, G1L::load(bk[v - 1]));
   }
   for (int d = 32; d >= 1; d >>= 1) {
     g1x o = shfl_down_pt(acc, d);
