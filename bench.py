@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_BATCH = 16       # batch size of the committed PMC pass (profiles/traffic_r01.json)
+TRAFFIC_BATCH = 64       # batch size of the committed PMC pass (profiles/traffic_r01.json)
 
 
 def algorithmic_bytes_per_proof(n: int) -> dict:
@@ -56,7 +56,7 @@ def _weighted_sums(sc: np.ndarray, lo: int):
     return s0, s1
 
 
-def msm_leg(cg, bu, torch, dist, rank, world, log_n, iters=5):
+def msm_leg(cg, bu, torch, dist, rank, world, log_n, iters=5, coll_dev="cuda"):
     """Point-range-sharded MSM: bases P_i = [a + i b]G generated on each rank's GPU for its range,
     scalars resident, local Pippenger, ONE exchange step (all-gather of a 96-byte Jacobian point per rank) and
     G-1 group additions.  Checked against [sum k_i (a + i b)] G."""
@@ -85,10 +85,10 @@ def msm_leg(cg, bu, torch, dist, rank, world, log_n, iters=5):
     dt = (time.perf_counter() - t0) / iters
     part = d_out.to_numpy()
     if dist is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        parts = par.all_gather_points(part, device="cuda")
+        parts = par.all_gather_points(part, device=coll_dev)
         total = cg.g1_sum(parts)
     else:
         total = part
@@ -131,6 +131,9 @@ def main():
                     help="transfer: P identical-shape 2-in/2-out transfer proofs per GPU (weak scaling, the headline); "
                          "mixed64: BASELINE config 4 - 32 transfer(2x3) + 13 mint + 19 freeze(3) proofs in total, "
                          "proof i on rank i mod N (strong scaling)")
+    ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
+                    help="nccl (= RCCL, the real multi-GPU path); gloo only to exercise the N>1 logic on a 1-GPU box "
+                         "together with CAPGPU_BENCH_DEVICE=0")
     ap.add_argument("--no-msm", action="store_true")
     ap.add_argument("--msm-log-n", type=int, default=20, help="size of the sharded MSM leg (24 = BASELINE config 5)")
     args = ap.parse_args()
@@ -138,12 +141,18 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if "CAPGPU_BENCH_DEVICE" in os.environ:          # test hook: all ranks on one device (gloo only)
+        local_rank = int(os.environ["CAPGPU_BENCH_DEVICE"])
     import torch
     dist = None
+    coll_dev = "cuda" if args.dist_backend == "nccl" else "cpu"
     if world > 1:
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        if args.dist_backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=world)
 
     from cap_amd import bench_utils as bu
     from cap_amd import lib as cg
@@ -220,7 +229,7 @@ def main():
         stats = cg.profile_stats() if profile else {}
         cg.profile_enable(False)
         if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+            t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
         return dt, stats, proofs
@@ -261,7 +270,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
                     # HBM bytes per launch from the committed PMC pass (profiles/traffic_r01.json, batch 16) or null
-                    "traffic": traffic_tab.get(dom) if P == TRAFFIC_BATCH and log_n == 15 else None,
+                    "traffic": traffic_tab.get(dom) if (P == TRAFFIC_BATCH and log_n == 15 and args.workload == "transfer") else None,
                     "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
                     "share_of_kernel_time": kern_ms[dom] / sum(kern_ms.values())}
     top = sorted(kern_ms.items(), key=lambda kv: -kv[1])[:8]
@@ -322,8 +331,8 @@ def main():
     if not args.no_msm:
         legs = []
         if world == 1:
-            legs.append(msm_leg(cg, bu, torch, dist, rank, world, 17))
-        legs.append(msm_leg(cg, bu, torch, dist, rank, world, args.msm_log_n))
+            legs.append(msm_leg(cg, bu, torch, dist, rank, world, 17, coll_dev=coll_dev))
+        legs.append(msm_leg(cg, bu, torch, dist, rank, world, args.msm_log_n, coll_dev=coll_dev))
         out["msm"] = legs
     if rank == 0:
         print(json.dumps(out), flush=True)
