@@ -121,9 +121,9 @@ def _words_to_ints(words):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=64, help="proofs per step per GPU")
+    ap.add_argument("--batch", type=int, default=128, help="proofs per step per GPU")
     ap.add_argument("--log-n", type=int, default=15, help="evaluation domain (15: pinned for depth 10; 16: upper bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-schedule", action="store_true")

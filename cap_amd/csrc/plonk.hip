@@ -16,6 +16,9 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
+#include <atomic>
+#include <thread>
 #include <vector>
 
 #include "context.hpp"
@@ -151,6 +154,31 @@ void append_fr(SolidityTranscript& t, const fe& a) {
 void affine_to_words(const g1_affine& p, uint64_t out[8]) {
   fe_to_words(p.x, out);
   fe_to_words(p.y, out + 4);
+}
+
+// The per-proof host work between rounds (Keccak transcript, a handful of field operations) is independent across
+// the proofs of a batch; the reference runs it under rayon (src/utils/params_builder.rs:194-226).  A serial loop
+// leaves the GPU idle for ~20 % of a 64-proof step.
+template <class F>
+void parallel_for(uint32_t count, F&& fn) {
+  static const unsigned hw = [] {
+    const char* e = getenv("CAPGPU_HOST_THREADS");
+    unsigned v = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
+    return std::min(std::max(v, 1u), 32u);
+  }();
+  const unsigned nt = std::min<unsigned>(hw, count);
+  if (nt <= 1) {
+    for (uint32_t i = 0; i < count; i++) fn(i);
+    return;
+  }
+  auto work = [&](unsigned t) {
+    for (uint32_t i = t; i < count; i += nt) fn(i);
+  };
+  std::vector<std::thread> th;
+  th.reserve(nt - 1);
+  for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
+  work(0);
+  for (auto& x : th) x.join();
 }
 
 // ---- launch helpers -----------------------------------------------------------------------------------------
@@ -303,11 +331,11 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
 
   // ---- transcripts (host) --------------------------------------------------------------------------------
   std::vector<SolidityTranscript> tr(P);
-  for (uint32_t p = 0; p < P; p++) {
+  parallel_for(P, [&](uint32_t p) {
     if (ext_msg && ext_len) tr[p].append(ext_msg, ext_len);
     tr[p].append(K.vk_bytes.data(), K.vk_bytes.size());
     for (size_t i = 0; i < num_inputs; i++) append_fr(tr[p], fe_from_words(pub_inputs + 4 * (p * num_inputs + i)));
-  }
+  });
   if (num_inputs)
     CAP_HIP(hipMemcpyAsync(w.d_pub, pub_inputs, sizeof(fe) * P * num_inputs, hipMemcpyHostToDevice, s));
   CAP_HIP(hipMemcpyAsync(w.d_blind, blinders, sizeof(fe) * P * 13, hipMemcpyHostToDevice, s));
@@ -333,7 +361,7 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
   if ((rc = run_msm(s, *B, w.wpoly, ps, 1, 0, n + 2, P * NW, w.comms))) return rc;
   if ((rc = fetch_comms(P * NW))) return rc;
   std::vector<Chal> chal(P);
-  for (uint32_t p = 0; p < P; p++) {
+  parallel_for(P, [&](uint32_t p) {
     for (int i = 0; i < NW; i++) {
       append_g1(tr[p], ha[p * NW + i]);
       affine_to_words(ha[p * NW + i], proofs[p].wires_poly_comms[i]);
@@ -343,7 +371,7 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
     chal[p].gamma = get_challenge(tr[p]);
     chal[p].alpha = Fr::zero();
     chal[p].alpha2 = Fr::zero();
-  }
+  });
   CAP_HIP(hipMemcpyAsync(w.chal, chal.data(), sizeof(Chal) * P, hipMemcpyHostToDevice, s));
 
   // ---- round 2: permutation grand product --------------------------------------------------------------
@@ -362,12 +390,12 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
   launch("k_blind", k_blind, dim3(P), dim3(64), 0, s, w.zpoly, ps, n, (const fe*)w.d_blind, 1u, 10u, 3u, P);
   if ((rc = run_msm(s, *B, w.zpoly, ps, 1, 0, n + 3, P, w.comms))) return rc;
   if ((rc = fetch_comms(P))) return rc;
-  for (uint32_t p = 0; p < P; p++) {
+  parallel_for(P, [&](uint32_t p) {
     append_g1(tr[p], ha[p]);
     affine_to_words(ha[p], proofs[p].prod_perm_poly_comm);
     chal[p].alpha = get_challenge(tr[p]);
     chal[p].alpha2 = Fr::sqr(chal[p].alpha);
-  }
+  });
   CAP_HIP(hipMemcpyAsync(w.chal, chal.data(), sizeof(Chal) * P, hipMemcpyHostToDevice, s));
 
   // ---- round 3: quotient polynomial ---------------------------------------------------------------------
@@ -405,14 +433,15 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
   std::vector<fe> zeta(P), zeta_w(P);
   std::vector<fe> pw((size_t)P * 4 * 24);
   const fe omega = ntt_root_of_unity(K.log_n);
-  for (uint32_t p = 0; p < P; p++) {
+  parallel_for(P, [&](uint32_t p) {
     for (int i = 0; i < NW; i++) {
       append_g1(tr[p], ha[p * NW + i]);
       affine_to_words(ha[p * NW + i], proofs[p].split_quot_poly_comms[i]);
     }
     zeta[p] = get_challenge(tr[p]);
     zeta_w[p] = Fr::mul(zeta[p], omega);
-    fe bases4[4] = {zeta[p], zeta_w[p], Fr::inv(zeta[p]), Fr::inv(zeta_w[p])};
+    fe zi = Fr::inv(Fr::mul(zeta[p], zeta_w[p]));  // one inversion for both: 1/z = zw * zi, 1/zw = z * zi
+    fe bases4[4] = {zeta[p], zeta_w[p], Fr::mul(zeta_w[p], zi), Fr::mul(zeta[p], zi)};
     for (int q = 0; q < 4; q++) {
       fe x = bases4[q];
       for (int b = 0; b < 24; b++) {
@@ -420,7 +449,7 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
         x = Fr::sqr(x);
       }
     }
-  }
+  });
 
   // ---- round 4: evaluations -------------------------------------------------------------------------------
   CAP_HIP(hipMemcpyAsync(w.pw, pw.data(), sizeof(fe) * pw.size(), hipMemcpyHostToDevice, s));
@@ -447,7 +476,8 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
   // ---- round 5: linearisation + opening proofs ---------------------------------------------------------
   std::vector<LinTerm> terms((size_t)P * kLinTerms);
   const fe n_mont = fr_from_u64((uint64_t)n);
-  for (uint32_t p = 0; p < P; p++) {
+  std::atomic<int> lin_err{0};
+  parallel_for(P, [&](uint32_t p) {
     const fe* ev = &evals[(size_t)p * 10];
     const fe *we = ev, *se = ev + NW;
     const fe znext = ev[9];
@@ -511,10 +541,11 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
       add_term(K.coef + (size_t)(NS + j) * ps, cf, n);
       cf = Fr::mul(cf, v);
     }
-    if (t != (int)kLinTerms) {
-      set_error("capgpu: internal error: %d linear terms", t);
-      return CAPGPU_ERR_PROOF;
-    }
+    if (t != (int)kLinTerms) lin_err = t;
+  });
+  if (lin_err) {
+    set_error("capgpu: internal error: %d linear terms", lin_err.load());
+    return CAPGPU_ERR_PROOF;
   }
   CAP_HIP(hipMemcpyAsync(w.terms, terms.data(), sizeof(LinTerm) * terms.size(), hipMemcpyHostToDevice, s));
   // batchpoly[p][0] = linear combination, batchpoly[p][1] = z polynomial
