@@ -186,6 +186,8 @@ def main():
         sc = bu.synthetic_circuit(ln, ni, seed=2 + ln + ni)
         sel, sig = sc.selectors_mont(), sc.sigma_mont()
         pk, _vk = cg.plonk_preprocess(srs, 1 << ln, ni, sel, sig)
+        if not groups:
+            _vk0 = _vk
         n_wit = max(1, min(cnt, 4))
         wit = [sc.witness(1000 * rank + 3 + i) for i in range(n_wit)]
         g = {"kind": kind, "n": 1 << ln, "num_inputs": ni, "count": cnt, "pk": pk, "sel": sel, "sig": sig}
@@ -322,6 +324,11 @@ def main():
                                     a["opening_proof"][None], a["shifted_opening_proof"][None]])
         got_evals = np.concatenate([a["wires_evals"], a["wire_sigma_evals"], a["perm_next_eval"][None]])
         parity = bool(rc == 0 and np.array_equal(got_comms, comms) and np.array_equal(got_evals, evals))
+        h2 = cg.g2_generator()
+        t0 = time.perf_counter()
+        accepted = cg.plonk_verify(_vk0, h2, cg.g2_mul(h2, tau), pubs[0], proofs[0], ext_msg)
+        out["verify"] = {"accepted_by_product_verifier": bool(accepted), "ms": (time.perf_counter() - t0) * 1e3,
+                         "note": "host-side pairing check (capgpu_plonk_verify), outside the timed region"}
         out["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "proofs/s", "cores": 1, "kind": "port",
                                "sample": f"1 proof of the same workload (n=2^{log_n}), {t_cpu:.1f} s, single-thread C "
                                          "restatement of the arkworks/jf-plonk algorithm (reference schedule, no asm)",

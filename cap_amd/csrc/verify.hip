@@ -1,0 +1,268 @@
+// Host-side TurboPlonk verifier: the acceptance predicate of the hot path's output.
+//
+// Replaces `jf_plonk::PlonkKzgSnark::verify::<SolidityTranscript>` as called by
+// `proof::transfer::verify` (src/proof/transfer.rs:192-212), `proof::mint::verify` (src/proof/mint.rs:124-140)
+// and `proof::freeze::verify` (src/proof/freeze.rs:162-178).  The reference verifies on the CPU in milliseconds;
+// so does this (no device needed, no capgpu_init needed): challenges from the Keccak transcript, ~25 G1 scalar
+// multiplications for the linearisation commitment, and one product of two pairings (pairing.hpp).
+#include <string.h>
+
+#include <vector>
+
+#include "../../include/capgpu.h"
+#include "host_util.hpp"
+#include "pairing.hpp"
+
+namespace cap {
+void set_error(const char* fmt, ...);
+
+namespace {
+
+using pairing::fq2;
+using pairing::g2_affine;
+
+g1_xyzz g1_smul(const g1_affine& p, const fe& k_mont) {
+  fe k = Fr::from_mont(k_mont);
+  g1_xyzz acc = G1::inf();
+  bool started = false;
+  for (int i = 7; i >= 0; i--)
+    for (int b = 31; b >= 0; b--) {
+      if (started) acc = G1::dbl(acc);
+      if ((k.v[i] >> b) & 1) {
+        acc = G1::add_mixed(acc, p);
+        started = true;
+      }
+    }
+  return acc;
+}
+g1_affine g1_from_words(const uint64_t w[8]) {
+  g1_affine p;
+  p.x = fe_from_words(w);
+  p.y = fe_from_words(w + 4);
+  return p;
+}
+g2_affine g2_from_words(const uint64_t w[16]) {
+  g2_affine q;
+  q.x = {fe_from_words(w), fe_from_words(w + 4)};
+  q.y = {fe_from_words(w + 8), fe_from_words(w + 12)};
+  q.inf = pairing::f2_is_zero(q.x) && pairing::f2_is_zero(q.y);
+  return q;
+}
+void g2_to_words(const g2_affine& q, uint64_t w[16]) {
+  if (q.inf) {
+    memset(w, 0, 16 * sizeof(uint64_t));
+    return;
+  }
+  fe_to_words(q.x.c0, w);
+  fe_to_words(q.x.c1, w + 4);
+  fe_to_words(q.y.c0, w + 8);
+  fe_to_words(q.y.c1, w + 12);
+}
+bool g1_on_curve(const g1_affine& p) {
+  if (G1::is_inf(p)) return true;
+  fe b3 = Fq::add(Fq::add(Fq::one(), Fq::one()), Fq::one());
+  return Fq::eq(Fq::sqr(p.y), Fq::add(Fq::mul(Fq::sqr(p.x), p.x), b3));
+}
+fe fr_pow_u64(const fe& a, uint64_t e) { return Fr::pow_u64(a, e); }
+
+}  // namespace
+}  // namespace cap
+
+using namespace cap;
+
+extern "C" {
+
+int capgpu_g2_generator(uint64_t out[16]) {
+  if (!out) return CAPGPU_ERR_INVALID_ARG;
+  g2_to_words(pairing::g2_generator(), out);
+  return CAPGPU_OK;
+}
+
+int capgpu_g2_mul(const uint64_t q[16], const uint64_t scalar[4], uint64_t out[16]) {
+  if (!q || !scalar || !out) return CAPGPU_ERR_INVALID_ARG;
+  g2_affine p = g2_from_words(q);
+  if (!pairing::g2_on_curve(p)) {
+    set_error("capgpu_g2_mul: point is not on the twist curve");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  g2_to_words(pairing::g2_mul(p, fe_from_words(scalar)), out);
+  return CAPGPU_OK;
+}
+
+int capgpu_pairing_check(const uint64_t* g1_points, const uint64_t* g2_points, size_t n, int* ok_out) {
+  if ((n && (!g1_points || !g2_points)) || !ok_out) return CAPGPU_ERR_INVALID_ARG;
+  std::vector<std::pair<g1_affine, g2_affine>> pairs;
+  for (size_t i = 0; i < n; i++) {
+    g1_affine p = g1_from_words(g1_points + 8 * i);
+    g2_affine q = g2_from_words(g2_points + 16 * i);
+    if (!g1_on_curve(p) || !pairing::g2_on_curve(q)) {
+      set_error("capgpu_pairing_check: input %zu is not on its curve", i);
+      return CAPGPU_ERR_INVALID_ARG;
+    }
+    pairs.emplace_back(p, q);
+  }
+  *ok_out = pairing::pairing_product_is_one(pairs) ? 1 : 0;
+  return CAPGPU_OK;
+}
+
+int capgpu_plonk_verify(const capgpu_verifying_key* vk, const uint64_t g2_h[16], const uint64_t g2_beta_h[16],
+                        const uint64_t* pub_inputs, size_t num_inputs, const capgpu_proof* proof,
+                        const uint8_t* ext_msg, size_t ext_msg_len, int* ok_out) {
+  if (!vk || !g2_h || !g2_beta_h || !proof || !ok_out || (num_inputs && !pub_inputs)) {
+    set_error("capgpu_plonk_verify: bad argument");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  *ok_out = 0;
+  const uint64_t n = vk->domain_size;
+  if (n < 4 || (n & (n - 1)) || num_inputs != vk->num_inputs) {
+    set_error("capgpu_plonk_verify: %zu public inputs given, key expects %llu (domain %llu)", num_inputs,
+              (unsigned long long)vk->num_inputs, (unsigned long long)n);
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  uint32_t log_n = 0;
+  while ((1ull << log_n) < n) log_n++;
+
+  // ---- gather the group elements; malformed points make the proof invalid, not the call ------------------
+  g1_affine sel[kNumSelectors], sig[kNumWires], wc[kNumWires], tq[kNumWires];
+  for (int i = 0; i < kNumSelectors; i++) sel[i] = g1_from_words(vk->selector_comms[i]);
+  for (int i = 0; i < kNumWires; i++) {
+    sig[i] = g1_from_words(vk->sigma_comms[i]);
+    wc[i] = g1_from_words(proof->wires_poly_comms[i]);
+    tq[i] = g1_from_words(proof->split_quot_poly_comms[i]);
+  }
+  g1_affine zc = g1_from_words(proof->prod_perm_poly_comm);
+  g1_affine w_zeta = g1_from_words(proof->opening_proof), w_zeta_w = g1_from_words(proof->shifted_opening_proof);
+  {
+    bool on = g1_on_curve(zc) && g1_on_curve(w_zeta) && g1_on_curve(w_zeta_w);
+    for (int i = 0; i < kNumWires; i++) on = on && g1_on_curve(wc[i]) && g1_on_curve(tq[i]);
+    if (!on) return CAPGPU_OK;
+  }
+  g2_affine h = g2_from_words(g2_h), beta_h = g2_from_words(g2_beta_h);
+  if (!pairing::g2_on_curve(h) || !pairing::g2_on_curve(beta_h) || h.inf || beta_h.inf) {
+    set_error("capgpu_plonk_verify: open key G2 elements are not on the twist curve");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  fe we[kNumWires], se[kNumWires - 1];
+  for (int i = 0; i < kNumWires; i++) we[i] = fe_from_words(proof->wires_evals[i]);
+  for (int i = 0; i < kNumWires - 1; i++) se[i] = fe_from_words(proof->wire_sigma_evals[i]);
+  const fe znext = fe_from_words(proof->perm_next_eval);
+  fe kk[kNumWires];
+  for (int i = 0; i < kNumWires; i++) kk[i] = fe_from_words(vk->k[i]);
+
+  // ---- challenges (same transcript as the prover) ------------------------------------------------------------
+  SolidityTranscript t;
+  if (ext_msg && ext_msg_len) t.append(ext_msg, ext_msg_len);
+  t.append_u64_le(254);
+  t.append_u64_le(n);
+  t.append_u64_le((uint64_t)num_inputs);
+  for (int i = 0; i < kNumWires; i++) append_fr(t, kk[i]);
+  for (int i = 0; i < kNumSelectors; i++) append_g1(t, sel[i]);
+  for (int i = 0; i < kNumWires; i++) append_g1(t, sig[i]);
+  std::vector<fe> pub(num_inputs);
+  for (size_t i = 0; i < num_inputs; i++) {
+    pub[i] = fe_from_words(pub_inputs + 4 * i);
+    append_fr(t, pub[i]);
+  }
+  for (int i = 0; i < kNumWires; i++) append_g1(t, wc[i]);
+  (void)get_challenge(t);  // plookup tau
+  const fe beta = get_challenge(t), gamma = get_challenge(t);
+  append_g1(t, zc);
+  const fe alpha = get_challenge(t), alpha2 = Fr::sqr(alpha);
+  for (int i = 0; i < kNumWires; i++) append_g1(t, tq[i]);
+  const fe zeta = get_challenge(t);
+  for (int i = 0; i < kNumWires; i++) append_fr(t, we[i]);
+  for (int i = 0; i < kNumWires - 1; i++) append_fr(t, se[i]);
+  append_fr(t, znext);
+  const fe v = get_challenge(t);
+  append_g1(t, w_zeta);
+  append_g1(t, w_zeta_w);
+  const fe u = get_challenge(t);
+
+  // ---- scalars ---------------------------------------------------------------------------------------------------
+  const fe one = Fr::one();
+  const fe zh = Fr::sub(fr_pow_u64(zeta, n), one);
+  if (Fr::is_zero(zh) || Fr::eq(zeta, one)) return CAPGPU_OK;  // zeta in the domain: reject
+  const fe n_m = fr_from_u64(n);
+  const fe l1 = Fr::mul(zh, Fr::inv(Fr::mul(n_m, Fr::sub(zeta, one))));
+  // omega_n = omega_28^(2^(28-log n))
+  fe omega;
+  {
+    const uint32_t root28[8] = {0x725b19f0u, 0x9bd61b6eu, 0x41112ed4u, 0x402d111eu,
+                                0x8ef62abcu, 0x00e0a7ebu, 0xa58a7e85u, 0x2a3c09f0u};
+    fe w;
+    for (int i = 0; i < 8; i++) w.v[i] = root28[i];
+    w = Fr::to_mont(w);
+    for (uint32_t i = log_n; i < 28; i++) w = Fr::sqr(w);
+    omega = w;
+  }
+  fe pi = Fr::zero();
+  {
+    fe x = one;
+    for (size_t i = 0; i < num_inputs; i++) {
+      fe li = Fr::mul(Fr::mul(zh, x), Fr::inv(Fr::mul(n_m, Fr::sub(zeta, x))));
+      pi = Fr::add(pi, Fr::mul(pub[i], li));
+      x = Fr::mul(x, omega);
+    }
+  }
+  // r0 = PI(zeta) - alpha^2 L1(zeta) - alpha z(zeta w) (w4 + gamma) prod_{i<4} (w_i + beta sigma_i + gamma)
+  fe tt = Fr::mul(Fr::mul(alpha, znext), Fr::add(we[4], gamma));
+  for (int j = 0; j < kNumWires - 1; j++) tt = Fr::mul(tt, Fr::add(Fr::add(we[j], gamma), Fr::mul(beta, se[j])));
+  const fe r0 = Fr::sub(Fr::sub(pi, Fr::mul(alpha2, l1)), tt);
+
+  // ---- D: commitment of the linearisation polynomial -----------------------------------------------------------
+  g1_xyzz acc = G1::inf();
+  auto add_term = [&](const g1_affine& c, const fe& s) { acc = G1::add(acc, g1_smul(c, s)); };
+  for (int j = 0; j < 4; j++) add_term(sel[j], we[j]);
+  const fe w01 = Fr::mul(we[0], we[1]), w23 = Fr::mul(we[2], we[3]);
+  add_term(sel[4], w01);
+  add_term(sel[5], w23);
+  for (int j = 0; j < 4; j++) {
+    fe w2 = Fr::sqr(we[j]);
+    add_term(sel[6 + j], Fr::mul(Fr::sqr(w2), we[j]));
+  }
+  add_term(sel[10], Fr::neg(we[4]));
+  acc = G1::add_mixed(acc, sel[11]);
+  add_term(sel[12], Fr::mul(Fr::mul(w01, w23), we[4]));
+  fe bz = Fr::mul(beta, zeta), cz = alpha;
+  for (int j = 0; j < kNumWires; j++) cz = Fr::mul(cz, Fr::add(Fr::add(we[j], gamma), Fr::mul(kk[j], bz)));
+  cz = Fr::add(cz, Fr::mul(alpha2, l1));
+  add_term(zc, cz);
+  fe cs = Fr::mul(Fr::mul(alpha, beta), znext);
+  for (int j = 0; j < kNumWires - 1; j++) cs = Fr::mul(cs, Fr::add(Fr::add(we[j], gamma), Fr::mul(beta, se[j])));
+  add_term(sig[kNumWires - 1], Fr::neg(cs));
+  fe zp = fr_pow_u64(zeta, n + 2), cq = Fr::neg(zh);
+  for (int j = 0; j < kNumWires; j++) {
+    add_term(tq[j], cq);
+    cq = Fr::mul(cq, zp);
+  }
+  // ---- batch the openings: F = D + sum v^j [p_j] + u [z],  E = -r0 + sum v^j p_j(zeta) + u z(zeta w) -------------
+  fe e_acc = Fr::neg(r0), cf = v;
+  for (int j = 0; j < kNumWires; j++) {
+    add_term(wc[j], cf);
+    e_acc = Fr::add(e_acc, Fr::mul(cf, we[j]));
+    cf = Fr::mul(cf, v);
+  }
+  for (int j = 0; j < kNumWires - 1; j++) {
+    add_term(sig[j], cf);
+    e_acc = Fr::add(e_acc, Fr::mul(cf, se[j]));
+    cf = Fr::mul(cf, v);
+  }
+  add_term(zc, u);
+  e_acc = Fr::add(e_acc, Fr::mul(u, znext));
+  // A = W_zeta + u W_zetaw ;  B = zeta W_zeta + u zeta omega W_zetaw + F - E G
+  g1_xyzz a_pt = G1::add(G1::from_affine(w_zeta), g1_smul(w_zeta_w, u));
+  g1_affine gen;
+  gen.x = Fq::one();
+  gen.y = Fq::dbl(Fq::one());
+  g1_xyzz b_pt = G1::add(g1_smul(w_zeta, zeta), g1_smul(w_zeta_w, Fr::mul(Fr::mul(u, zeta), omega)));
+  b_pt = G1::add(b_pt, acc);
+  b_pt = G1::add(b_pt, g1_smul(gen, Fr::neg(e_acc)));
+  // e(A, [tau]H) == e(B, H)   <=>   e(A, [tau]H) e(-B, H) == 1
+  g1_affine a_aff = G1::to_affine(a_pt), b_aff = G1::to_affine(b_pt);
+  b_aff.y = Fq::neg(b_aff.y);
+  std::vector<std::pair<g1_affine, g2_affine>> pairs = {{a_aff, beta_h}, {b_aff, h}};
+  *ok_out = pairing::pairing_product_is_one(pairs) ? 1 : 0;
+  return CAPGPU_OK;
+}
+
+}  // extern "C"

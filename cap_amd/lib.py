@@ -309,3 +309,37 @@ def proof_to_arrays(pr: Proof) -> dict:
         "shifted_opening_proof": a(pr.shifted_opening_proof), "wires_evals": a(pr.wires_evals),
         "wire_sigma_evals": a(pr.wire_sigma_evals), "perm_next_eval": a(pr.perm_next_eval),
     }
+
+
+# ---- verification (host only) -------------------------------------------------------------------------
+def g2_generator() -> np.ndarray:
+    out = np.zeros(16, dtype=np.uint64)
+    check(load().capgpu_g2_generator(_p(out)))
+    return out
+
+
+def g2_mul(q: np.ndarray, scalar: int) -> np.ndarray:
+    out = np.zeros(16, dtype=np.uint64)
+    check(load().capgpu_g2_mul(_p(np.ascontiguousarray(q, dtype=np.uint64)), _limbs(scalar), _p(out)))
+    return out
+
+
+def pairing_check(g1_points: np.ndarray, g2_points: np.ndarray) -> bool:
+    g1_points = np.ascontiguousarray(g1_points, dtype=np.uint64).reshape(-1, 8)
+    g2_points = np.ascontiguousarray(g2_points, dtype=np.uint64).reshape(-1, 16)
+    ok = ctypes.c_int(0)
+    check(load().capgpu_pairing_check(_p(g1_points.reshape(-1)), _p(g2_points.reshape(-1)),
+                                      ctypes.c_size_t(g1_points.shape[0]), ctypes.byref(ok)))
+    return bool(ok.value)
+
+
+def plonk_verify(vk: VerifyingKey, g2_h: np.ndarray, g2_beta_h: np.ndarray, pub_inputs: np.ndarray, proof: Proof,
+                 ext_msg: bytes | None = None) -> bool:
+    pub_inputs = np.ascontiguousarray(pub_inputs, dtype=np.uint64).reshape(-1)
+    mbuf, mlen = _bytes_arg(ext_msg)
+    ok = ctypes.c_int(0)
+    check(load().capgpu_plonk_verify(ctypes.byref(vk), _p(np.ascontiguousarray(g2_h, dtype=np.uint64)),
+                                     _p(np.ascontiguousarray(g2_beta_h, dtype=np.uint64)),
+                                     _p(pub_inputs) if pub_inputs.size else None, ctypes.c_size_t(pub_inputs.size // 4),
+                                     ctypes.byref(proof), mbuf, ctypes.c_size_t(mlen), ctypes.byref(ok)))
+    return bool(ok.value)

@@ -4,6 +4,7 @@ Same names and argument meaning as `/root/reference/src/proof/`:
   universal_setup       src/proof/mod.rs:59-69     (SRS = powers of tau in G1; synthetic tau here)
   preprocess            src/proof/transfer.rs:124-155, mint.rs:69-93, freeze.rs:93-121
   prove                 src/proof/transfer.rs:159-188, mint.rs:97-120, freeze.rs:125-158
+  verify                src/proof/transfer.rs:192-212, mint.rs:124-140, freeze.rs:162-178
 Errors surface as `TxnApiError.FailedSnark(str)` like the reference maps every SNARK failure
 (src/errors.rs:25-63, src/proof/transfer.rs:187).
 
@@ -33,6 +34,8 @@ class TxnApiError(Exception):
 class UniversalSrs:
     handle: int
     max_degree: int
+    h: np.ndarray | None = None        # G2 generator, 16 Montgomery words (open key of the verifier)
+    beta_h: np.ndarray | None = None   # [tau] H
 
 
 @dataclass
@@ -48,6 +51,8 @@ class VerifyingKey:
     raw: _lib.VerifyingKey
     n: int
     num_inputs: int
+    h: np.ndarray | None = None
+    beta_h: np.ndarray | None = None
 
 
 def universal_setup(max_degree: int, tau: int) -> UniversalSrs:
@@ -55,7 +60,8 @@ def universal_setup(max_degree: int, tau: int) -> UniversalSrs:
     (The reference samples tau from its rng; benches use test_rng, benches/transfer.rs:71.)"""
     try:
         _lib.init()
-        return UniversalSrs(_lib.srs_generate(tau, max_degree + 1), max_degree)
+        h = _lib.g2_generator()
+        return UniversalSrs(_lib.srs_generate(tau, max_degree + 1), max_degree, h, _lib.g2_mul(h, tau))
     except _lib.CapGpuError as e:
         raise TxnApiError.FailedSnark(f"Failed to generate universal SRS: {e}") from e
 
@@ -66,7 +72,7 @@ def preprocess(srs: UniversalSrs, n: int, num_inputs: int, selectors: np.ndarray
         h, vk = _lib.plonk_preprocess(srs.handle, n, num_inputs, selectors, sigma_evals)
     except _lib.CapGpuError as e:
         raise TxnApiError.FailedSnark(f"Preprocessing circuit of domain size {n} failed: {e}") from e
-    return ProvingKey(h, n, num_inputs, srs), VerifyingKey(vk, n, num_inputs), n
+    return ProvingKey(h, n, num_inputs, srs), VerifyingKey(vk, n, num_inputs, srs.h, srs.beta_h), n
 
 
 def prove(proving_key: ProvingKey, wires: np.ndarray, public_inputs: np.ndarray, blinders: np.ndarray,
@@ -85,3 +91,14 @@ def prove_batch(proving_key: ProvingKey, wires: np.ndarray, public_inputs: np.nd
         return _lib.plonk_prove_batch(proving_key.handle, wires, public_inputs, blinders, ext_msg, count)
     except _lib.CapGpuError as e:
         raise TxnApiError.FailedSnark(f"Proof Creation failure: {e}") from e
+
+
+def verify(verifying_key: VerifyingKey, public_inputs: np.ndarray, proof, ext_msg: bytes | None = None) -> None:
+    """src/proof/transfer.rs:192-212 / mint.rs:124-140 / freeze.rs:162-178: Ok(()) or TxnApiError::FailedSnark.
+    Runs on the host (pairing check); it does not need the GPU."""
+    try:
+        ok = _lib.plonk_verify(verifying_key.raw, verifying_key.h, verifying_key.beta_h, public_inputs, proof, ext_msg)
+    except _lib.CapGpuError as e:
+        raise TxnApiError.FailedSnark(f"Proof Verification failure: {e}") from e
+    if not ok:
+        raise TxnApiError.FailedSnark("Proof Verification failure: WrongProof")

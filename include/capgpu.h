@@ -14,6 +14,8 @@
  *   capgpu_plonk_preprocess   PlonkKzgSnark::preprocess   (call sites src/proof/transfer.rs:133, mint.rs:76, freeze.rs:102)
  *   capgpu_plonk_prove        PlonkKzgSnark::prove::<_,_,SolidityTranscript>
  *                                                         (call sites src/proof/transfer.rs:181-186, mint.rs:113, freeze.rs:151)
+ *   capgpu_plonk_verify       PlonkKzgSnark::verify::<SolidityTranscript>
+ *                                                         (call sites src/proof/transfer.rs:202-207, mint.rs:132, freeze.rs:170)
  *
  * Conventions
  *   - All integers little-endian.  Field element Fr / Fq = uint64_t[4] (arkworks
@@ -162,6 +164,21 @@ int capgpu_plonk_prove_batch(uint64_t pk_handle, int count, const uint64_t* wire
 int capgpu_plonk_prove_batch_dev(uint64_t pk_handle, int count, const void* d_wires, const uint64_t* pub_inputs,
                                  size_t num_inputs, const uint8_t* ext_msg, size_t ext_msg_len,
                                  const uint64_t* blinders, capgpu_proof* proofs_out);
+
+/* ---- verification (host only: needs neither a GPU nor capgpu_init) ---------------------------------------- */
+/* G2 elements: x.c0, x.c1, y.c0, y.c1 of the twist point (Fq2 = Fq[u]/(u^2+1)), Montgomery, 16 words;
+ * all-zero = infinity.  They are the `h` / `beta_h` of jf-plonk's VerifyingKey.open_key. */
+int capgpu_g2_generator(uint64_t out[16]);
+/* out = scalar * q (canonical 4 x u64 scalar): builds [tau]H for a synthetic SRS (src/proof/mod.rs:59-69) */
+int capgpu_g2_mul(const uint64_t q[16], const uint64_t scalar[4], uint64_t out[16]);
+/* *ok_out = (prod_i e(P_i, Q_i) == 1);  P_i: n affine G1 points (8 words each), Q_i: n G2 points (16 words each) */
+int capgpu_pairing_check(const uint64_t* g1_points, const uint64_t* g2_points, size_t n, int* ok_out);
+/* Replaces PlonkKzgSnark::verify::<SolidityTranscript> (src/proof/transfer.rs:192-212, mint.rs:124-140,
+ * freeze.rs:162-178).  Returns CAPGPU_OK with *ok_out = 1 (accept) / 0 (reject); a negative code only for
+ * malformed arguments (wrong number of public inputs, G2 elements off the curve). */
+int capgpu_plonk_verify(const capgpu_verifying_key* vk, const uint64_t g2_h[16], const uint64_t g2_beta_h[16],
+                        const uint64_t* pub_inputs, size_t num_inputs, const capgpu_proof* proof,
+                        const uint8_t* ext_msg, size_t ext_msg_len, int* ok_out);
 
 /* ---- instrumentation ------------------------------------------------------------------------------ */
 /* When enabled, every kernel launch is bracketed by HIP events on the launch stream and accumulated

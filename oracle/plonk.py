@@ -332,12 +332,33 @@ def prove(pk: ProvingKeyOracle, wires, pub_inputs, blinders, ext_msg: bytes | No
 
 def verify(n, num_inputs, selector_comms, sigma_comms, pub_inputs, proof: Proof, tau: int,
            ext_msg: bytes | None = None) -> bool:
-    """Standard PLONK verifier; the two pairing checks e(A,[tau]H) = e(B,H) are done as tau*A == B in G1
+    """Standard PLONK verifier; the pairing check e(A,[tau]H) = e(B,H) is done as tau*A == B in G1
     (tau is known for the synthetic SRS - SURVEY §8c.5)."""
+    ab = verifier_pairing_inputs(n, num_inputs, selector_comms, sigma_comms, pub_inputs, proof, ext_msg)
+    if ab is None:
+        return False
+    a_pt, b_pt = ab
+    return bn.g1_mul(a_pt, tau) == b_pt
+
+
+def verify_pairing(n, num_inputs, selector_comms, sigma_comms, pub_inputs, proof: Proof, h_g2, beta_h_g2,
+                   ext_msg: bytes | None = None) -> bool:
+    """The same verifier with the real check e(A, [tau]H) * e(-B, H) == 1 (oracle/pairing.py)."""
+    from . import pairing as pr
+    ab = verifier_pairing_inputs(n, num_inputs, selector_comms, sigma_comms, pub_inputs, proof, ext_msg)
+    if ab is None:
+        return False
+    a_pt, b_pt = ab
+    return pr.pairing_product_is_one([(a_pt, beta_h_g2), (bn.g1_neg(b_pt), h_g2)])
+
+
+def verifier_pairing_inputs(n, num_inputs, selector_comms, sigma_comms, pub_inputs, proof: Proof,
+                            ext_msg: bytes | None = None):
+    """-> (A, B) with the proof valid iff e(A, [tau]H) == e(B, H); None for malformed input."""
     ln = log2(n)
     omega = bn.root_of_unity(ln)
     if len(pub_inputs) != num_inputs:
-        return False
+        return None
     tr = SolidityTranscript()
     if ext_msg is not None:
         tr.append_message(ext_msg)
@@ -363,7 +384,7 @@ def verify(n, num_inputs, selector_comms, sigma_comms, pub_inputs, proof: Proof,
     alpha2 = alpha * alpha % R
     zh = (pow(zeta, n, R) - 1) % R
     if zh == 0 or zeta == 1:
-        return False
+        return None
     l1 = zh * inv_mod(n * (zeta - 1), R) % R
     pi = 0
     x = 1
@@ -416,8 +437,7 @@ def verify(n, num_inputs, selector_comms, sigma_comms, pub_inputs, proof: Proof,
     F = bn.g1_add(F, smul(proof.prod_perm_poly_comm, u))
     E = (E + u * z_next) % R
     lhs_pt = bn.g1_add(proof.opening_proof, smul(proof.shifted_opening_proof, u))
-    lhs = smul(lhs_pt, tau)
     rhs = bn.g1_add(smul(proof.opening_proof, zeta), smul(proof.shifted_opening_proof, u * zeta % R * omega))
     rhs = bn.g1_add(rhs, F)
     rhs = bn.g1_add(rhs, bn.g1_neg(smul(bn.G1_GEN, E)))
-    return lhs == rhs
+    return lhs_pt, rhs

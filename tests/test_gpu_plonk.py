@@ -66,10 +66,17 @@ def test_batch_vs_c_oracle(cg, tau, log_n, nin, P):
         rc, comms, evals = key.prove(ws[p], ps[p], bls[p], msg)
         assert rc == 0
         assert H.proof_points(proofs[p]) == H.cref_proof_points(comms, evals), f"proof {p}"
-    # the host-side API mirror gives the same object
-    pk = capproof.ProvingKey(pkh, sc.n, nin, capproof.UniversalSrs(h, sc.n + 2))
+    # the host-side API mirror gives the same object, and its verify() accepts / rejects like the reference's
+    g2h = cg.g2_generator()
+    srs = capproof.UniversalSrs(h, sc.n + 2, g2h, cg.g2_mul(g2h, tau))
+    pk = capproof.ProvingKey(pkh, sc.n, nin, srs)
     single = capproof.prove(pk, ws[0], ps[0], bls[0], msg)
     assert H.proof_points(single) == H.proof_points(proofs[0])
+    vkey = capproof.VerifyingKey(vk, sc.n, nin, srs.h, srs.beta_h)
+    for p in range(P):
+        capproof.verify(vkey, ps[p], proofs[p], msg)
+    with pytest.raises(capproof.TxnApiError):
+        capproof.verify(vkey, ps[0], proofs[0], b"other-bound-data")
     cg.plonk_free_key(pkh)
     cg.srs_free(h)
 
@@ -94,6 +101,16 @@ def test_transfer_note_shape_full_size(cg, tau):
     assert rc == 0
     assert H.proof_points(proofs[0]) == H.cref_proof_points(comms, evals)
     assert H.proof_points(proofs[1]) != H.proof_points(proofs[0])
+    # prove -> verify round trip with the product's own (pairing) verifier, as the reference tests do
+    # (src/proof/transfer.rs:599-760): good proofs pass; wrong public input / bound data / swapped proof fail
+    g2h = cg.g2_generator()
+    bh = cg.g2_mul(g2h, tau)
+    assert cg.plonk_verify(vk, g2h, bh, pm, proofs[0], b"memo")
+    assert cg.plonk_verify(vk, g2h, bh, pubs_arr(pubs2), proofs[1], b"memo")
+    assert not cg.plonk_verify(vk, g2h, bh, pubs_arr(pubs2), proofs[0], b"memo")
+    assert not cg.plonk_verify(vk, g2h, bh, pm, proofs[0], b"memO")
+    bad = pm.copy(); bad[26, 0] ^= 1
+    assert not cg.plonk_verify(vk, g2h, bh, bad, proofs[0], b"memo")
     cg.plonk_free_key(pkh)
     cg.srs_free(h)
 

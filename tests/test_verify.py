@@ -1,0 +1,137 @@
+"""Row A12 (verify): the product's host-side verifier (pairing-based, no GPU needed) against the oracle.
+Mirrors the reference's proof tests (src/proof/transfer.rs:599-760, mint.rs:344-471, freeze.rs:429-534):
+a good proof verifies; wrong public input / proof / verifying key / bound data must fail.  (`-m "not gpu"`)"""
+import copy
+import ctypes
+
+import numpy as np
+import pytest
+
+from cap_amd import bench_utils as bu
+from cap_amd import lib as cg
+from oracle import bn254 as bn
+from oracle import capref as cr
+from oracle import pairing as pr
+from oracle import plonk as pl
+from tests import helpers as H
+
+
+def g2_words(q):
+    """oracle G2 point ((x0, x1), (y0, y1)) -> 16 Montgomery words"""
+    vals = [q[0][0], q[0][1], q[1][0], q[1][1]]
+    return cr.ints_to_array([bn.to_mont(v, bn.P) for v in vals]).reshape(-1)
+
+
+def g2_ints(w):
+    v = [bn.from_mont(x, bn.P) for x in cr.array_to_ints(np.asarray(w, dtype=np.uint64).reshape(4, 4))]
+    return ((v[0], v[1]), (v[2], v[3]))
+
+
+def fill_words(dst, arr):
+    arr = np.asarray(arr, dtype=np.uint64).reshape(-1)
+    for i, v in enumerate(arr):
+        dst[i] = int(v)
+
+
+def make_vk(n, num_inputs, sel_pts, sig_pts):
+    vk = cg.VerifyingKey()
+    vk.domain_size, vk.num_inputs = n, num_inputs
+    for i, k in enumerate(pl.K):
+        fill_words(vk.k[i], cr.ints_to_array([bn.to_mont(k, bn.R)]))
+    for i, p in enumerate(sel_pts):
+        fill_words(vk.selector_comms[i], cr.points_to_array([p]))
+    for i, p in enumerate(sig_pts):
+        fill_words(vk.sigma_comms[i], cr.points_to_array([p]))
+    return vk
+
+
+def make_proof(pts, evals):
+    pr_ = cg.Proof()
+    for i in range(5):
+        fill_words(pr_.wires_poly_comms[i], cr.points_to_array([pts[i]]))
+        fill_words(pr_.split_quot_poly_comms[i], cr.points_to_array([pts[6 + i]]))
+        fill_words(pr_.wires_evals[i], cr.ints_to_array([bn.to_mont(evals[i], bn.R)]))
+    for i in range(4):
+        fill_words(pr_.wire_sigma_evals[i], cr.ints_to_array([bn.to_mont(evals[5 + i], bn.R)]))
+    fill_words(pr_.prod_perm_poly_comm, cr.points_to_array([pts[5]]))
+    fill_words(pr_.opening_proof, cr.points_to_array([pts[11]]))
+    fill_words(pr_.shifted_opening_proof, cr.points_to_array([pts[12]]))
+    fill_words(pr_.perm_next_eval, cr.ints_to_array([bn.to_mont(evals[9], bn.R)]))
+    return pr_
+
+
+def test_g2_and_pairing_against_oracle():
+    g2 = cg.g2_generator()
+    assert g2_ints(g2) == pr.G2_GEN                       # EIP-197 generator
+    a, b = 0x1234567, 0xABCDEF0123
+    assert g2_ints(cg.g2_mul(g2, a)) == pr.g2_mul(pr.G2_GEN, a)
+    assert not cg.g2_mul(g2, bn.R).any()                  # order r
+    g1 = cr.points_to_array([bn.g1_mul(bn.G1_GEN, a), bn.g1_neg(bn.g1_mul(bn.G1_GEN, a * b % bn.R))])
+    # bilinearity: e(aG, bH) * e(-abG, H) == 1, and it fails for a wrong exponent
+    assert cg.pairing_check(g1, np.stack([cg.g2_mul(g2, b), g2]))
+    assert not cg.pairing_check(g1, np.stack([cg.g2_mul(g2, b + 1), g2]))
+    assert pr.pairing_product_is_one([(cr.affine_to_ints(g1[0]), pr.g2_mul(pr.G2_GEN, b)),
+                                      (cr.affine_to_ints(g1[1]), pr.G2_GEN)])
+    # non-degenerate: e(G, H) != 1
+    assert not cg.pairing_check(cr.points_to_array([bn.G1_GEN]), g2[None])
+    with pytest.raises(cg.CapGpuError):                   # off-curve input is refused, not mis-evaluated
+        bad = g1.copy(); bad[0, 0] ^= 1
+        cg.pairing_check(bad, np.stack([g2, g2]))
+
+
+def test_oracle_pairing_verifier_matches_trapdoor_verifier(tau):
+    sc = bu.synthetic_circuit(4, 2, seed=2)
+    w, pubs = sc.witness(100)
+    pk = pl.preprocess(pl.Circuit(n=sc.n, num_inputs=2, selectors=sc.selectors, sigma=sc.sigma), tau)
+    proof = pl.prove(pk, w, pubs, bu.blinders(200), ext_msg=b"x")
+    bh = pr.g2_mul(pr.G2_GEN, tau)
+    args = (sc.n, 2, pk.selector_comms, pk.sigma_comms)
+    assert pl.verify(*args, pubs, proof, tau, ext_msg=b"x")
+    assert pl.verify_pairing(*args, pubs, proof, pr.G2_GEN, bh, ext_msg=b"x")
+    bad = list(pubs); bad[0] = (bad[0] + 1) % bn.R
+    assert not pl.verify_pairing(*args, bad, proof, pr.G2_GEN, bh, ext_msg=b"x")
+
+
+def test_product_verifier_on_golden_proof(tau):
+    """The committed golden proof (made by the Python oracle) is accepted by the product's C++ verifier, and
+    every corruption the reference's tests try is rejected."""
+    g = H.load_golden("proof_log5.json")
+    n, nin = 1 << g["log_n"], g["num_inputs"]
+    sc = bu.synthetic_circuit(g["log_n"], nin, seed=g["circuit_seed"])
+    _, pubs = sc.witness(g["witness_seed"])
+    sel = [H.unhex_pt(p) for p in g["selector_comms"]]
+    sig = [H.unhex_pt(p) for p in g["sigma_comms"]]
+    pts = [H.unhex_pt(p) for p in g["wires_poly_comms"]] + [H.unhex_pt(g["prod_perm_poly_comm"])] + \
+        [H.unhex_pt(p) for p in g["split_quot_poly_comms"]] + [H.unhex_pt(g["opening_proof"]),
+                                                              H.unhex_pt(g["shifted_opening_proof"])]
+    evals = [int(h, 16) for h in g["wires_evals"] + g["wire_sigma_evals"] + [g["perm_next_eval"]]]
+    vk, proof = make_vk(n, nin, sel, sig), make_proof(pts, evals)
+    h2 = cg.g2_generator()
+    bh = cg.g2_mul(h2, tau)
+    assert np.array_equal(bh, g2_words(pr.g2_mul(pr.G2_GEN, tau)))
+    pub_arr = bu.to_mont_array(pubs)
+    msg = g["ext_msg"].encode()
+    assert cg.plonk_verify(vk, h2, bh, pub_arr, proof, msg)
+    # wrong public input
+    bad_pub = pub_arr.copy(); bad_pub[1, 0] ^= 1
+    assert not cg.plonk_verify(vk, h2, bh, bad_pub, proof, msg)
+    # wrong bound data (ext_msg) / missing bound data
+    assert not cg.plonk_verify(vk, h2, bh, pub_arr, proof, msg + b"!")
+    assert not cg.plonk_verify(vk, h2, bh, pub_arr, proof, None)
+    # wrong proof: an evaluation, a commitment, an opening
+    p2 = make_proof(pts, [evals[0] + 1] + evals[1:]); assert not cg.plonk_verify(vk, h2, bh, pub_arr, p2, msg)
+    pts3 = list(pts); pts3[7] = bn.g1_add(pts3[7], bn.G1_GEN)
+    assert not cg.plonk_verify(vk, h2, bh, pub_arr, make_proof(pts3, evals), msg)
+    pts4 = list(pts); pts4[11] = bn.g1_add(pts4[11], bn.G1_GEN)
+    assert not cg.plonk_verify(vk, h2, bh, pub_arr, make_proof(pts4, evals), msg)
+    pts5 = list(pts); pts5[0] = (pts5[0][0], (pts5[0][1] + 1) % bn.P)          # not even on the curve
+    assert not cg.plonk_verify(vk, h2, bh, pub_arr, make_proof(pts5, evals), msg)
+    # wrong verifying key
+    sig2 = list(sig); sig2[2] = bn.g1_add(sig2[2], bn.G1_GEN)
+    assert not cg.plonk_verify(make_vk(n, nin, sel, sig2), h2, bh, pub_arr, proof, msg)
+    # wrong SRS trapdoor
+    assert not cg.plonk_verify(vk, h2, cg.g2_mul(h2, tau + 1), pub_arr, proof, msg)
+    # malformed call: wrong number of public inputs is an argument error (reference: PlonkError)
+    with pytest.raises(cg.CapGpuError) as e:
+        cg.plonk_verify(vk, h2, bh, pub_arr[:2], proof, msg)
+    assert e.value.code == -1
