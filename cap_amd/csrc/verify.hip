@@ -105,14 +105,12 @@ int capgpu_pairing_check(const uint64_t* g1_points, const uint64_t* g2_points, s
   return CAPGPU_OK;
 }
 
-int capgpu_plonk_verify(const capgpu_verifying_key* vk, const uint64_t g2_h[16], const uint64_t g2_beta_h[16],
-                        const uint64_t* pub_inputs, size_t num_inputs, const capgpu_proof* proof,
-                        const uint8_t* ext_msg, size_t ext_msg_len, int* ok_out) {
-  if (!vk || !g2_h || !g2_beta_h || !proof || !ok_out || (num_inputs && !pub_inputs)) {
-    set_error("capgpu_plonk_verify: bad argument");
-    return CAPGPU_ERR_INVALID_ARG;
-  }
-  *ok_out = 0;
+// Everything of the verifier up to the pairing: on success *valid = 1 and the proof holds iff
+// e(A, [tau]H) == e(B, H); *valid = 0 means the proof is already known to be invalid.
+static int verifier_prepare(const capgpu_verifying_key* vk, const uint64_t* pub_inputs, size_t num_inputs,
+                            const capgpu_proof* proof, const uint8_t* ext_msg, size_t ext_msg_len, g1_affine* a_out,
+                            g1_affine* b_out, int* valid) {
+  int* ok_out = valid;
   const uint64_t n = vk->domain_size;
   if (n < 4 || (n & (n - 1)) || num_inputs != vk->num_inputs) {
     set_error("capgpu_plonk_verify: %zu public inputs given, key expects %llu (domain %llu)", num_inputs,
@@ -136,11 +134,6 @@ int capgpu_plonk_verify(const capgpu_verifying_key* vk, const uint64_t g2_h[16],
     bool on = g1_on_curve(zc) && g1_on_curve(w_zeta) && g1_on_curve(w_zeta_w);
     for (int i = 0; i < kNumWires; i++) on = on && g1_on_curve(wc[i]) && g1_on_curve(tq[i]);
     if (!on) return CAPGPU_OK;
-  }
-  g2_affine h = g2_from_words(g2_h), beta_h = g2_from_words(g2_beta_h);
-  if (!pairing::g2_on_curve(h) || !pairing::g2_on_curve(beta_h) || h.inf || beta_h.inf) {
-    set_error("capgpu_plonk_verify: open key G2 elements are not on the twist curve");
-    return CAPGPU_ERR_INVALID_ARG;
   }
   fe we[kNumWires], se[kNumWires - 1];
   for (int i = 0; i < kNumWires; i++) we[i] = fe_from_words(proof->wires_evals[i]);
@@ -257,11 +250,125 @@ int capgpu_plonk_verify(const capgpu_verifying_key* vk, const uint64_t g2_h[16],
   g1_xyzz b_pt = G1::add(g1_smul(w_zeta, zeta), g1_smul(w_zeta_w, Fr::mul(Fr::mul(u, zeta), omega)));
   b_pt = G1::add(b_pt, acc);
   b_pt = G1::add(b_pt, g1_smul(gen, Fr::neg(e_acc)));
+  *a_out = G1::to_affine(a_pt);
+  *b_out = G1::to_affine(b_pt);
+  *valid = 1;
+  return CAPGPU_OK;
+}
+
+static int load_open_key(const uint64_t g2_h[16], const uint64_t g2_beta_h[16], g2_affine* h, g2_affine* beta_h) {
+  *h = g2_from_words(g2_h);
+  *beta_h = g2_from_words(g2_beta_h);
+  if (!pairing::g2_on_curve(*h) || !pairing::g2_on_curve(*beta_h) || h->inf || beta_h->inf) {
+    set_error("capgpu_plonk_verify: open key G2 elements are not on the twist curve");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  return CAPGPU_OK;
+}
+
+int capgpu_plonk_verify(const capgpu_verifying_key* vk, const uint64_t g2_h[16], const uint64_t g2_beta_h[16],
+                        const uint64_t* pub_inputs, size_t num_inputs, const capgpu_proof* proof,
+                        const uint8_t* ext_msg, size_t ext_msg_len, int* ok_out) {
+  if (!vk || !g2_h || !g2_beta_h || !proof || !ok_out || (num_inputs && !pub_inputs)) {
+    set_error("capgpu_plonk_verify: bad argument");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  *ok_out = 0;
+  g2_affine h, beta_h;
+  int rc = load_open_key(g2_h, g2_beta_h, &h, &beta_h);
+  if (rc) return rc;
+  g1_affine a, b;
+  int valid = 0;
+  rc = verifier_prepare(vk, pub_inputs, num_inputs, proof, ext_msg, ext_msg_len, &a, &b, &valid);
+  if (rc || !valid) return rc;
   // e(A, [tau]H) == e(B, H)   <=>   e(A, [tau]H) e(-B, H) == 1
-  g1_affine a_aff = G1::to_affine(a_pt), b_aff = G1::to_affine(b_pt);
-  b_aff.y = Fq::neg(b_aff.y);
-  std::vector<std::pair<g1_affine, g2_affine>> pairs = {{a_aff, beta_h}, {b_aff, h}};
+  b.y = Fq::neg(b.y);
+  std::vector<std::pair<g1_affine, g2_affine>> pairs = {{a, beta_h}, {b, h}};
   *ok_out = pairing::pairing_product_is_one(pairs) ? 1 : 0;
+  return CAPGPU_OK;
+}
+
+// Replaces PlonkKzgSnark::batch_verify as used by txn_batch_verify (src/lib.rs:455-529, call at :517-522): the
+// per-proof pairing inputs (A_i, B_i) are folded with pseudo-random weights r_i (Keccak of all of them) and one
+// pairing product decides the whole batch.  Proofs may belong to different circuits / keys of one SRS.
+int capgpu_plonk_batch_verify(const capgpu_verifying_key* const* vks, const uint64_t g2_h[16],
+                              const uint64_t g2_beta_h[16], const uint64_t* const* pub_inputs,
+                              const size_t* num_inputs, const capgpu_proof* const* proofs,
+                              const uint8_t* const* ext_msgs, const size_t* ext_msg_lens, size_t count, int* ok_out) {
+  if (!ok_out || !g2_h || !g2_beta_h || (count && (!vks || !pub_inputs || !num_inputs || !proofs))) {
+    set_error("capgpu_plonk_batch_verify: bad argument");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  *ok_out = 0;
+  g2_affine h, beta_h;
+  int rc = load_open_key(g2_h, g2_beta_h, &h, &beta_h);
+  if (rc) return rc;
+  if (count == 0) {
+    *ok_out = 1;
+    return CAPGPU_OK;
+  }
+  std::vector<g1_affine> as(count), bs(count);
+  SolidityTranscript seed;
+  for (size_t i = 0; i < count; i++) {
+    if (!vks[i] || !proofs[i] || (num_inputs[i] && !pub_inputs[i])) return CAPGPU_ERR_INVALID_ARG;
+    int valid = 0;
+    rc = verifier_prepare(vks[i], pub_inputs[i], num_inputs[i], proofs[i], ext_msgs ? ext_msgs[i] : nullptr,
+                          (ext_msgs && ext_msg_lens) ? ext_msg_lens[i] : 0, &as[i], &bs[i], &valid);
+    if (rc) return rc;
+    if (!valid) return CAPGPU_OK;
+    append_g1(seed, as[i]);
+    append_g1(seed, bs[i]);
+  }
+  g1_xyzz a_sum = G1::inf(), b_sum = G1::inf();
+  for (size_t i = 0; i < count; i++) {
+    fe r = i == 0 ? Fr::one() : get_challenge(seed);
+    a_sum = G1::add(a_sum, g1_smul(as[i], r));
+    b_sum = G1::add(b_sum, g1_smul(bs[i], r));
+  }
+  g1_affine a = G1::to_affine(a_sum), b = G1::to_affine(b_sum);
+  b.y = Fq::neg(b.y);
+  std::vector<std::pair<g1_affine, g2_affine>> pairs = {{a, beta_h}, {b, h}};
+  *ok_out = pairing::pairing_product_is_one(pairs) ? 1 : 0;
+  return CAPGPU_OK;
+}
+
+// ark-serialize 0.3 CanonicalSerialize of jf_plonk's Proof (what sits inside TransferNote.proof, src/transfer.rs:60):
+// 13 compressed G1 (5 wires, prod_perm, 5 split quotient, opening, shifted opening), each Vec with a u64 LE length
+// prefix, then the 10 evaluations (wires_evals Vec, wire_sigma_evals Vec, perm_next_eval), then plookup_proof: None.
+// Layout as recalled: unverified against jellyfish.  Returns the number of bytes written.
+int capgpu_proof_serialize(const capgpu_proof* proof, uint8_t* out, size_t cap, size_t* len_out) {
+  if (!proof || !out || !len_out) return CAPGPU_ERR_INVALID_ARG;
+  std::vector<uint8_t> buf;
+  auto put_u64 = [&](uint64_t v) { buf.insert(buf.end(), (uint8_t*)&v, (uint8_t*)&v + 8); };
+  auto put_g1 = [&](const uint64_t w[8]) {
+    uint8_t b[32];
+    serialize_g1(g1_from_words(w), b);
+    buf.insert(buf.end(), b, b + 32);
+  };
+  auto put_fr = [&](const uint64_t w[4]) {
+    uint8_t b[32];
+    serialize_fr(fe_from_words(w), b);
+    buf.insert(buf.end(), b, b + 32);
+  };
+  put_u64(kNumWires);
+  for (int i = 0; i < kNumWires; i++) put_g1(proof->wires_poly_comms[i]);
+  put_g1(proof->prod_perm_poly_comm);
+  put_u64(kNumWires);
+  for (int i = 0; i < kNumWires; i++) put_g1(proof->split_quot_poly_comms[i]);
+  put_g1(proof->opening_proof);
+  put_g1(proof->shifted_opening_proof);
+  put_u64(kNumWires);
+  for (int i = 0; i < kNumWires; i++) put_fr(proof->wires_evals[i]);
+  put_u64(kNumWires - 1);
+  for (int i = 0; i < kNumWires - 1; i++) put_fr(proof->wire_sigma_evals[i]);
+  put_fr(proof->perm_next_eval);
+  buf.push_back(0);  // Option::None for plookup_proof
+  *len_out = buf.size();
+  if (buf.size() > cap) {
+    set_error("capgpu_proof_serialize: buffer too small (%zu needed)", buf.size());
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  memcpy(out, buf.data(), buf.size());
   return CAPGPU_OK;
 }
 

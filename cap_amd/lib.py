@@ -343,3 +343,28 @@ def plonk_verify(vk: VerifyingKey, g2_h: np.ndarray, g2_beta_h: np.ndarray, pub_
                                      _p(pub_inputs) if pub_inputs.size else None, ctypes.c_size_t(pub_inputs.size // 4),
                                      ctypes.byref(proof), mbuf, ctypes.c_size_t(mlen), ctypes.byref(ok)))
     return bool(ok.value)
+
+
+def plonk_batch_verify(vks, g2_h: np.ndarray, g2_beta_h: np.ndarray, pub_inputs_list, proofs, ext_msgs=None) -> bool:
+    cnt = len(proofs)
+    vk_arr = (ctypes.POINTER(VerifyingKey) * cnt)(*[ctypes.pointer(v) for v in vks])
+    pubs = [np.ascontiguousarray(p, dtype=np.uint64).reshape(-1) for p in pub_inputs_list]
+    pub_arr = (u64p * cnt)(*[(_p(p) if p.size else None) for p in pubs])
+    nin = (ctypes.c_size_t * cnt)(*[p.size // 4 for p in pubs])
+    pr_arr = (ctypes.POINTER(Proof) * cnt)(*[ctypes.pointer(p) for p in proofs])
+    msgs = [(m if m is not None else b"") for m in (ext_msgs or [None] * cnt)]
+    bufs = [(ctypes.c_uint8 * max(len(m), 1)).from_buffer_copy(m + (b"\0" if not m else b"")) for m in msgs]
+    msg_arr = (ctypes.POINTER(ctypes.c_uint8) * cnt)(*[ctypes.cast(b, ctypes.POINTER(ctypes.c_uint8)) for b in bufs])
+    len_arr = (ctypes.c_size_t * cnt)(*[len(m) for m in msgs])
+    ok = ctypes.c_int(0)
+    check(load().capgpu_plonk_batch_verify(vk_arr, _p(np.ascontiguousarray(g2_h, dtype=np.uint64)),
+                                           _p(np.ascontiguousarray(g2_beta_h, dtype=np.uint64)), pub_arr, nin, pr_arr,
+                                           msg_arr, len_arr, ctypes.c_size_t(cnt), ctypes.byref(ok)))
+    return bool(ok.value)
+
+
+def proof_serialize(proof: Proof) -> bytes:
+    buf = (ctypes.c_uint8 * 1024)()
+    n = ctypes.c_size_t(0)
+    check(load().capgpu_proof_serialize(ctypes.byref(proof), buf, ctypes.c_size_t(1024), ctypes.byref(n)))
+    return bytes(buf[:n.value])

@@ -180,6 +180,17 @@ int capgpu_plonk_verify(const capgpu_verifying_key* vk, const uint64_t g2_h[16],
                         const uint64_t* pub_inputs, size_t num_inputs, const capgpu_proof* proof,
                         const uint8_t* ext_msg, size_t ext_msg_len, int* ok_out);
 
+/* Replaces PlonkKzgSnark::batch_verify as used by txn_batch_verify (src/lib.rs:455-529): one pairing product for
+ * `count` proofs (possibly of different circuits / keys under one SRS).  ext_msgs / ext_msg_lens may be NULL. */
+int capgpu_plonk_batch_verify(const capgpu_verifying_key* const* vks, const uint64_t g2_h[16],
+                              const uint64_t g2_beta_h[16], const uint64_t* const* pub_inputs,
+                              const size_t* num_inputs, const capgpu_proof* const* proofs,
+                              const uint8_t* const* ext_msgs, const size_t* ext_msg_lens, size_t count, int* ok_out);
+/* ark-serialize 0.3 CanonicalSerialize bytes of the Proof as it sits inside a TransferNote / MintNote / FreezeNote
+ * (src/transfer.rs:60): compressed G1 (32 B), Fr little-endian, Vec = u64 length prefix, plookup_proof = None.
+ * 769 bytes; *len_out receives the size. */
+int capgpu_proof_serialize(const capgpu_proof* proof, uint8_t* out, size_t cap, size_t* len_out);
+
 /* ---- instrumentation ------------------------------------------------------------------------------ */
 /* When enabled, every kernel launch is bracketed by HIP events on the launch stream and accumulated
  * per kernel name (costs a few microseconds per launch; leave off for throughput runs). */

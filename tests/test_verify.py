@@ -135,3 +135,40 @@ def test_product_verifier_on_golden_proof(tau):
     with pytest.raises(cg.CapGpuError) as e:
         cg.plonk_verify(vk, h2, bh, pub_arr[:2], proof, msg)
     assert e.value.code == -1
+
+
+def test_batch_verify_and_proof_serialization(tau):
+    """txn_batch_verify counterpart (src/lib.rs:455-529): proofs of two different circuits under one SRS."""
+    h2 = cg.g2_generator()
+    bh = cg.g2_mul(h2, tau)
+    vks, pubs_l, proofs, msgs, oproofs = [], [], [], [], []
+    for log_n, nin, seed in ((4, 2, 11), (5, 3, 12)):
+        sc = bu.synthetic_circuit(log_n, nin, seed=seed)
+        w, pubs = sc.witness(seed)
+        pk = pl.preprocess(pl.Circuit(n=sc.n, num_inputs=nin, selectors=sc.selectors, sigma=sc.sigma), tau)
+        msg = b"note-%d" % seed
+        op = pl.prove(pk, w, pubs, bu.blinders(seed), ext_msg=msg)
+        pts, ev = H.oracle_proof_points(op)
+        vks.append(make_vk(sc.n, nin, pk.selector_comms, pk.sigma_comms))
+        pubs_l.append(bu.to_mont_array(pubs))
+        proofs.append(make_proof(pts, ev))
+        msgs.append(msg)
+        oproofs.append(op)
+    assert all(cg.plonk_verify(vks[i], h2, bh, pubs_l[i], proofs[i], msgs[i]) for i in range(2))
+    assert cg.plonk_batch_verify(vks, h2, bh, pubs_l, proofs, msgs)
+    assert cg.plonk_batch_verify([], h2, bh, [], [], [])
+    bad = pubs_l[1].copy(); bad[0, 0] ^= 1
+    assert not cg.plonk_batch_verify(vks, h2, bh, [pubs_l[0], bad], proofs, msgs)
+    assert not cg.plonk_batch_verify(vks, h2, bh, pubs_l, proofs, [msgs[0], b"x"])
+    assert not cg.plonk_batch_verify(vks, h2, bh, pubs_l, [proofs[0], proofs[0]], msgs)
+    # ark-serialize bytes of the proof = what the oracle's encoders give
+    op = oproofs[0]
+    exp = (5).to_bytes(8, "little") + b"".join(bn.g1_serialize_compressed(p) for p in op.wires_poly_comms)
+    exp += bn.g1_serialize_compressed(op.prod_perm_poly_comm)
+    exp += (5).to_bytes(8, "little") + b"".join(bn.g1_serialize_compressed(p) for p in op.split_quot_poly_comms)
+    exp += bn.g1_serialize_compressed(op.opening_proof) + bn.g1_serialize_compressed(op.shifted_opening_proof)
+    exp += (5).to_bytes(8, "little") + b"".join(bn.fr_to_bytes_le(v) for v in op.wires_evals)
+    exp += (4).to_bytes(8, "little") + b"".join(bn.fr_to_bytes_le(v) for v in op.wire_sigma_evals)
+    exp += bn.fr_to_bytes_le(op.perm_next_eval) + b"\x00"
+    got = cg.proof_serialize(proofs[0])
+    assert got == exp and len(got) == 769
