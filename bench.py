@@ -27,7 +27,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_BATCH = 64       # batch size of the committed PMC pass (profiles/traffic_r01.json)
+TRAFFIC_BATCH = 128      # batch size of the committed PMC pass (profiles/traffic_r01.json)
 
 
 def algorithmic_bytes_per_proof(n: int) -> dict:
