@@ -258,12 +258,20 @@ int ntt_build_domain(NttDomain* d, uint32_t log_n, hipStream_t stream) {
            (const fe*)src[k], n);
   }
   d->n_inv29 = Fr29::pack(Fr29::canonical(Fr29::from_ext(d->n_inv)));
+  // 5^i * 2^266 = internal form of (5^i * 32): build 32 * 5^i in arkworks form, then convert
+  {
+    fe k32 = host_from_u64(32);
+    if ((e = hipMalloc(&d->coset29_fwd_x32, sizeof(fe) * n)) != hipSuccess) return (int)e;
+    if ((rc = build_powers(d->coset29_fwd_x32, n, g, &k32, stream))) return rc;
+    launch("table_to_internal", table_to_internal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+           d->coset29_fwd_x32, (const fe*)d->coset29_fwd_x32, n);
+  }
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) return (int)e;
-  // only omega^j (tw_fwd) is still read in arkworks' form by other kernels
+  // omega^j (tw_fwd) is still read in arkworks' form by other kernels; coset_inv doubles as the internal -> arkworks
+  // scaling table of the inverse coset transform
   hipFree(d->tw_inv);
   hipFree(d->coset_fwd);
-  hipFree(d->coset_inv);
-  d->tw_inv = d->coset_fwd = d->coset_inv = nullptr;
+  d->tw_inv = d->coset_fwd = nullptr;
   return 0;
 }
 
@@ -272,14 +280,21 @@ void ntt_free_domain(NttDomain* d) {
   if (d->tw_inv) hipFree(d->tw_inv);
   if (d->coset_fwd) hipFree(d->coset_fwd);
   if (d->coset_inv) hipFree(d->coset_inv);
-  for (fe* t : {d->tw29_fwd, d->tw29_inv, d->coset29_fwd, d->coset29_inv})
+  for (fe* t : {d->tw29_fwd, d->tw29_inv, d->coset29_fwd, d->coset29_inv, d->coset29_fwd_x32})
     if (t) hipFree(t);
   d->tw_fwd = d->tw_inv = d->coset_fwd = d->coset_inv = nullptr;
-  d->tw29_fwd = d->tw29_inv = d->coset29_fwd = d->coset29_inv = nullptr;
+  d->tw29_fwd = d->tw29_inv = d->coset29_fwd = d->coset29_inv = d->coset29_fwd_x32 = nullptr;
+}
+
+void ntt_table_to_internal(fe* out, const fe* in, size_t n, hipStream_t stream) {
+  if (n == 0) return;
+  launch("table_to_internal", table_to_internal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out, in, n);
 }
 
 int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scratch, size_t stride_elems,
-            uint32_t count, int dir, int coset, hipStream_t stream) {
+            uint32_t count, int dir, int coset, hipStream_t stream, int io_form) {
+  if ((io_form == kNttOutInternal && (dir || !coset)) || (io_form == kNttInInternal && (!dir || !coset)))
+    return (int)hipErrorInvalidValue;
   const uint32_t log_n = dom.log_n;
   if (count == 0) return 0;
   if (log_n == 0) {
@@ -312,7 +327,7 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
   p.tw_full = tw_full;
   p.use_post_scalar = 0;
 
-  const fe* pre = (!dir && coset) ? dom.coset29_fwd : nullptr;
+  const fe* pre = (!dir && coset) ? (io_form == kNttOutInternal ? dom.coset29_fwd_x32 : dom.coset29_fwd) : nullptr;
   bool first = true;
   const fe* cur_in = data;
   // column passes
@@ -350,7 +365,7 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
     p.out = data;
     p.tw_small = tws[log_len];
     p.pre_scale = first ? pre : nullptr;
-    p.post_scale = (dir && coset) ? dom.coset29_inv : nullptr;
+    p.post_scale = (dir && coset) ? (io_form == kNttInInternal ? dom.coset_inv : dom.coset29_inv) : nullptr;
     p.use_post_scalar = (dir && !coset) ? 1 : 0;
     p.post_scalar = dom.n_inv29;
     p.log_len = log_len;

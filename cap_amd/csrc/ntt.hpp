@@ -28,7 +28,15 @@ struct NttDomain {
   fe* coset29_fwd = nullptr;
   fe* coset29_inv = nullptr;
   fe n_inv29;
+  // form-changing coset tables (kNttOutInternal / kNttInInternal below)
+  fe* coset29_fwd_x32 = nullptr;  // 5^i * 2^266: forward coset transform of arkworks-form data -> internal-form output
+                                  // (coset_inv, the arkworks-form table n^-1 5^-i 2^256, does the reverse on the way back)
 };
+
+// io_form flags of ntt_run: the quotient kernel works on internal-form (x * 2^261) data; the transforms feeding and
+// draining it change the form for free through their coset-scaling multiplication.
+constexpr int kNttOutInternal = 1;  // forward coset transform: arkworks-form input, internal-form output
+constexpr int kNttInInternal = 2;   // inverse coset transform: internal-form input, arkworks-form (canonical) output
 
 // Small-size twiddles shared by every domain (internal form): fwd[s] -> omega_{2^s}^i, i < 2^(s-1), s <= kMaxLogTile
 constexpr int kMaxLogTile = 11;
@@ -50,6 +58,9 @@ fe ntt_root_of_unity(uint32_t log_n);
 // elements, array b at data + b * stride_elems.  `scratch` must hold count * 2^log_n
 // elements.  dir: 0 forward, 1 inverse.  coset: 0/1.
 int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scratch, size_t stride_elems,
-            uint32_t count, int dir, int coset, hipStream_t stream);
+            uint32_t count, int dir, int coset, hipStream_t stream, int io_form = 0);
+
+// out[i] = internal Montgomery form (x * 2^261, canonical) of the arkworks-form value in[i]
+void ntt_table_to_internal(fe* out, const fe* in, size_t n, hipStream_t stream);
 
 }  // namespace cap

@@ -39,7 +39,8 @@ struct ProvingKey {
   fe* sig_eval = nullptr;  // [5][n]
   fe* pk_coset = nullptr;  // [18][m]
   fe* inv_nx1 = nullptr;   // [m]
-  QuotConst qc;
+  QuotConst qc;    // arkworks form (host arithmetic, k_perm_numden)
+  QuotConst qc29;  // internal form of the lazy field (k_quotient)
   capgpu_verifying_key vk;
   std::vector<uint8_t> vk_bytes;
   bool recompute = false;
@@ -101,14 +102,14 @@ void scan_exclusive(hipStream_t s, const fe* in, fe* out, size_t len, size_t str
   }
 }
 
-int run_ntt(hipStream_t s, uint32_t log_n, fe* data, size_t stride, uint32_t count, int dir, int coset) {
+int run_ntt(hipStream_t s, uint32_t log_n, fe* data, size_t stride, uint32_t count, int dir, int coset, int io_form = 0) {
   Context& c = ctx();
   const NttDomain* dom = nullptr;
   int rc = get_domain(log_n, &dom);
   if (rc) return rc;
   rc = scratch_reserve(c.ntt_scratch, sizeof(fe) * stride * count);
   if (rc) return rc;
-  rc = ntt_run(*dom, c.small, data, (fe*)c.ntt_scratch.p, stride, count, dir, coset, s);
+  rc = ntt_run(*dom, c.small, data, (fe*)c.ntt_scratch.p, stride, count, dir, coset, s, io_form);
   if (rc) return hip_fail((hipError_t)rc, "ntt_run");
   return CAPGPU_OK;
 }
@@ -140,6 +141,7 @@ struct BatchWs {
   fe *wpoly, *pi, *num, *den, *pre, *sfx, *scan_tot, *inv_total, *zpoly, *coset, *pkc, *t, *pows, *pw, *batchpoly,
       *hbuf, *quot, *evals, *eval_partial, *d_pub, *d_blind;
   Chal* chal;
+  Chal* chal29;  // the same challenges in the internal form
   uint32_t* flags;
   g1_jac* comms;
   EvalDesc* edesc;
@@ -175,6 +177,7 @@ BatchWs carve(void* base, const ProvingKey& K, uint32_t P) {
   w.d_pub = c.take<fe>((size_t)P * (K.num_inputs ? K.num_inputs : 1));
   w.d_blind = c.take<fe>((size_t)P * 13);
   w.chal = c.take<Chal>(P);
+  w.chal29 = c.take<Chal>(P);
   w.flags = c.take<uint32_t>(P);
   w.comms = c.take<g1_jac>((size_t)P * 5);
   w.edesc = c.take<EvalDesc>((size_t)P * 10);
@@ -197,7 +200,7 @@ int find_srs(uint64_t h, const MsmBases** out) {
 // the 18 fixed polynomials -> coset evaluations on the 8n domain
 int compute_pk_coset(hipStream_t s, const ProvingKey& K, fe* dst) {
   pad_copy(s, dst, K.m, 0, K.coef, K.ps, 0, 1, 18, K.n, K.m);
-  return run_ntt(s, K.log_m, dst, K.m, 18, 0, 1);
+  return run_ntt(s, K.log_m, dst, K.m, 18, 0, 1, kNttOutInternal);
 }
 
 int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pub_inputs, size_t num_inputs,
@@ -295,12 +298,21 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
     chal[p].alpha2 = Fr::sqr(chal[p].alpha);
   });
   CAP_HIP(hipMemcpyAsync(w.chal, chal.data(), sizeof(Chal) * P, hipMemcpyHostToDevice, s));
+  std::vector<Chal> chal29(P);
+  parallel_for(P, [&](uint32_t p) {
+    auto conv = [](const fe& a) { return Fr29::pack(Fr29::canonical(Fr29::from_ext(a))); };
+    chal29[p].beta = conv(chal[p].beta);
+    chal29[p].gamma = conv(chal[p].gamma);
+    chal29[p].alpha = conv(chal[p].alpha);
+    chal29[p].alpha2 = conv(chal[p].alpha2);
+  });
+  CAP_HIP(hipMemcpyAsync(w.chal29, chal29.data(), sizeof(Chal) * P, hipMemcpyHostToDevice, s));
 
   // ---- round 3: quotient polynomial ---------------------------------------------------------------------
   pad_copy(s, w.coset, 7 * m, m, w.wpoly, NW * ps, ps, NW, P * NW, n + 2, m);
   pad_copy(s, w.coset + 5 * m, 7 * m, 0, w.zpoly, ps, 0, 1, P, n + 3, m);
   pad_copy(s, w.coset + 6 * m, 7 * m, 0, w.pi, n, 0, 1, P, n, m);
-  if ((rc = run_ntt(s, K.log_m, w.coset, m, P * 7, 0, 1))) return rc;
+  if ((rc = run_ntt(s, K.log_m, w.coset, m, P * 7, 0, 1, kNttOutInternal))) return rc;
   const fe* pkc = K.pk_coset;
   if (K.recompute) {
     // reference schedule: the 18 selector / sigma polynomials are re-transformed for every proof
@@ -309,8 +321,8 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
     pkc = w.pkc;
   }
   launch("k_quotient", k_quotient, dim3(cdiv(m, kThreads), P), dim3(kThreads), 0, s, pkc, (const fe*)w.coset,
-         (const fe*)dom_m->tw_fwd, (const fe*)K.inv_nx1, (const Chal*)w.chal, K.qc, m, w.t);
-  if ((rc = run_ntt(s, K.log_m, w.t, m, P, 1, 1))) return rc;
+         (const fe*)dom_m->tw29_fwd, (const fe*)K.inv_nx1, (const Chal*)w.chal29, K.qc29, m, w.t);
+  if ((rc = run_ntt(s, K.log_m, w.t, m, P, 1, 1, kNttInInternal))) return rc;
   {
     size_t lo = NW * (n + 1) + 3;  // first index that must be zero: degree is exactly 5(n+1)+2
     launch("k_check_degree", k_check_degree, dim3(cdiv(m - (lo - 1), kThreads), P), dim3(kThreads), 0, s,
@@ -544,6 +556,13 @@ int capgpu_plonk_preprocess(uint64_t srs_handle, size_t n, size_t num_inputs, co
   if ((rc = get_domain(K->log_m, &dom_m))) return rc;
   launch("k_inv_nx1", k_inv_nx1, dim3(cdiv(m, kThreads)), dim3(kThreads), 0, s, K->inv_nx1, (const fe*)dom_m->tw_fwd,
          K->qc.g, fr_from_u64((uint64_t)n), m);
+  ntt_table_to_internal(K->inv_nx1, K->inv_nx1, m, s);
+  {
+    auto conv = [](const fe& a) { return Fr29::pack(Fr29::canonical(Fr29::from_ext(a))); };
+    K->qc29.g = conv(K->qc.g);
+    for (int i = 0; i < NW; i++) K->qc29.k[i] = conv(K->qc.k[i]);
+    for (int i = 0; i < 8; i++) K->qc29.zh_inv[i] = conv(K->qc.zh_inv[i]);
+  }
   if (!K->recompute) {
     CAP_HIP(hipMalloc(&K->pk_coset, sizeof(fe) * 18 * m));
     if ((rc = compute_pk_coset(s, *K, K->pk_coset))) return rc;

@@ -10,6 +10,7 @@
 #include <hip/hip_runtime.h>
 
 #include "field.hpp"
+#include "field29.hpp"
 
 namespace cap {
 namespace pk {
@@ -203,53 +204,94 @@ __global__ __launch_bounds__(kThreads) void k_perm_finish(const fe* __restrict__
 }
 
 // ---- round 3: fused quotient evaluation on the coset of size m = 8n ----------------------------------
+// All inputs are in the internal Montgomery form of the lazy 29-bit field (x * 2^261): the forward coset NTTs emit
+// it (kNttOutInternal) and the inverse coset NTT that follows consumes it (kNttInInternal).
 // pkc: [18][m] coset evaluations of 13 selectors then 5 sigmas (shared by all proofs)
-// cos: [P][7][m] coset evaluations of 5 wires, z, pi
+// cos: [P][7][m] coset evaluations of 5 wires, z, pi;   tw_m: omega_m^i;   inv_nx1: 1 / (n (x_i - 1))
+// Sums of products share one Montgomery reduction (at most 6 products per 64-bit column accumulator).
+struct ColAcc {
+  uint64_t c[18];
+  __device__ __forceinline__ void clear() {
+#pragma unroll
+    for (int k = 0; k < 18; k++) c[k] = 0;
+  }
+  __device__ __forceinline__ void mad(const fl& a, const fl& b) {
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+      for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)a.v[i] * b.v[j];
+  }
+  __device__ __forceinline__ fl reduce() { return Fr29::reduce_cols(c); }
+};
+
 __global__ __launch_bounds__(kThreads) void k_quotient(const fe* __restrict__ pkc, const fe* __restrict__ cos,
                                                        const fe* __restrict__ tw_m,
                                                        const fe* __restrict__ inv_nx1,
                                                        const Chal* __restrict__ chal, QuotConst qc, size_t m,
                                                        fe* __restrict__ t_out) {
+  using F = Fr29;
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
   const uint32_t p = blockIdx.y;
   const fe* c = cos + (size_t)p * 7 * m;
-  const Chal ch = chal[p];
-  fe w[NW];
-#pragma unroll
-  for (int j = 0; j < NW; j++) w[j] = c[(size_t)j * m + i];
-  const fe zx = c[(size_t)5 * m + i];
-  const fe zwx = c[(size_t)5 * m + ((i + 8) & (m - 1))];
-  const fe pi = c[(size_t)6 * m + i];
+  auto sel = [&](int s) { return F::load(pkc[(size_t)s * m + i]); };
+  fl w0 = F::load(c[i]), w1 = F::load(c[m + i]), w2 = F::load(c[2 * m + i]), w3 = F::load(c[3 * m + i]),
+     w4 = F::load(c[4 * m + i]);
   // gate constraint (spec eq. (1); selector order q_lc, q_mul, q_hash, q_o, q_c, q_ecc)
-  fe acc = Fr::add(pkc[(size_t)11 * m + i], pi);
-#pragma unroll
-  for (int j = 0; j < 4; j++) {
-    acc = Fr::add(acc, Fr::mul(pkc[(size_t)j * m + i], w[j]));
-    fe w2 = Fr::sqr(w[j]);
-    fe w5 = Fr::mul(Fr::sqr(w2), w[j]);
-    acc = Fr::add(acc, Fr::mul(pkc[(size_t)(6 + j) * m + i], w5));
+  fl w01 = F::mul(w0, w1), w23 = F::mul(w2, w3);
+  ColAcc acc;
+  acc.clear();
+  acc.mad(sel(0), w0);
+  acc.mad(sel(1), w1);
+  acc.mad(sel(2), w2);
+  acc.mad(sel(3), w3);
+  acc.mad(sel(4), w01);
+  acc.mad(sel(5), w23);
+  fl gate = acc.reduce();
+  acc.clear();
+  {
+    fl t = F::sqr(w0);
+    acc.mad(sel(6), F::mul(F::sqr(t), w0));
+    t = F::sqr(w1);
+    acc.mad(sel(7), F::mul(F::sqr(t), w1));
+    t = F::sqr(w2);
+    acc.mad(sel(8), F::mul(F::sqr(t), w2));
+    t = F::sqr(w3);
+    acc.mad(sel(9), F::mul(F::sqr(t), w3));
   }
-  fe w01 = Fr::mul(w[0], w[1]);
-  fe w23 = Fr::mul(w[2], w[3]);
-  acc = Fr::add(acc, Fr::mul(pkc[(size_t)4 * m + i], w01));
-  acc = Fr::add(acc, Fr::mul(pkc[(size_t)5 * m + i], w23));
-  acc = Fr::add(acc, Fr::mul(pkc[(size_t)12 * m + i], Fr::mul(Fr::mul(w01, w23), w[4])));
-  acc = Fr::sub(acc, Fr::mul(pkc[(size_t)10 * m + i], w[4]));
+  acc.mad(sel(12), F::mul(F::mul(w01, w23), w4));
+  acc.mad(F::neg(sel(10)), w4);
+  fl gate2 = acc.reduce();
+  // gate + q_c + pi: four values < 2p each, limbs < 2^31 after the lazy adds
+  fl total = F::normalize(F::add(F::add(gate, gate2), F::add(sel(11), F::load(c[6 * m + i]))));
   // permutation part
-  fe x = Fr::mul(qc.g, tw_m[i]);
-  fe bx = Fr::mul(ch.beta, x);
-  fe a = zx, b = zwx;
-#pragma unroll
-  for (int j = 0; j < NW; j++) {
-    fe wg = Fr::add(w[j], ch.gamma);
-    a = Fr::mul(a, Fr::add(wg, j == 0 ? bx : Fr::mul(qc.k[j], bx)));
-    b = Fr::mul(b, Fr::add(wg, Fr::mul(ch.beta, pkc[(size_t)(NS + j) * m + i])));
+  const fl beta = F::load(chal[p].beta), gamma = F::load(chal[p].gamma);
+  const fl zx = F::load(c[5 * m + i]);
+  {
+    fl x = F::mul(F::load(qc.g), F::load(tw_m[i]));
+    fl bx = F::mul(beta, x);
+    fl a = zx, b = F::load(c[5 * m + ((i + 8) & (m - 1))]);
+    fl wg = F::add(w0, gamma);
+    a = F::mul(a, F::normalize(F::add(wg, bx)));
+    b = F::mul(b, F::normalize(F::add(wg, F::mul(beta, sel(NS + 0)))));
+    wg = F::add(w1, gamma);
+    a = F::mul(a, F::normalize(F::add(wg, F::mul(F::load(qc.k[1]), bx))));
+    b = F::mul(b, F::normalize(F::add(wg, F::mul(beta, sel(NS + 1)))));
+    wg = F::add(w2, gamma);
+    a = F::mul(a, F::normalize(F::add(wg, F::mul(F::load(qc.k[2]), bx))));
+    b = F::mul(b, F::normalize(F::add(wg, F::mul(beta, sel(NS + 2)))));
+    wg = F::add(w3, gamma);
+    a = F::mul(a, F::normalize(F::add(wg, F::mul(F::load(qc.k[3]), bx))));
+    b = F::mul(b, F::normalize(F::add(wg, F::mul(beta, sel(NS + 3)))));
+    wg = F::add(w4, gamma);
+    a = F::mul(a, F::normalize(F::add(wg, F::mul(F::load(qc.k[4]), bx))));
+    b = F::mul(b, F::normalize(F::add(wg, F::mul(beta, sel(NS + 4)))));
+    total = F::normalize(F::add(total, F::mul(F::load(chal[p].alpha), F::sub(a, b))));
   }
-  acc = Fr::add(acc, Fr::mul(ch.alpha, Fr::sub(a, b)));
-  acc = Fr::mul(acc, qc.zh_inv[i & 7]);
-  fe l1 = Fr::mul(Fr::mul(ch.alpha2, Fr::sub(zx, Fr::one())), inv_nx1[i]);
-  t_out[(size_t)p * m + i] = Fr::add(acc, l1);
+  // (gate + alpha * perm) / Z_H  +  alpha^2 (z - 1) / (n (x - 1)) : two products, one reduction
+  fl l1a = F::mul(F::load(chal[p].alpha2), F::sub(zx, F::one()));
+  fl r = F::mul_add_mul(total, F::load(qc.zh_inv[i & 7]), l1a, F::load(inv_nx1[i]));
+  t_out[(size_t)p * m + i] = F::store(r);
 }
 
 // out[i] = 1 / (n * (g * w_m^i - 1))   (one-time table of the proving key)
