@@ -155,6 +155,8 @@ fe fe_from_u64x4(const uint64_t v[4]) {
   return r;
 }
 
+}  // namespace
+
 int register_srs(g1_affine* d_bases, size_t n, uint64_t* handle_out) {
   Context& c = ctx();
   SrsEntry e;
@@ -168,7 +170,17 @@ int register_srs(g1_affine* d_bases, size_t n, uint64_t* handle_out) {
   return CAPGPU_OK;
 }
 
-}  // namespace
+int find_srs(uint64_t h, const MsmBases** out) {
+  Context& c = ctx();
+  auto it = c.srs.find(h);
+  if (it == c.srs.end()) {
+    set_error("capgpu: unknown SRS handle %llu", (unsigned long long)h);
+    return CAPGPU_ERR_BAD_HANDLE;
+  }
+  *out = &it->second.bases;
+  return CAPGPU_OK;
+}
+
 }  // namespace cap
 
 using namespace cap;

@@ -47,6 +47,9 @@ int hip_fail(hipError_t e, const char* what);  // records message, returns CAPGP
 int scratch_reserve(Scratch& s, size_t bytes);
 // cached domain tables for 2^log_n
 int get_domain(uint32_t log_n, const NttDomain** out);
+// builds the window table of `n` device-resident affine bases (arkworks form, (0,0) = infinity) and registers it
+int register_srs(g1_affine* d_bases, size_t n, uint64_t* handle_out);
+int find_srs(uint64_t h, const MsmBases** out);
 
 #define CAP_CHECK_INIT()                                                  \
   do {                                                                    \

@@ -24,6 +24,7 @@
 #include "context.hpp"
 #include "host_util.hpp"
 #include "launch.hpp"
+#include "params.hpp"
 #include "plonk_kernels.hpp"
 
 namespace cap {
@@ -184,17 +185,6 @@ BatchWs carve(void* base, const ProvingKey& K, uint32_t P) {
   w.terms = c.take<LinTerm>((size_t)P * kLinTerms);
   w.total = c.off + 256;
   return w;
-}
-
-int find_srs(uint64_t h, const MsmBases** out) {
-  Context& c = ctx();
-  auto it = c.srs.find(h);
-  if (it == c.srs.end()) {
-    set_error("capgpu: unknown SRS handle %llu", (unsigned long long)h);
-    return CAPGPU_ERR_BAD_HANDLE;
-  }
-  *out = &it->second.bases;
-  return CAPGPU_OK;
 }
 
 // the 18 fixed polynomials -> coset evaluations on the 8n domain
@@ -477,6 +467,81 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
   return CAPGPU_OK;
 }
 
+// ---- proving-key construction shared by preprocess and the blob loader -------------------------------------
+int key_init(ProvingKey& K, size_t n, size_t num_inputs, uint64_t srs_handle) {
+  K.n = n;
+  K.m = 8 * n;
+  K.ps = n + 8;
+  while (((size_t)1 << K.log_n) < n) K.log_n++;
+  K.log_m = K.log_n + 3;
+  if (K.log_m > 27) {
+    set_error("capgpu_plonk_preprocess: domain too large");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  K.num_inputs = num_inputs;
+  K.srs_handle = srs_handle;
+  const char* env = getenv("CAPGPU_RECOMPUTE_PK_COSET");
+  K.recompute = env && atoi(env) != 0;
+  CAP_HIP(hipMalloc(&K.coef, sizeof(fe) * 18 * K.ps));
+  CAP_HIP(hipMalloc(&K.sig_eval, sizeof(fe) * NW * n));
+  CAP_HIP(hipMalloc(&K.inv_nx1, sizeof(fe) * K.m));
+  return CAPGPU_OK;
+}
+
+// everything derived from the coefficient table: constants of the quotient kernel, 1 / (n (x - 1)) on the coset,
+// and the cached coset evaluations of the 18 fixed polynomials
+int key_finish_tables(hipStream_t s, ProvingKey& K) {
+  const size_t n = K.n, m = K.m;
+  int rc;
+  const uint64_t five[4] = {5, 0, 0, 0};
+  K.qc.g = Fr::to_mont(fe_from_words(five));
+  for (int i = 0; i < NW; i++) K.qc.k[i] = Fr::to_mont(fe_from_words(K_CANON[i]));
+  {
+    uint32_t e_n[8] = {(uint32_t)n, (uint32_t)((uint64_t)n >> 32), 0, 0, 0, 0, 0, 0};
+    fe gn = Fr::pow(K.qc.g, e_n);
+    fe w8 = Fr::pow(ntt_root_of_unity(K.log_m), e_n);  // omega_m^n: primitive 8th root of unity
+    fe x = gn;
+    for (int i = 0; i < 8; i++) {
+      K.qc.zh_inv[i] = Fr::inv(Fr::sub(x, Fr::one()));
+      x = Fr::mul(x, w8);
+    }
+  }
+  const NttDomain* dom_m = nullptr;
+  if ((rc = get_domain(K.log_m, &dom_m))) return rc;
+  launch("k_inv_nx1", k_inv_nx1, dim3(cdiv(m, kThreads)), dim3(kThreads), 0, s, K.inv_nx1, (const fe*)dom_m->tw_fwd,
+         K.qc.g, fr_from_u64((uint64_t)n), m);
+  ntt_table_to_internal(K.inv_nx1, K.inv_nx1, m, s);
+  {
+    auto conv = [](const fe& a) { return Fr29::pack(Fr29::canonical(Fr29::from_ext(a))); };
+    K.qc29.g = conv(K.qc.g);
+    for (int i = 0; i < NW; i++) K.qc29.k[i] = conv(K.qc.k[i]);
+    for (int i = 0; i < 8; i++) K.qc29.zh_inv[i] = conv(K.qc.zh_inv[i]);
+  }
+  if (!K.recompute) {
+    CAP_HIP(hipMalloc(&K.pk_coset, sizeof(fe) * 18 * m));
+    if ((rc = compute_pk_coset(s, K, K.pk_coset))) return rc;
+  }
+  return CAPGPU_OK;
+}
+
+// verifying key and transcript prefix from the 18 affine commitments (13 selectors, then 5 sigmas)
+void key_set_vk(ProvingKey& K, const std::vector<g1_affine>& ha) {
+  memset(&K.vk, 0, sizeof(K.vk));
+  K.vk.domain_size = K.n;
+  K.vk.num_inputs = K.num_inputs;
+  for (int i = 0; i < NW; i++) fe_to_words(K.qc.k[i], K.vk.k[i]);
+  for (int i = 0; i < NS; i++) affine_to_words(ha[i], K.vk.selector_comms[i]);
+  for (int i = 0; i < NW; i++) affine_to_words(ha[NS + i], K.vk.sigma_comms[i]);
+  // transcript prefix (SURVEY A.8): field bits, domain size, #inputs, k_i, selector and sigma commitments
+  SolidityTranscript t;
+  t.append_u64_le(254);
+  t.append_u64_le((uint64_t)K.n);
+  t.append_u64_le((uint64_t)K.num_inputs);
+  for (int i = 0; i < NW; i++) append_fr(t, K.qc.k[i]);
+  for (int i = 0; i < 18; i++) append_g1(t, ha[i]);
+  K.vk_bytes = t.buf;
+}
+
 int lookup_key(uint64_t h, std::shared_ptr<ProvingKey>* out) {
   Context& c = ctx();
   auto it = c.keys.find(h);
@@ -513,23 +578,8 @@ int capgpu_plonk_preprocess(uint64_t srs_handle, size_t n, size_t num_inputs, co
   }
   hipStream_t s = c.stream;
   auto K = std::make_shared<ProvingKey>();
-  K->n = n;
-  K->m = 8 * n;
-  K->ps = n + 8;
-  while (((size_t)1 << K->log_n) < n) K->log_n++;
-  K->log_m = K->log_n + 3;
-  if (K->log_m > 27) {
-    set_error("capgpu_plonk_preprocess: domain too large");
-    return CAPGPU_ERR_INVALID_ARG;
-  }
-  K->num_inputs = num_inputs;
-  K->srs_handle = srs_handle;
-  const char* env = getenv("CAPGPU_RECOMPUTE_PK_COSET");
-  K->recompute = env && atoi(env) != 0;
-  const size_t ps = K->ps, m = K->m;
-  CAP_HIP(hipMalloc(&K->coef, sizeof(fe) * 18 * ps));
-  CAP_HIP(hipMalloc(&K->sig_eval, sizeof(fe) * NW * n));
-  CAP_HIP(hipMalloc(&K->inv_nx1, sizeof(fe) * m));
+  if ((rc = key_init(*K, n, num_inputs, srs_handle))) return rc;
+  const size_t ps = K->ps;
   // stage the evaluation columns, then interpolate
   fe* stage = nullptr;
   CAP_HIP(hipMalloc(&stage, sizeof(fe) * 18 * n));
@@ -538,35 +588,7 @@ int capgpu_plonk_preprocess(uint64_t srs_handle, size_t n, size_t num_inputs, co
   CAP_HIP(hipMemcpyAsync(K->sig_eval, stage + (size_t)NS * n, sizeof(fe) * NW * n, hipMemcpyDeviceToDevice, s));
   pad_copy(s, K->coef, ps, 0, stage, n, 0, 1, 18, n, ps);
   if ((rc = run_ntt(s, K->log_n, K->coef, ps, 18, 1, 0))) return rc;
-  // constants of the quotient kernel
-  const uint64_t five[4] = {5, 0, 0, 0};
-  K->qc.g = Fr::to_mont(fe_from_words(five));
-  for (int i = 0; i < NW; i++) K->qc.k[i] = Fr::to_mont(fe_from_words(K_CANON[i]));
-  {
-    uint32_t e_n[8] = {(uint32_t)n, (uint32_t)((uint64_t)n >> 32), 0, 0, 0, 0, 0, 0};
-    fe gn = Fr::pow(K->qc.g, e_n);
-    fe w8 = Fr::pow(ntt_root_of_unity(K->log_m), e_n);  // omega_m^n: primitive 8th root of unity
-    fe x = gn;
-    for (int i = 0; i < 8; i++) {
-      K->qc.zh_inv[i] = Fr::inv(Fr::sub(x, Fr::one()));
-      x = Fr::mul(x, w8);
-    }
-  }
-  const NttDomain* dom_m = nullptr;
-  if ((rc = get_domain(K->log_m, &dom_m))) return rc;
-  launch("k_inv_nx1", k_inv_nx1, dim3(cdiv(m, kThreads)), dim3(kThreads), 0, s, K->inv_nx1, (const fe*)dom_m->tw_fwd,
-         K->qc.g, fr_from_u64((uint64_t)n), m);
-  ntt_table_to_internal(K->inv_nx1, K->inv_nx1, m, s);
-  {
-    auto conv = [](const fe& a) { return Fr29::pack(Fr29::canonical(Fr29::from_ext(a))); };
-    K->qc29.g = conv(K->qc.g);
-    for (int i = 0; i < NW; i++) K->qc29.k[i] = conv(K->qc.k[i]);
-    for (int i = 0; i < 8; i++) K->qc29.zh_inv[i] = conv(K->qc.zh_inv[i]);
-  }
-  if (!K->recompute) {
-    CAP_HIP(hipMalloc(&K->pk_coset, sizeof(fe) * 18 * m));
-    if ((rc = compute_pk_coset(s, *K, K->pk_coset))) return rc;
-  }
+  if ((rc = key_finish_tables(s, *K))) return rc;
   // verifying key: commitments of the 18 polynomials
   g1_jac* d_comms = nullptr;
   CAP_HIP(hipMalloc(&d_comms, sizeof(g1_jac) * 18));
@@ -578,26 +600,178 @@ int capgpu_plonk_preprocess(uint64_t srs_handle, size_t n, size_t num_inputs, co
   hipFree(d_comms);
   hipFree(stage);
   batch_to_affine(hj, ha);
-  memset(&K->vk, 0, sizeof(K->vk));
-  K->vk.domain_size = n;
-  K->vk.num_inputs = num_inputs;
-  for (int i = 0; i < NW; i++) fe_to_words(K->qc.k[i], K->vk.k[i]);
-  for (int i = 0; i < NS; i++) affine_to_words(ha[i], K->vk.selector_comms[i]);
-  for (int i = 0; i < NW; i++) affine_to_words(ha[NS + i], K->vk.sigma_comms[i]);
-  // transcript prefix (SURVEY A.8): field bits, domain size, #inputs, k_i, selector and sigma commitments
-  {
-    SolidityTranscript t;
-    t.append_u64_le(254);
-    t.append_u64_le((uint64_t)n);
-    t.append_u64_le((uint64_t)num_inputs);
-    for (int i = 0; i < NW; i++) append_fr(t, K->qc.k[i]);
-    for (int i = 0; i < 18; i++) append_g1(t, ha[i]);
-    K->vk_bytes = t.buf;
-  }
+  key_set_vk(*K, ha);
   if (vk_out) *vk_out = K->vk;
   uint64_t h = c.next_handle++;
   c.keys[h] = K;
   *pk_handle_out = h;
+  return CAPGPU_OK;
+}
+
+// ---- ProvingKey blob (layout in include/capgpu.h) ---------------------------------------------
+int capgpu_plonk_key_serialize(uint64_t pk_handle, const uint64_t gamma_g[8], const uint64_t h[16],
+                               const uint64_t beta_h[16], uint8_t* out, size_t cap, size_t* len_out) {
+  CAP_CHECK_INIT();
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  if (!h || !beta_h || !len_out) {
+    set_error("capgpu_plonk_key_serialize: bad argument");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  std::shared_ptr<ProvingKey> K;
+  int rc = lookup_key(pk_handle, &K);
+  if (rc) return rc;
+  const MsmBases* B = nullptr;
+  if ((rc = find_srs(K->srs_handle, &B))) return rc;
+  const size_t n = K->n, ps = K->ps, n_ck = n + 3;
+  // upper bound: every polynomial at full length
+  const size_t bound = 2 * 8 + 18 * (8 + 32 * n) + 8 + 32 * n_ck + 8 + 1024;
+  if (!out) {
+    *len_out = bound;
+    return CAPGPU_OK;
+  }
+  hipStream_t s = c.stream;
+  std::vector<uint8_t> coef(32 * 18 * ps), ck(32 * n_ck);
+  if ((rc = params::fr_mont_to_bytes(K->coef, 18 * ps, coef.data(), s))) return rc;
+  if ((rc = params::compress_g1(B->ext, 1, n_ck, ck.data(), s))) return rc;
+  params::Writer w;
+  auto poly = [&](int idx) {  // DensePolynomial: no trailing zero coefficients
+    const uint8_t* p = &coef[32 * (size_t)idx * ps];
+    size_t len = n;
+    auto zero = [&](size_t i) {
+      for (int b = 0; b < 32; b++)
+        if (p[32 * i + b]) return false;
+      return true;
+    };
+    while (len && zero(len - 1)) len--;
+    w.u64(len);
+    w.put(p, 32 * len);
+  };
+  w.u64(NW);
+  for (int i = 0; i < NW; i++) poly(NS + i);
+  w.u64(NS);
+  for (int i = 0; i < NS; i++) poly(i);
+  w.u64(n_ck);
+  w.put(ck.data(), ck.size());
+  w.u64(0);  // powers_of_gamma_g: none
+  params::OpenKey ok;
+  {
+    g1_affine g0;
+    if (!params::g1_decompress_host(ck.data(), &g0)) return CAPGPU_ERR_SERIALIZATION;
+    ok.g = g0;
+  }
+  ok.gamma_g.x = ok.gamma_g.y = Fq::zero();
+  if (gamma_g) ok.gamma_g = params::g1_from_words(gamma_g);
+  ok.h = params::g2_from_words(h);
+  ok.beta_h = params::g2_from_words(beta_h);
+  params::write_vk(w, K->vk, ok);
+  w.u8(0);  // plookup_pk = None
+  *len_out = w.buf.size();
+  if (cap < w.buf.size()) {
+    set_error("capgpu_plonk_key_serialize: buffer of %zu bytes, %zu needed", cap, w.buf.size());
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  memcpy(out, w.buf.data(), w.buf.size());
+  return CAPGPU_OK;
+}
+
+int capgpu_plonk_key_deserialize(const uint8_t* bytes, size_t len, uint64_t* srs_handle_out, uint64_t* pk_handle_out,
+                                 capgpu_verifying_key* vk_out, uint64_t h_out[16], uint64_t beta_h_out[16],
+                                 size_t* consumed_out) {
+  CAP_CHECK_INIT();
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  if (!bytes || !srs_handle_out || !pk_handle_out) {
+    set_error("capgpu_plonk_key_deserialize: bad argument");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  params::Reader rd(bytes, len);
+  auto fail = [&](const char* why) {
+    set_error("capgpu_plonk_key_deserialize: %s (byte %zu of %zu)", why, rd.pos, len);
+    return CAPGPU_ERR_SERIALIZATION;
+  };
+  struct Span {
+    const uint8_t* p;
+    uint64_t len;
+  };
+  Span polys[18];  // internal order: 13 selectors, then 5 sigmas
+  uint64_t cnt = 0;
+  if (!rd.count(8, &cnt)) return fail("unexpected end of input");
+  if (cnt != NW) return fail("sigmas: a TurboPlonk key has 5 of them");
+  for (int i = 0; i < NW; i++) {
+    if (!rd.count(32, &polys[NS + i].len)) return fail("unexpected end of input");
+    polys[NS + i].p = rd.take(32 * polys[NS + i].len);
+  }
+  if (!rd.count(8, &cnt)) return fail("unexpected end of input");
+  if (cnt != NS) return fail("selectors: a TurboPlonk key has 13 of them");
+  for (int i = 0; i < NS; i++) {
+    if (!rd.count(32, &polys[i].len)) return fail("unexpected end of input");
+    polys[i].p = rd.take(32 * polys[i].len);
+  }
+  uint64_t n_ck = 0, n_gamma = 0;
+  if (!rd.count(32, &n_ck)) return fail("unexpected end of input");
+  const uint8_t* ck = rd.take(32 * n_ck);
+  if (!rd.count(32, &n_gamma)) return fail("unexpected end of input");
+  const uint8_t* gamma = rd.take(32 * n_gamma);
+  capgpu_verifying_key vk;
+  params::OpenKey ok;
+  if (const char* why = params::read_vk(rd, &vk, &ok)) return fail(why);
+  const uint8_t* tag = rd.take(1);
+  if (!tag) return fail("unexpected end of input");
+  if (*tag) return fail("plookup proving keys are not supported");
+  const size_t n = vk.domain_size;
+  if (n < 4 || (n & (n - 1)) || vk.num_inputs >= n) return fail("domain_size must be a power of two above num_inputs");
+  if (n_ck < n + 3) return fail("commit key shorter than domain_size + 3");
+  for (int i = 0; i < 18; i++)
+    if (polys[i].len > n) return fail("polynomial longer than the domain");
+  // the prover's quotient kernel is specialised to the k_i of jf-plonk; refuse anything else
+  for (int i = 0; i < NW; i++) {
+    uint64_t want[4];
+    fe_to_words(Fr::to_mont(fe_from_words(K_CANON[i])), want);
+    if (memcmp(want, vk.k[i], 32) != 0) return fail("coset representatives k_i differ from jf-plonk's");
+  }
+
+  hipStream_t s = c.stream;
+  int rc;
+  // commit key -> device -> window table
+  g1_affine* d_ck = nullptr;
+  CAP_HIP(hipMalloc(&d_ck, sizeof(g1_affine) * std::max<uint64_t>(n_ck, n_gamma)));
+  rc = n_gamma ? params::decompress_g1(gamma, n_gamma, d_ck, s) : CAPGPU_OK;  // validated, then dropped
+  if (rc == CAPGPU_OK) rc = params::decompress_g1(ck, n_ck, d_ck, s);
+  uint64_t srs_handle = 0;
+  if (rc == CAPGPU_OK) rc = register_srs(d_ck, n_ck, &srs_handle);
+  hipFree(d_ck);
+  if (rc) return rc;
+  auto K = std::make_shared<ProvingKey>();
+  auto bail = [&](int code) {
+    capgpu_srs_free(srs_handle);
+    return code;
+  };
+  if ((rc = key_init(*K, n, vk.num_inputs, srs_handle))) return bail(rc);
+  const size_t ps = K->ps;
+  {
+    std::vector<uint8_t> coef(32 * 18 * ps, 0);
+    for (int i = 0; i < 18; i++)
+      if (polys[i].len) memcpy(&coef[32 * (size_t)i * ps], polys[i].p, 32 * polys[i].len);
+    if ((rc = params::fr_bytes_to_mont(coef.data(), 18 * ps, K->coef, s))) return bail(rc);
+  }
+  // sigma evaluations on the domain (round 2 reads them)
+  pad_copy(s, K->sig_eval, n, 0, K->coef + (size_t)NS * ps, ps, 0, 1, NW, n, n);
+  if ((rc = run_ntt(s, K->log_n, K->sig_eval, n, NW, 0, 0))) return bail(rc);
+  if ((rc = key_finish_tables(s, *K))) return bail(rc);
+  std::vector<g1_affine> ha(18);
+  for (int i = 0; i < NS; i++) ha[i] = params::g1_from_words(vk.selector_comms[i]);
+  for (int i = 0; i < NW; i++) ha[NS + i] = params::g1_from_words(vk.sigma_comms[i]);
+  key_set_vk(*K, ha);
+  CAP_HIP(hipStreamSynchronize(s));
+  if (vk_out) *vk_out = K->vk;
+  if (h_out) params::g2_to_words(ok.h, h_out);
+  if (beta_h_out) params::g2_to_words(ok.beta_h, beta_h_out);
+  if (consumed_out) *consumed_out = rd.pos;
+  uint64_t h = c.next_handle++;
+  c.keys[h] = K;
+  *pk_handle_out = h;
+  *srs_handle_out = srs_handle;
   return CAPGPU_OK;
 }
 

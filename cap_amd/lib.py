@@ -165,6 +165,12 @@ def srs_free(handle: int):
     check(load().capgpu_srs_free(ctypes.c_uint64(handle)))
 
 
+def srs_size(handle: int) -> int:
+    n = ctypes.c_size_t(0)
+    check(load().capgpu_srs_size(ctypes.c_uint64(handle), ctypes.byref(n)))
+    return n.value
+
+
 # ---- MSM -----------------------------------------------------------------------------------------
 def msm_g1(handle: int, scalars: np.ndarray, offset: int = 0) -> np.ndarray:
     """scalars (n,4) canonical -> Jacobian (12,) Montgomery."""
@@ -368,3 +374,82 @@ def proof_serialize(proof: Proof) -> bytes:
     n = ctypes.c_size_t(0)
     check(load().capgpu_proof_serialize(ctypes.byref(proof), buf, ctypes.c_size_t(1024), ctypes.byref(n)))
     return bytes(buf[:n.value])
+
+
+# ---- on-disk parameter formats (include/capgpu.h) ----------------------------------------
+CAPGPU_ERR_SERIALIZATION = -8
+
+
+def _u8buf(b: bytes):
+    return (ctypes.c_uint8 * max(len(b), 1)).from_buffer_copy(b if b else b"\0")
+
+
+def _opt_words(a, n):
+    return _p(np.ascontiguousarray(a, dtype=np.uint64).reshape(n)) if a is not None else None
+
+
+def g1_decompress(data: bytes) -> np.ndarray:
+    """n x 32 bytes -> (n, 8) affine Montgomery words, (0, 0) = infinity."""
+    n = len(data) // 32
+    out = np.zeros((n, 8), dtype=np.uint64)
+    check(load().capgpu_g1_decompress(_u8buf(data), ctypes.c_size_t(n), _p(out.reshape(-1)) if n else None))
+    return out
+
+
+def g1_compress(points: np.ndarray) -> bytes:
+    points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 8)
+    n = points.shape[0]
+    out = (ctypes.c_uint8 * max(32 * n, 1))()
+    check(load().capgpu_g1_compress(_p(points.reshape(-1)) if n else None, ctypes.c_size_t(n), out))
+    return bytes(out[:32 * n])
+
+
+def srs_deserialize(data: bytes, max_degree: int = 0):
+    """-> (handle, h, beta_h, consumed)"""
+    handle, used = ctypes.c_uint64(0), ctypes.c_size_t(0)
+    h, bh = np.zeros(16, dtype=np.uint64), np.zeros(16, dtype=np.uint64)
+    check(load().capgpu_srs_deserialize(_u8buf(data), ctypes.c_size_t(len(data)), ctypes.c_size_t(max_degree),
+                                        ctypes.byref(handle), _p(h), _p(bh), ctypes.byref(used)))
+    return handle.value, h, bh, used.value
+
+
+def _sized_call(fn, *head):
+    n = ctypes.c_size_t(0)
+    check(fn(*head, None, ctypes.c_size_t(0), ctypes.byref(n)))
+    buf = (ctypes.c_uint8 * max(n.value, 1))()
+    check(fn(*head, buf, ctypes.c_size_t(n.value), ctypes.byref(n)))
+    return bytes(buf[:n.value])
+
+
+def srs_serialize(handle: int, h: np.ndarray, beta_h: np.ndarray) -> bytes:
+    return _sized_call(load().capgpu_srs_serialize, ctypes.c_uint64(handle), _opt_words(h, 16), _opt_words(beta_h, 16))
+
+
+def plonk_vk_serialize(vk: VerifyingKey, g: np.ndarray, h: np.ndarray, beta_h: np.ndarray, gamma_g=None) -> bytes:
+    return _sized_call(load().capgpu_plonk_vk_serialize, ctypes.byref(vk), _opt_words(g, 8), _opt_words(gamma_g, 8),
+                       _opt_words(h, 16), _opt_words(beta_h, 16))
+
+
+def plonk_vk_deserialize(data: bytes):
+    """-> (vk, g, gamma_g, h, beta_h, consumed)"""
+    vk, used = VerifyingKey(), ctypes.c_size_t(0)
+    g, gg = np.zeros(8, dtype=np.uint64), np.zeros(8, dtype=np.uint64)
+    h, bh = np.zeros(16, dtype=np.uint64), np.zeros(16, dtype=np.uint64)
+    check(load().capgpu_plonk_vk_deserialize(_u8buf(data), ctypes.c_size_t(len(data)), ctypes.byref(vk), _p(g), _p(gg),
+                                             _p(h), _p(bh), ctypes.byref(used)))
+    return vk, g, gg, h, bh, used.value
+
+
+def plonk_key_serialize(pk_handle: int, h: np.ndarray, beta_h: np.ndarray, gamma_g=None) -> bytes:
+    return _sized_call(load().capgpu_plonk_key_serialize, ctypes.c_uint64(pk_handle), _opt_words(gamma_g, 8),
+                       _opt_words(h, 16), _opt_words(beta_h, 16))
+
+
+def plonk_key_deserialize(data: bytes):
+    """-> (srs_handle, pk_handle, vk, h, beta_h, consumed)"""
+    srs, pk, used = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_size_t(0)
+    vk = VerifyingKey()
+    h, bh = np.zeros(16, dtype=np.uint64), np.zeros(16, dtype=np.uint64)
+    check(load().capgpu_plonk_key_deserialize(_u8buf(data), ctypes.c_size_t(len(data)), ctypes.byref(srs),
+                                              ctypes.byref(pk), ctypes.byref(vk), _p(h), _p(bh), ctypes.byref(used)))
+    return srs.value, pk.value, vk, h, bh, used.value

@@ -58,6 +58,8 @@ extern "C" {
 #define CAPGPU_ERR_OOM (-5)
 #define CAPGPU_ERR_NOT_INITIALISED (-6)
 #define CAPGPU_ERR_PROOF (-7) /* prover-side failure: wrong quotient degree (unsatisfied circuit), bad sizes */
+#define CAPGPU_ERR_SERIALIZATION (-8) /* malformed parameter blob: ark_serialize::SerializationError, which the
+                                         reference maps to TxnApiError::DeserializationError (src/errors.rs:81-85) */
 
 #define CAPGPU_NUM_WIRE_TYPES 5
 #define CAPGPU_NUM_SELECTORS 13
@@ -190,6 +192,53 @@ int capgpu_plonk_batch_verify(const capgpu_verifying_key* const* vks, const uint
  * (src/transfer.rs:60): compressed G1 (32 B), Fr little-endian, Vec = u64 length prefix, plookup_proof = None.
  * 769 bytes; *len_out receives the size. */
 int capgpu_proof_serialize(const capgpu_proof* proof, uint8_t* out, size_t cap, size_t* len_out);
+
+/* ---- on-disk parameter formats ------------------------------------------------------
+ * The reference stores and loads its parameters as ark-serialize 0.3 `CanonicalSerialize` bytes
+ * (store_data / load_data, src/parameters.rs:560-577; load_srs, src/proof/mod.rs:74-109) and notes that
+ * "deserializing these parameter files takes longer than reproducing them" (src/lib.rs:81-86): the cost is a
+ * square root in Fq per compressed point.  Here the bulk G1 decompression is one kernel launch.
+ * Encodings: usize = u64 LE; Vec / BTreeMap = u64 length + items; Fr = 32 B LE canonical; G1 compressed = x (32 B
+ * LE) with 0x80 of the last byte = "y is the larger root" and 0x40 = infinity; G2 compressed = x.c0, x.c1 (64 B)
+ * with the same flags in the last byte.  The field order inside each struct is restated from the crates'
+ * definitions (ark-poly-commit @ cafc05e, jf-plonk @ bcd92b2), which are not in the reference tree: parity with a
+ * blob written by the reference is unpinned. */
+
+/* n compressed G1 points (32 B each) <-> affine (x, y), 8 Montgomery words each, (0, 0) = infinity.
+ * Decompression fails with CAPGPU_ERR_SERIALIZATION on x >= p, x not on the curve, or both flag bits set. */
+int capgpu_g1_decompress(const uint8_t* in, size_t n, uint64_t* out_xy);
+int capgpu_g1_compress(const uint64_t* xy, size_t n, uint8_t* out);
+
+/* UniversalSrs blob (parameters::load_universal_parameter, src/parameters.rs:97-109; load_srs): validates every
+ * point, keeps the first max_degree + 1 powers of g resident (0 = all) and returns the handle plus the open key
+ * (h, beta_h: G2 affine, x.c0 x.c1 y.c0 y.c1 Montgomery).  *consumed_out = bytes read. */
+int capgpu_srs_deserialize(const uint8_t* bytes, size_t len, size_t max_degree, uint64_t* handle_out,
+                           uint64_t h_out[16], uint64_t beta_h_out[16], size_t* consumed_out);
+/* parameters::store_universal_parameter_for_demo (src/parameters.rs:47-65).  out == NULL queries the size. */
+int capgpu_srs_serialize(uint64_t handle, const uint64_t h[16], const uint64_t beta_h[16], uint8_t* out, size_t cap,
+                         size_t* len_out);
+
+/* jf-plonk VerifyingKey blob (store_/load_*_verifying_key, src/parameters.rs:190-241, 314-362, 438-478) without
+ * the note-shape trailer the Transfer/Mint/Freeze wrappers append (src/proof/transfer.rs:83-94); host only.
+ * g, gamma_g: the G1 part of the open key (gamma_g may be NULL on serialize = infinity: commitments here are
+ * non-hiding and neither prover nor verifier reads it). */
+int capgpu_plonk_vk_serialize(const capgpu_verifying_key* vk, const uint64_t g[8], const uint64_t gamma_g[8],
+                              const uint64_t h[16], const uint64_t beta_h[16], uint8_t* out, size_t cap,
+                              size_t* len_out);
+int capgpu_plonk_vk_deserialize(const uint8_t* bytes, size_t len, capgpu_verifying_key* vk_out, uint64_t g_out[8],
+                                uint64_t gamma_g_out[8], uint64_t h_out[16], uint64_t beta_h_out[16],
+                                size_t* consumed_out);
+
+/* jf-plonk ProvingKey blob (store_/load_*_proving_key, src/parameters.rs:113-188, 244-312, 364-436), again without
+ * the wrapper's trailer: sigma and selector polynomials, the commit key and the verifying key.  Deserialising
+ * decompresses the commit key on the device, registers it as a new SRS (*srs_handle_out, owned by the caller) and
+ * rebuilds the resident tables of the prover without redoing the 18 interpolations and commitments of
+ * preprocess.  out == NULL on serialize queries the size. */
+int capgpu_plonk_key_serialize(uint64_t pk_handle, const uint64_t gamma_g[8], const uint64_t h[16],
+                               const uint64_t beta_h[16], uint8_t* out, size_t cap, size_t* len_out);
+int capgpu_plonk_key_deserialize(const uint8_t* bytes, size_t len, uint64_t* srs_handle_out, uint64_t* pk_handle_out,
+                                 capgpu_verifying_key* vk_out, uint64_t h_out[16], uint64_t beta_h_out[16],
+                                 size_t* consumed_out);
 
 /* ---- instrumentation ------------------------------------------------------------------------------ */
 /* When enabled, every kernel launch is bracketed by HIP events on the launch stream and accumulated

@@ -14,6 +14,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
 
 from cap_amd import bench_utils as bu  # noqa: E402  (workload synthesis only)
 from oracle import bn254 as bn  # noqa: E402
+from oracle import pairing as pr2  # noqa: E402
+from oracle import params as pm  # noqa: E402
 from oracle import plonk as pl  # noqa: E402
 
 
@@ -81,8 +83,38 @@ def proof_vector():
             "wire_sigma_evals": [hx(v) for v in pr.wire_sigma_evals], "perm_next_eval": hx(pr.perm_next_eval)}
 
 
+def params_vector():
+    """On-disk formats (oracle/params.py) for the log-5 circuit of proof_log5.json under the same tau."""
+    tau = bn.SplitMix64(0xCA9).field(bn.R)
+    sc = bu.synthetic_circuit(5, 3, seed=2)
+    c = pl.Circuit(n=sc.n, num_inputs=3, selectors=sc.selectors, sigma=sc.sigma)
+    pk = pl.preprocess(c, tau)
+    powers, x = [], 1
+    for _ in range(sc.n + 3):
+        powers.append(bn.g1_mul(bn.G1_GEN, x))
+        x = x * tau % bn.R
+    h, beta_h = pr2.G2_GEN, pr2.g2_mul(pr2.G2_GEN, tau)
+    srs = pm.serialize_universal_params(powers, {}, h, beta_h, {})
+    vk = pm.serialize_verifying_key(sc.n, 3, pk.sigma_comms, pk.selector_comms, pl.K, powers[0], bn.INF, h, beta_h)
+    key = pm.serialize_proving_key(pk.sigma_polys, pk.selector_polys, powers, vk)
+    # compressed G1 edge cases: infinity, both roots of one x, and encodings ark-serialize rejects
+    p5 = bn.g1_mul(bn.G1_GEN, 5)
+    x_off = next(v for v in range(1, 50) if pm.fq_sqrt(v ** 3 + 3) is None)
+    bad = {"x_not_on_curve": x_off.to_bytes(32, "little").hex(),
+           "x_not_canonical": (bn.P + 1).to_bytes(32, "little").hex(),
+           "both_flags": (bytes(31) + b"\xc0").hex(),
+           "infinity_with_x": (b"\x01" + bytes(30) + b"\x40").hex()}
+    return {"log_n": 5, "num_inputs": 3, "circuit_seed": 2, "tau_seed": 0xCA9, "srs": srs.hex(), "vk": vk.hex(),
+            "proving_key": key.hex(),
+            "g1_ok": [[bn.g1_serialize_compressed(q).hex(), pt(q)] for q in (bn.INF, p5, bn.g1_neg(p5), bn.G1_GEN)],
+            "g1_bad": bad,
+            "g2": [[pm.g2_serialize_compressed(q).hex(), [[hx(q[0][0]), hx(q[0][1])], [hx(q[1][0]), hx(q[1][1])]]]
+                   for q in (h, beta_h, pr2.g2_neg(beta_h))]}
+
+
 if __name__ == "__main__":
-    for name, fn in (("msm.json", msm_vectors), ("ntt.json", ntt_vectors), ("proof_log5.json", proof_vector)):
+    for name, fn in (("msm.json", msm_vectors), ("ntt.json", ntt_vectors), ("proof_log5.json", proof_vector),
+                     ("params.json", params_vector)):
         with open(os.path.join(HERE, name), "w") as f:
             json.dump(fn(), f, indent=0)
         print("wrote", name)
