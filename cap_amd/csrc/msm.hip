@@ -20,10 +20,12 @@ namespace {
 
 constexpr uint32_t kSkip = 0xFFFFFFFFu;
 constexpr int kThreads = 256;
-constexpr uint32_t kReduceChunk = 4096;  // buckets per msm_reduce_bits workgroup
 constexpr uint32_t kDigitTile = 1024;    // scalars per msm_digits_local workgroup (its entries are sorted in LDS)
 constexpr int kDigitThreads = 1024;       // one scalar per thread: 16 waves hide the LDS-atomic latency
-constexpr uint32_t kItemLen = 32;        // list entries per msm_accumulate work item
+// A bucket's list is cut into work items of at most item_len entries (one msm_accumulate thread each).  item_len
+// is chosen per launch: long items (one per bucket at the prover's sizes) when the batch alone fills the chip,
+// short ones when a single MSM has to be spread over all CUs.
+constexpr uint32_t kMinItemLen = 32, kMaxItemLen = 256;
 
 __device__ __forceinline__ fl shfl_down_fl(const fl& a, int d) {
   fl r;
@@ -254,11 +256,11 @@ __global__ __launch_bounds__(kThreads) void msm_scatter_runs(const uint32_t* __r
 }
 
 // ---- K4: exclusive scan, one workgroup per batch entry ------------------------------------------
-// ITEMS == 0: scans the bucket counts (-> list offsets).  ITEMS == 1: scans ceil(count / kItemLen), the number of
+// ITEMS == 0: scans the bucket counts (-> list offsets).  ITEMS == 1: scans ceil(count / item_len), the number of
 // work items of each bucket (-> item offsets inside the batch entry); the per-entry total goes to totals[].
 template <int ITEMS>
 __global__ __launch_bounds__(1024) void msm_scan(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
-                                                 uint32_t nb, uint32_t* __restrict__ totals) {
+                                                 uint32_t nb, uint32_t* __restrict__ totals, uint32_t item_len) {
   constexpr uint32_t E = 8;  // consecutive elements per thread
   __shared__ uint32_t sh[1024];
   __shared__ uint32_t carry_s;
@@ -273,7 +275,7 @@ __global__ __launch_bounds__(1024) void msm_scan(const uint32_t* __restrict__ co
 #pragma unroll
     for (uint32_t t = 0; t < E; t++) {
       uint32_t x = idx0 + t < nb ? cnt[idx0 + t] : 0;
-      if (ITEMS) x = (x + kItemLen - 1) / kItemLen;
+      if (ITEMS) x = (x + item_len - 1) / item_len;
       v[t] = run;
       run += x;
     }
@@ -309,16 +311,54 @@ __global__ void msm_item_bases(const uint32_t* __restrict__ totals, uint32_t bat
   item_base[batch] = acc;
 }
 
-// item -> global bucket map
-__global__ __launch_bounds__(kThreads) void msm_fill_items(const uint32_t* __restrict__ counts,
-                                                           const uint32_t* __restrict__ item_off,
-                                                           const uint32_t* __restrict__ item_base, uint32_t half,
-                                                           uint32_t total_buckets, uint32_t* __restrict__ item_bucket) {
-  uint32_t gb = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gb >= total_buckets) return;
-  uint32_t items = (counts[gb] + kItemLen - 1) / kItemLen;
-  uint32_t first = item_base[gb / half] + item_off[gb];
-  for (uint32_t j = 0; j < items; j++) item_bucket[first + j] = gb;
+// Work items of one batch entry, ordered by length (longest first): slot -> (bucket, sub-item).  Bucket sizes are
+// Poisson-spread (160 +- 13 entries at the prover's sizes), and a wavefront runs as long as its longest item; with
+// the items of a wave drawn from a sorted list every lane runs (nearly) the same number of additions.  One
+// workgroup per batch entry; counting sort over the item lengths in LDS.
+__global__ __launch_bounds__(1024) void msm_sort_items(const uint32_t* __restrict__ counts,
+                                                       const uint32_t* __restrict__ item_base, uint32_t half,
+                                                       uint32_t item_len, uint32_t* __restrict__ item_bucket,
+                                                       uint32_t* __restrict__ item_sub) {
+  __shared__ uint32_t hist[kMaxItemLen + 1];
+  __shared__ uint32_t cursor[kMaxItemLen + 1];
+  const uint32_t b = blockIdx.x;
+  for (uint32_t l = threadIdx.x; l <= kMaxItemLen; l += blockDim.x) hist[l] = 0;
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < half; j += blockDim.x) {
+    const uint32_t cnt = counts[(size_t)b * half + j];
+    if (cnt == 0) continue;
+    const uint32_t items = (cnt + item_len - 1) / item_len, q = cnt / items, r = cnt - q * items;
+    if (r) atomicAdd(&hist[q + 1], r);
+    atomicAdd(&hist[q], items - r);
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (int l = (int)kMaxItemLen; l >= 0; l--) {
+      cursor[l] = acc;
+      acc += hist[l];
+    }
+  }
+  __syncthreads();
+  const uint32_t ib = item_base[b];
+  for (uint32_t j = threadIdx.x; j < half; j += blockDim.x) {
+    const uint32_t gb = b * half + j;
+    const uint32_t cnt = counts[gb];
+    if (cnt == 0) continue;
+    const uint32_t items = (cnt + item_len - 1) / item_len, q = cnt / items, r = cnt - q * items;
+    if (r) {
+      uint32_t pos = ib + atomicAdd(&cursor[q + 1], r);
+      for (uint32_t k = 0; k < r; k++) {
+        item_bucket[pos + k] = gb;
+        item_sub[pos + k] = k;
+      }
+    }
+    uint32_t pos = ib + atomicAdd(&cursor[q], items - r);
+    for (uint32_t k = r; k < items; k++) {
+      item_bucket[pos + k - r] = gb;
+      item_sub[pos + k - r] = k;
+    }
+  }
 }
 
 __global__ __launch_bounds__(kThreads) void msm_scatter(const uint32_t* __restrict__ keys,
@@ -344,27 +384,28 @@ __global__ __launch_bounds__(kThreads) void msm_scatter(const uint32_t* __restri
 }
 
 // ---- K5: bucket accumulation --------------------------------------------------------------------
-// A bucket's list is cut into work items of at most kItemLen entries; one thread per item.  Every lane of a
-// wavefront therefore runs (almost) the same number of mixed additions whatever the bucket sizes are - a
-// thread-per-bucket mapping loses ~40 % to wave quantisation and the Poisson spread of list lengths, and
-// degrades without bound on skewed scalars (one giant bucket = one serial chain).
+// One thread per work item (a slice of one bucket's list).  The slices of a bucket are of (almost) equal length
+// and the items of a wavefront come from a length-sorted list (msm_sort_items), so every lane of a wavefront runs
+// practically the same number of mixed additions whatever the bucket sizes are; a skewed scalar distribution (one
+// giant bucket) is cut into many items instead of one serial chain.
 __global__ __launch_bounds__(kThreads) void msm_accumulate(const g1_affine* __restrict__ ext,
                                                            const uint32_t* __restrict__ sorted,
                                                            const uint32_t* __restrict__ counts,
                                                            const uint32_t* __restrict__ offsets,
                                                            const uint32_t* __restrict__ item_off,
                                                            const uint32_t* __restrict__ item_base,
-                                                           const uint32_t* __restrict__ item_bucket, size_t per,
-                                                           uint32_t half, uint32_t batch,
+                                                           const uint32_t* __restrict__ item_bucket,
+                                                           const uint32_t* __restrict__ item_sub, size_t per,
+                                                           uint32_t half, uint32_t batch, uint32_t item_len,
                                                            g1_xyzz* __restrict__ item_pts) {
   uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
   if (it >= item_base[batch]) return;
-  uint32_t gb = item_bucket[it];
-  uint32_t b = gb / half;
-  uint32_t j = it - (item_base[b] + item_off[gb]);
-  uint32_t cnt = counts[gb];
-  uint32_t lo = j * kItemLen, hi = lo + kItemLen;
-  if (hi > cnt) hi = cnt;
+  const uint32_t gb = item_bucket[it], j = item_sub[it];
+  const uint32_t b = gb / half;
+  const uint32_t cnt = counts[gb];
+  const uint32_t items = (cnt + item_len - 1) / item_len;
+  const uint32_t q = cnt / items, r = cnt - q * items;
+  const uint32_t lo = j * q + (j < r ? j : r), hi = lo + q + (j < r ? 1u : 0u);
   const uint32_t* lst = sorted + (size_t)b * per + offsets[gb];
   g1x acc = G1L::inf();
   for (uint32_t e = lo; e < hi; e++) {
@@ -372,22 +413,109 @@ __global__ __launch_bounds__(kThreads) void msm_accumulate(const g1_affine* __re
     g1a p = G1L::load(ext[v & 0x7FFFFFFFu]);
     acc = G1L::add_mixed(acc, p, (v >> 31) != 0);
   }
-  item_pts[it] = G1L::store(acc);
+  item_pts[item_base[b] + item_off[gb] + j] = G1L::store(acc);
 }
 
+// ---- K6: bucket reduction by running sums ------------------------------------------------------------------
+// sum_j (j + 1) B_j.  One thread per segment of seg_len consecutive buckets walks it from the top with S += B_j,
+// T += S, so that after the walk  S = sum B_j,  T = sum (j - j_lo + 1) B_j : two additions per bucket, where the
+// bit-plane reduction below spends (c - 1) / 2.
+__global__ __launch_bounds__(kThreads) void msm_reduce_segments(const g1_xyzz* __restrict__ buckets, uint32_t half,
+                                                                uint32_t seg_len, uint32_t nseg, uint32_t batch,
+                                                                g1_xyzz* __restrict__ seg_pts) {
+  uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= nseg * batch) return;
+  const uint32_t b = t / nseg, sg = t - b * nseg;
+  const uint32_t j_lo = sg * seg_len;
+  uint32_t j_hi = j_lo + seg_len;
+  if (j_hi > half) j_hi = half;
+  const g1_xyzz* bk = buckets + (size_t)b * half;
+  g1x S = G1L::inf(), T = G1L::inf();
+  g1_xyzz cur = bk[j_hi - 1];
+  for (uint32_t j = j_hi; j-- > j_lo;) {
+    const g1_xyzz nxt = bk[j > j_lo ? j - 1 : j];  // in flight while the two additions below run
+    S = G1L::add(S, G1L::load(cur));
+    T = G1L::add(T, S);
+    cur = nxt;
+  }
+  seg_pts[2 * (size_t)t] = G1L::store(S);
+  seg_pts[2 * (size_t)t + 1] = G1L::store(T);
+}
+
+__device__ __forceinline__ g1x wave_sum(g1x v) {
+  for (int d = 32; d >= 1; d >>= 1) {
+    g1x o = shfl_down_pt(v, d);
+    v = G1L::add(v, o);
+  }
+  return v;  // lane 0 holds the sum
+}
+__device__ g1x mul_small(const g1x& p, uint32_t k) {
+  g1x r = G1L::inf();
+  for (int bit = 31; bit >= 0; bit--) {
+    if (!G1L::is_inf(r)) r = G1L::dbl(r);
+    if ((k >> bit) & 1) r = G1L::add(r, p);
+  }
+  return r;
+}
+
+// One wavefront per batch entry: total = sum_s T_s + seg_len * sum_s s S_s.  Lane l owns q consecutive segments and
+// repeats the running-sum walk one level up; the lane weights come from a suffix scan across the wave:
+// sum_l l S_l = sum_{m >= 1} (S_m + S_{m+1} + ... + S_63).  The whole kernel is one dependent chain of ~30 point
+// operations per launch, so it is written for depth, not for work.
+__global__ __launch_bounds__(64) void msm_reduce_final(const g1_xyzz* __restrict__ seg_pts, uint32_t seg_len,
+                                                       uint32_t nseg, g1_jac* __restrict__ out) {
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  const uint32_t q = (nseg + 63) / 64;
+  const uint32_t s_lo = lane * q;
+  uint32_t s_hi = s_lo + q;
+  if (s_hi > nseg) s_hi = nseg;
+  const g1_xyzz* sp = seg_pts + 2 * (size_t)b * nseg;
+  g1x S = G1L::inf(), T = G1L::inf(), A = G1L::inf();
+  for (uint32_t s = s_hi; s > s_lo;) {
+    s--;
+    T = G1L::add(T, S);                       // every segment above s gains one more unit of weight
+    S = G1L::add(S, G1L::load(sp[2 * s]));
+    A = G1L::add(A, G1L::load(sp[2 * s + 1]));
+  }
+  // S = sum S_s, T = sum (s - s_lo) S_s, A = sum T_s over the lane's segments
+  g1x suf = S;  // inclusive suffix sum over lanes
+  for (int d = 1; d < 64; d <<= 1) {
+    g1x o = shfl_down_pt(suf, d);
+    if (lane + d < 64) suf = G1L::add(suf, o);
+  }
+  if (lane == 0) suf = G1L::inf();
+  // per lane: A + seg_len * (T + q * suf); their sum over the wave is the result
+  g1x r = G1L::add(T, mul_small(suf, q));
+  r = G1L::add(mul_small(r, seg_len), A);
+  r = wave_sum(r);
+  if (lane == 0) out[b] = G1L::to_jac_ext(r);
+}
+
+// ---- K6 for small batches --------------------------------------------------------------------------------------
+// The running-sum walk needs thousands of independent segments to fill the chip; one large MSM (or a handful) does
+// not have them.  There the buckets are combined per bucket and reduced through bit planes, both log-depth.
+constexpr uint32_t kReduceChunk = 4096;  // buckets per msm_reduce_bits workgroup
 // bucket = sum of its work items (a handful of full additions per bucket)
 __global__ __launch_bounds__(kThreads) void msm_combine(const g1_xyzz* __restrict__ item_pts,
                                                         const uint32_t* __restrict__ counts,
                                                         const uint32_t* __restrict__ item_off,
                                                         const uint32_t* __restrict__ item_base, uint32_t half,
-                                                        uint32_t total_buckets, g1_xyzz* __restrict__ buckets) {
+                                                        uint32_t total_buckets, uint32_t item_len,
+                                                        g1_xyzz* __restrict__ buckets) {
   uint32_t gb = blockIdx.x * blockDim.x + threadIdx.x;
   if (gb >= total_buckets) return;
-  uint32_t items = (counts[gb] + kItemLen - 1) / kItemLen;
+  uint32_t items = (counts[gb] + item_len - 1) / item_len;
   uint32_t first = item_base[gb / half] + item_off[gb];
   g1x acc = G1L::inf();
-  if (items) acc = G1L::load(item_pts[first]);
-  for (uint32_t j = 1; j < items; j++) acc = G1L::add(acc, G1L::load(item_pts[first + j]));
+  if (items) {
+    acc = G1L::load(item_pts[first]);
+    g1_xyzz cur = item_pts[first + (items > 1 ? 1 : 0)];
+    for (uint32_t j = 1; j < items; j++) {
+      const g1_xyzz nxt = item_pts[first + (j + 1 < items ? j + 1 : j)];  // in flight during the addition
+      acc = G1L::add(acc, G1L::load(cur));
+      cur = nxt;
+    }
+  }
   buckets[gb] = G1L::store(acc);
 }
 
@@ -424,7 +552,7 @@ __global__ __launch_bounds__(kThreads) void msm_reduce_bits(const g1_xyzz* __res
 
 // ---- K6b: sum_b 2^b T_b ------------------------------------------------------------------------------
 // one wavefront per batch entry; lane = bit.
-__global__ __launch_bounds__(64) void msm_reduce_final(const g1_xyzz* __restrict__ partial, uint32_t c,
+__global__ __launch_bounds__(64) void msm_reduce_bits_final(const g1_xyzz* __restrict__ partial, uint32_t c,
                                                        uint32_t chunks, g1_jac* __restrict__ out) {
   const uint32_t b = blockIdx.x, lane = threadIdx.x;
   g1x acc = G1L::inf();
@@ -446,9 +574,21 @@ __global__ __launch_bounds__(64) void msm_reduce_final(const g1_xyzz* __restrict
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
-  size_t counts, offsets, keys, ranks, sorted, buckets, partial, item_off, item_base, totals, item_bucket, item_pts,
+  size_t counts, offsets, keys, ranks, sorted, buckets, partial, item_off, item_base, totals, item_bucket, item_sub, item_pts,
       max_items, table, off2, tloc, chunks, nblk, total;
 };
+// buckets per msm_reduce_segments thread: 16 keeps >= 64 segments per batch entry from c = 11 up
+uint32_t reduce_seg_len(uint32_t half) { return half >= 1024 ? 16u : (half >= 64 ? half / 64 : 1u); }
+// the running-sum reduction wants >= 16 Ki independent segments (64 waves per XCD); below that the log-depth path
+bool use_segment_reduce(uint32_t half, uint32_t batch) {
+  uint32_t seg_len = reduce_seg_len(half);
+  return (size_t)((half + seg_len - 1) / seg_len) * batch >= 16384;
+}
+// about 2 waves per SIMD worth of work items (256 CUs x 4 SIMDs x 64 lanes x 2) before items grow beyond the minimum
+uint32_t choose_item_len(size_t entries) {
+  size_t l = entries / ((size_t)1 << 17);
+  return (uint32_t)std::min<size_t>(std::max<size_t>(l, kMinItemLen), kMaxItemLen);
+}
 bool use_local_digits(uint32_t c, size_t n, uint32_t batch) {
   size_t half = (size_t)1 << (c - 1);
   size_t nblk = (n + kDigitTile - 1) / kDigitTile;
@@ -459,20 +599,26 @@ WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t batch) {
   WsLayout L{};
   size_t half = (size_t)1 << (c - 1);
   size_t per = (size_t)windows * n;
-  size_t chunks = (half + kReduceChunk - 1) / kReduceChunk;
+  size_t seg_len = reduce_seg_len((uint32_t)half);
+  size_t nseg = (half + seg_len - 1) / seg_len;
   size_t o = 0;
   L.counts = o;  o = align_up(o + sizeof(uint32_t) * half * batch, 256);
   L.offsets = o; o = align_up(o + sizeof(uint32_t) * half * batch, 256);
   L.keys = o;    o = align_up(o + sizeof(uint32_t) * per * batch, 256);
   L.ranks = o;   o = align_up(o + sizeof(uint32_t) * per * batch, 256);
   L.sorted = o;  o = align_up(o + sizeof(uint32_t) * per * batch, 256);
-  L.buckets = o; o = align_up(o + sizeof(g1_xyzz) * half * batch, 256);
-  L.partial = o; o = align_up(o + sizeof(g1_xyzz) * c * chunks * batch, 256);
-  L.max_items = per * batch / kItemLen + half * batch;  // sum ceil(cnt/L) <= entries/L + non-empty buckets
+  {
+    size_t chunks = (half + kReduceChunk - 1) / kReduceChunk;
+    size_t npart = use_segment_reduce((uint32_t)half, batch) ? 2 * nseg : c * chunks;
+    L.buckets = o; o = align_up(o + sizeof(g1_xyzz) * half * batch, 256);
+    L.partial = o; o = align_up(o + sizeof(g1_xyzz) * npart * batch, 256);
+  }
+  L.max_items = per * batch / choose_item_len(per * batch) + half * batch;  // sum ceil(cnt/L) <= entries/L + buckets
   L.item_off = o;    o = align_up(o + sizeof(uint32_t) * half * batch, 256);
   L.item_base = o;   o = align_up(o + sizeof(uint32_t) * (batch + 1), 256);
   L.totals = o;      o = align_up(o + sizeof(uint32_t) * batch, 256);
   L.item_bucket = o; o = align_up(o + sizeof(uint32_t) * L.max_items, 256);
+  L.item_sub = o;    o = align_up(o + sizeof(uint32_t) * L.max_items, 256);
   L.item_pts = o;    o = align_up(o + sizeof(g1_xyzz) * L.max_items, 256);
   L.nblk = use_local_digits(c, n, batch) ? (n + kDigitTile - 1) / kDigitTile : 0;
   L.table = o;       o = align_up(o + sizeof(uint32_t) * half * L.nblk * batch, 256);
@@ -543,10 +689,9 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
   uint32_t* keys = reinterpret_cast<uint32_t*>(base + L.keys);
   uint32_t* ranks = reinterpret_cast<uint32_t*>(base + L.ranks);
   uint32_t* sorted = reinterpret_cast<uint32_t*>(base + L.sorted);
-  g1_xyzz* buckets = reinterpret_cast<g1_xyzz*>(base + L.buckets);
   g1_xyzz* partial = reinterpret_cast<g1_xyzz*>(base + L.partial);
   const size_t per = (size_t)W * n;
-  const uint32_t chunks = (half + kReduceChunk - 1) / kReduceChunk;
+  const uint32_t seg_len = reduce_seg_len(half), nseg = (half + seg_len - 1) / seg_len;
   const uint32_t total_buckets = half * batch;
 
   if (L.nblk) {
@@ -565,7 +710,7 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
     launch("msm_digits_local", msm_digits_local, dim3(nblk, batch), dim3(kDigitThreads), lds_bytes, stream, d_scalars,
            outer_stride, inner, inner_stride, n, montgomery, c, W, nblk, bases.n, offset, table, tloc, chunk_buf);
     launch("msm_scan", msm_scan<0>, dim3(batch), dim3(1024), 0, stream, (const uint32_t*)table, off2, half * nblk,
-           (uint32_t*)nullptr);
+           (uint32_t*)nullptr, 0u);
     launch("msm_bucket_ranges", msm_bucket_ranges, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0,
            stream, (const uint32_t*)table, (const uint32_t*)off2, half, nblk, total_buckets, counts, offsets);
     size_t rows = (size_t)total_buckets * nblk;
@@ -581,7 +726,7 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
              stream, d_scalars, outer_stride, inner, inner_stride, n, batch, montgomery, c, W, counts, keys, ranks);
     }
     launch("msm_scan", msm_scan<0>, dim3(batch), dim3(1024), 0, stream, (const uint32_t*)counts, offsets, half,
-           (uint32_t*)nullptr);
+           (uint32_t*)nullptr, 0u);
     if (n > 0) {
       size_t ne = per * batch;
       launch("msm_scatter", msm_scatter, dim3((unsigned)((ne + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
@@ -593,24 +738,35 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
   uint32_t* totals = reinterpret_cast<uint32_t*>(base + L.totals);
   uint32_t* item_bucket = reinterpret_cast<uint32_t*>(base + L.item_bucket);
   g1_xyzz* item_pts = reinterpret_cast<g1_xyzz*>(base + L.item_pts);
+  uint32_t* item_sub = reinterpret_cast<uint32_t*>(base + L.item_sub);
+  const uint32_t item_len = choose_item_len(per * batch);
   launch("msm_scan_items", msm_scan<1>, dim3(batch), dim3(1024), 0, stream, (const uint32_t*)counts, item_off, half,
-         totals);
+         totals, item_len);
   launch("msm_item_bases", msm_item_bases, dim3(1), dim3(64), 0, stream, (const uint32_t*)totals, batch, item_base);
-  launch("msm_fill_items", msm_fill_items, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0, stream,
-         (const uint32_t*)counts, (const uint32_t*)item_off, (const uint32_t*)item_base, half, total_buckets,
-         item_bucket);
+  launch("msm_sort_items", msm_sort_items, dim3(batch), dim3(1024), 0, stream, (const uint32_t*)counts,
+         (const uint32_t*)item_base, half, item_len, item_bucket, item_sub);
   if (L.max_items > 0) {
     launch("msm_accumulate", msm_accumulate, dim3((unsigned)((L.max_items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
            stream, bases.ext, (const uint32_t*)sorted, (const uint32_t*)counts, (const uint32_t*)offsets,
-           (const uint32_t*)item_off, (const uint32_t*)item_base, (const uint32_t*)item_bucket, per, half, batch,
-           item_pts);
+           (const uint32_t*)item_off, (const uint32_t*)item_base, (const uint32_t*)item_bucket,
+           (const uint32_t*)item_sub, per, half, batch, item_len, item_pts);
   }
+  g1_xyzz* buckets = reinterpret_cast<g1_xyzz*>(base + L.buckets);
   launch("msm_combine", msm_combine, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0, stream,
          (const g1_xyzz*)item_pts, (const uint32_t*)counts, (const uint32_t*)item_off, (const uint32_t*)item_base, half,
-         total_buckets, buckets);
-  launch("msm_reduce_bits", msm_reduce_bits, dim3(chunks, c, batch), dim3(kThreads), 0, stream, buckets, half, c, chunks,
-                     partial);
-  launch("msm_reduce_final", msm_reduce_final, dim3(batch), dim3(64), 0, stream, partial, c, chunks, d_out);
+         total_buckets, item_len, buckets);
+  if (use_segment_reduce(half, batch)) {
+    launch("msm_reduce_segments", msm_reduce_segments, dim3((nseg * batch + kThreads - 1) / kThreads), dim3(kThreads),
+           0, stream, (const g1_xyzz*)buckets, half, seg_len, nseg, batch, partial);
+    launch("msm_reduce_final", msm_reduce_final, dim3(batch), dim3(64), 0, stream, (const g1_xyzz*)partial, seg_len,
+           nseg, d_out);
+  } else {
+    const uint32_t chunks = (half + kReduceChunk - 1) / kReduceChunk;
+    launch("msm_reduce_bits", msm_reduce_bits, dim3(chunks, c, batch), dim3(kThreads), 0, stream,
+           (const g1_xyzz*)buckets, half, c, chunks, partial);
+    launch("msm_reduce_bits_final", msm_reduce_bits_final, dim3(batch), dim3(64), 0, stream, (const g1_xyzz*)partial, c,
+           chunks, d_out);
+  }
   return (int)hipGetLastError();
 }
 

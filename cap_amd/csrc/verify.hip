@@ -110,7 +110,6 @@ int capgpu_pairing_check(const uint64_t* g1_points, const uint64_t* g2_points, s
 static int verifier_prepare(const capgpu_verifying_key* vk, const uint64_t* pub_inputs, size_t num_inputs,
                             const capgpu_proof* proof, const uint8_t* ext_msg, size_t ext_msg_len, g1_affine* a_out,
                             g1_affine* b_out, int* valid) {
-  int* ok_out = valid;
   const uint64_t n = vk->domain_size;
   if (n < 4 || (n & (n - 1)) || num_inputs != vk->num_inputs) {
     set_error("capgpu_plonk_verify: %zu public inputs given, key expects %llu (domain %llu)", num_inputs,
