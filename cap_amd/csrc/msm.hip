@@ -140,8 +140,8 @@ __device__ __forceinline__ uint32_t msm_digit(const fe& k, uint32_t w, uint32_t 
 __global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __restrict__ scalars, size_t outer_stride,
                                                              uint32_t inner, size_t inner_stride, size_t n,
                                                              int montgomery, uint32_t c, uint32_t windows,
-                                                             uint32_t nblk, size_t srs_n, size_t base_offset,
-                                                             uint32_t* __restrict__ table,
+                                                             uint32_t nblk, uint32_t batch, size_t srs_n,
+                                                             size_t base_offset, uint32_t* __restrict__ table,
                                                              uint32_t* __restrict__ tloc,
                                                              uint32_t* __restrict__ chunks) {
   extern __shared__ uint32_t lds[];
@@ -150,16 +150,22 @@ __global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __re
   uint32_t* loff = lds + half;       // [half]   tile-local exclusive offsets
   uint32_t* buf = lds + 2 * half;    // [kDigitTile * windows] sorted entries
   __shared__ uint32_t wave_tot[kDigitThreads / 64];
-  const uint32_t b = blockIdx.y, blk = blockIdx.x;
+  // XCD-aware block order: workgroups are dealt round-robin to the 8 XCDs, each with its own L2.  The tiles of one
+  // batch entry write interleaved 4-byte cells of the same table lines ([bucket][tile] layout), so they are all sent
+  // to one XCD, where the partial writes merge in that L2 instead of leaving eight L2s as masked partial lines.
+  const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const uint32_t b = (slot / nblk) * 8 + xcd, blk = slot % nblk;
+  if (b >= batch) return;
   for (uint32_t j = threadIdx.x; j < half; j += kDigitThreads) hist[j] = 0;
   __syncthreads();
   const fe* sc = scalars + (size_t)(b / inner) * outer_stride + (size_t)(b % inner) * inner_stride;
-  // pass A: histogram
-  for (uint32_t q = 0; q < kDigitTile / kDigitThreads; q++) {
-    size_t i = (size_t)blk * kDigitTile + q * kDigitThreads + threadIdx.x;
-    if (i >= n) break;
-    fe k = sc[i];
+  static_assert(kDigitTile == kDigitThreads, "one scalar per thread: it stays in registers between the passes");
+  const size_t i = (size_t)blk * kDigitTile + threadIdx.x;
+  fe k;
+  if (i < n) {
+    k = sc[i];
     if (montgomery) k = Fr::from_mont(k);
+    // pass A: histogram
     uint32_t carry = 0;
     for (uint32_t w = 0; w < windows; w++) {
       uint32_t d = msm_digit(k, w, c, carry) & 0x7FFFFFFFu;
@@ -198,18 +204,14 @@ __global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __re
   }
   __syncthreads();
   // pass B: place the table indices
-  for (uint32_t q = 0; q < kDigitTile / kDigitThreads; q++) {
-    size_t i = (size_t)blk * kDigitTile + q * kDigitThreads + threadIdx.x;
-    if (i >= n) break;
-    fe k = sc[i];
-    if (montgomery) k = Fr::from_mont(k);
+  if (i < n) {
     uint32_t carry = 0;
     for (uint32_t w = 0; w < windows; w++) {
       uint32_t d = msm_digit(k, w, c, carry);
       uint32_t mag = d & 0x7FFFFFFFu;
       if (mag) {
-        uint32_t slot = atomicAdd(&hist[mag - 1], 1u);
-        buf[slot] = (uint32_t)((size_t)w * srs_n + base_offset + i) | (d & 0x80000000u);
+        uint32_t pos = atomicAdd(&hist[mag - 1], 1u);
+        buf[pos] = (uint32_t)((size_t)w * srs_n + base_offset + i) | (d & 0x80000000u);
       }
     }
   }
@@ -584,9 +586,9 @@ bool use_segment_reduce(uint32_t half, uint32_t batch) {
   uint32_t seg_len = reduce_seg_len(half);
   return (size_t)((half + seg_len - 1) / seg_len) * batch >= 16384;
 }
-// about 2 waves per SIMD worth of work items (256 CUs x 4 SIMDs x 64 lanes x 2) before items grow beyond the minimum
+// about 8 waves per SIMD worth of work items (256 CUs x 4 SIMDs x 64 lanes x 8) before items grow beyond the minimum
 uint32_t choose_item_len(size_t entries) {
-  size_t l = entries / ((size_t)1 << 17);
+  size_t l = entries / ((size_t)1 << 19);
   return (uint32_t)std::min<size_t>(std::max<size_t>(l, kMinItemLen), kMaxItemLen);
 }
 bool use_local_digits(uint32_t c, size_t n, uint32_t batch) {
@@ -707,8 +709,9 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
                           160 * 1024 - 64);
       attr_set = true;
     }
-    launch("msm_digits_local", msm_digits_local, dim3(nblk, batch), dim3(kDigitThreads), lds_bytes, stream, d_scalars,
-           outer_stride, inner, inner_stride, n, montgomery, c, W, nblk, bases.n, offset, table, tloc, chunk_buf);
+    launch("msm_digits_local", msm_digits_local, dim3(nblk * ((batch + 7) / 8) * 8), dim3(kDigitThreads), lds_bytes,
+           stream, d_scalars, outer_stride, inner, inner_stride, n, montgomery, c, W, nblk, batch, bases.n, offset,
+           table, tloc, chunk_buf);
     launch("msm_scan", msm_scan<0>, dim3(batch), dim3(1024), 0, stream, (const uint32_t*)table, off2, half * nblk,
            (uint32_t*)nullptr, 0u);
     launch("msm_bucket_ranges", msm_bucket_ranges, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0,

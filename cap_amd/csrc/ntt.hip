@@ -67,6 +67,17 @@ __device__ __forceinline__ void lds_ntt(fl* sh, const fe* __restrict__ tw_small,
       uint32_t j = ((bb >> s) << (s + 1)) + pos;
       uint32_t i0 = (j << log_c) + c, i1 = ((j + half) << log_c) + c;
       fl u = sh[i0], v = sh[i1];
+      if (s < 3) {
+        // zero-padded inputs (a degree-n polynomial on the 8n coset: 7 of the prover's 8 large transforms): the rows
+        // beyond len/8 are zero, so in the first three stages every odd operand is zero and the butterfly is a copy
+        uint32_t any = 0;
+#pragma unroll
+        for (int k = 0; k < 9; k++) any |= v.v[k];
+        if (any == 0) {
+          sh[i1] = u;
+          continue;
+        }
+      }
       uint32_t e = pos << (log_len - 1 - s);
       fl t = e ? Fr29::mul(v, Fr29::load(tw_small[e])) : Fr29::weak_reduce(v);
       sh[i0] = Fr29::normalize(Fr29::add(u, t));
@@ -93,8 +104,12 @@ __global__ __launch_bounds__(kThreads) void ntt_col_pass(PassParams p) {
   for (uint32_t e = threadIdx.x; e < tile; e += kThreads) {
     uint32_t c = e & cmask, j = e >> p.log_c;
     size_t g = base + ((size_t)j << log_s) + c;
-    fl v = Fr29::load(in[g]);
-    if (p.pre_scale) v = Fr29::mul(v, Fr29::load(p.pre_scale[g]));
+    const fe raw = in[g];
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) any |= raw.v[k];
+    fl v = Fr29::load(raw);
+    if (p.pre_scale && any) v = Fr29::mul(v, Fr29::load(p.pre_scale[g]));  // zero padding needs no coset scaling
     sh[(bitrev32(j, p.log_len) << p.log_c) + c] = v;
   }
   __syncthreads();
@@ -124,8 +139,12 @@ __global__ __launch_bounds__(kThreads) void ntt_row_pass(PassParams p) {
   for (uint32_t e = threadIdx.x; e < tile; e += kThreads) {
     uint32_t j = e & lmask, c = e >> p.log_len;
     size_t g = ((((size_t)(r0 + c) << p.log_n2) + k2) << p.log_len) + j;
-    fl v = Fr29::load(in[g]);
-    if (p.pre_scale) v = Fr29::mul(v, Fr29::load(p.pre_scale[g]));
+    const fe raw = in[g];
+    uint32_t any = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) any |= raw.v[k];
+    fl v = Fr29::load(raw);
+    if (p.pre_scale && any) v = Fr29::mul(v, Fr29::load(p.pre_scale[g]));  // zero padding needs no coset scaling
     sh[(bitrev32(j, p.log_len) << p.log_c) + c] = v;
   }
   __syncthreads();

@@ -310,7 +310,7 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
       if ((rc = compute_pk_coset(s, K, w.pkc))) return rc;
     pkc = w.pkc;
   }
-  launch("k_quotient", k_quotient, dim3(cdiv(m, kThreads), P), dim3(kThreads), 0, s, pkc, (const fe*)w.coset,
+  launch("k_quotient", k_quotient, dim3(P, cdiv(m, kThreads)), dim3(kThreads), 0, s, pkc, (const fe*)w.coset,
          (const fe*)dom_m->tw29_fwd, (const fe*)K.inv_nx1, (const Chal*)w.chal29, K.qc29, m, w.t);
   if ((rc = run_ntt(s, K.log_m, w.t, m, P, 1, 1, kNttInInternal))) return rc;
   {

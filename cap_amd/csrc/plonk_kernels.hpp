@@ -230,9 +230,11 @@ __global__ __launch_bounds__(kThreads) void k_quotient(const fe* __restrict__ pk
                                                        const Chal* __restrict__ chal, QuotConst qc, size_t m,
                                                        fe* __restrict__ t_out) {
   using F = Fr29;
-  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  // grid (proofs, tiles): the proofs of one tile run together, so the 18 shared selector / sigma tiles are read from
+  // HBM once per tile and served from L2 to the other proofs of the batch
+  size_t i = (size_t)blockIdx.y * blockDim.x + threadIdx.x;
   if (i >= m) return;
-  const uint32_t p = blockIdx.y;
+  const uint32_t p = blockIdx.x;
   const fe* c = cos + (size_t)p * 7 * m;
   auto sel = [&](int s) { return F::load(pkc[(size_t)s * m + i]); };
   fl w0 = F::load(c[i]), w1 = F::load(c[m + i]), w2 = F::load(c[2 * m + i]), w3 = F::load(c[3 * m + i]),
