@@ -36,12 +36,13 @@ struct PassParams {
   const fe* in;
   fe* out;
   size_t batch_stride;       // elements between consecutive arrays of the batch
-  const fe* tw_small;        // omega_len^i, i < len/2
+  const fl* tw_small;        // omega_len^i, i < len/2, unpacked limbs
   const fe* tw_full;         // omega_N^e, e < N (col pass twiddles); may be null for row pass
   const fe* pre_scale;       // indexed by global input index, or null
   const fe* post_scale;      // indexed by global output index, or null
   fe post_scalar;            // used when use_post_scalar
   uint32_t use_post_scalar;
+  uint32_t lazy_out;         // row pass: leave results weakly reduced (< 2r) instead of canonical
   uint32_t log_n;
   uint32_t log_len;          // sub-transform size
   uint32_t log_c;            // tile width
@@ -55,7 +56,7 @@ __device__ __forceinline__ uint32_t bitrev32(uint32_t x, uint32_t bits) { return
 // Lazy 29-bit field: per butterfly  t = v * w (one Montgomery product, < 1.2p),  (u + t, u + 2p - t); values
 // grow by at most 2p per stage (<= 2p * 11 stages + input), far below the 169p capacity of 9 x 29-bit limbs.
 // Twiddles are stored in the internal Montgomery form (w * 2^261), so data keeps whatever form it came in.
-__device__ __forceinline__ void lds_ntt(fl* sh, const fe* __restrict__ tw_small, uint32_t log_len, uint32_t log_c) {
+__device__ __forceinline__ void lds_ntt(fl* sh, const fl* __restrict__ tw_small, uint32_t log_len, uint32_t log_c) {
   const uint32_t half_tile = 1u << (log_len + log_c - 1);
   const uint32_t cmask = (1u << log_c) - 1;
   for (uint32_t s = 0; s < log_len; s++) {
@@ -79,7 +80,7 @@ __device__ __forceinline__ void lds_ntt(fl* sh, const fe* __restrict__ tw_small,
         }
       }
       uint32_t e = pos << (log_len - 1 - s);
-      fl t = e ? Fr29::mul(v, Fr29::load(tw_small[e])) : Fr29::weak_reduce(v);
+      fl t = e ? Fr29::mul(v, tw_small[e]) : Fr29::weak_reduce(v);
       sh[i0] = Fr29::normalize(Fr29::add(u, t));
       sh[i1] = Fr29::sub2p(u, t);
     }
@@ -155,8 +156,15 @@ __global__ __launch_bounds__(kThreads) void ntt_row_pass(PassParams p) {
     size_t g = (size_t)(r0 + c) + ((size_t)k2 << p.log_n1) + ((size_t)k << (p.log_n1 + p.log_n2));
     if (p.post_scale) v = Fr29::mul(v, Fr29::load(p.post_scale[g]));
     else if (p.use_post_scalar) v = Fr29::mul(v, Fr29::load(p.post_scalar));
-    out[g] = Fr29::pack(Fr29::canonical(v));   // results leave the transform canonical (< r), as arkworks stores them
+    // results leave the transform canonical (< r), as arkworks stores them - except the internal-form coset
+    // evaluations, whose only reader (k_quotient) takes any representative below 2^256
+    out[g] = p.lazy_out ? Fr29::store(v) : Fr29::pack(Fr29::canonical(v));
   }
+}
+
+__global__ void table_unpack(fl* __restrict__ out, const fe* __restrict__ in, size_t n) {
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e < n) out[e] = Fr29::load(in[e]);
 }
 
 // internal-form table: out[e] = pack(canonical(in_ext[e] * 2^5))  (x * 2^256 -> x * 2^261)
@@ -239,6 +247,13 @@ int ntt_build_small_tables(NttSmallTables* t, hipStream_t stream) {
            (const fe*)t->fwd[s], n);
     launch("table_to_internal", table_to_internal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, t->inv[s],
            (const fe*)t->inv[s], n);
+    for (int d = 0; d < 2; d++) {
+      uint32_t** dst = d ? &t->inv_u[s] : &t->fwd_u[s];
+      e = hipMalloc(dst, sizeof(fl) * n);
+      if (e != hipSuccess) return (int)e;
+      launch("table_unpack", table_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
+             reinterpret_cast<fl*>(*dst), (const fe*)(d ? t->inv[s] : t->fwd[s]), n);
+    }
     hipError_t es = hipStreamSynchronize(stream);
     if (es != hipSuccess) return (int)es;
   }
@@ -249,7 +264,10 @@ void ntt_free_small_tables(NttSmallTables* t) {
   for (int s = 0; s <= kMaxLogTile; s++) {
     if (t->fwd[s]) hipFree(t->fwd[s]);
     if (t->inv[s]) hipFree(t->inv[s]);
+    if (t->fwd_u[s]) hipFree(t->fwd_u[s]);
+    if (t->inv_u[s]) hipFree(t->inv_u[s]);
     t->fwd[s] = t->inv[s] = nullptr;
+    t->fwd_u[s] = t->inv_u[s] = nullptr;
   }
 }
 
@@ -337,7 +355,7 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
     lg[2] = log_n - lg[0] - lg[1];
   }
   if (lg[0] > 10 || lg[1] > 10 || lg[2] > 10) return (int)hipErrorInvalidValue;
-  const fe* const* tws = dir ? small.inv : small.fwd;
+  uint32_t* const* tws = dir ? small.inv_u : small.fwd_u;
   const fe* tw_full = dir ? dom.tw29_inv : dom.tw29_fwd;
 
   PassParams p{};
@@ -359,7 +377,7 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
     if (log_c > 4) log_c = 4;
     p.in = cur_in;
     p.out = scratch;
-    p.tw_small = tws[log_len];
+    p.tw_small = reinterpret_cast<const fl*>(tws[log_len]);
     p.pre_scale = first ? pre : nullptr;
     p.post_scale = nullptr;
     p.log_len = log_len;
@@ -382,11 +400,12 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
     if (log_c > 4) log_c = 4;
     p.in = cur_in;
     p.out = data;
-    p.tw_small = tws[log_len];
+    p.tw_small = reinterpret_cast<const fl*>(tws[log_len]);
     p.pre_scale = first ? pre : nullptr;
     p.post_scale = (dir && coset) ? (io_form == kNttInInternal ? dom.coset_inv : dom.coset29_inv) : nullptr;
     p.use_post_scalar = (dir && !coset) ? 1 : 0;
     p.post_scalar = dom.n_inv29;
+    p.lazy_out = io_form == kNttOutInternal ? 1 : 0;
     p.log_len = log_len;
     p.log_c = log_c;
     p.log_n1 = log_n1;
