@@ -175,6 +175,41 @@ def test_msm_known_tau_identity_full_size(cg, tau, log_n):
     cg.srs_free(h)
 
 
+def test_msm_skewed_scalars_in_a_large_batch(cg, tau):
+    """Worst case for a bucket method: every scalar of an MSM equal, so each window sends all n entries into ONE
+    bucket.  In a batch large enough for the running-sum reduction (>= 64 MSMs at c = 13) the giant buckets are cut
+    into many length-sorted work items and recombined; the batch also holds ordinary random MSMs and an all-zero one.
+    Checked with the known-tau identity: sum_i k tau^i G = [k (tau^n - 1) / (tau - 1)] G, and against the same MSMs
+    run one at a time (the single-MSM path reduces through bit planes instead)."""
+    n, batch = 6000, 64
+    h = cg.srs_generate(tau, n)
+    geo = (pow(tau, n, bn.R) - 1) * pow(tau - 1, bn.R - 2, bn.R) % bn.R
+    rng = bn.SplitMix64(4242)
+    consts = [rng.field(bn.R) for _ in range(batch)]
+    consts[1], consts[2], consts[3] = 1, bn.R - 1, (1 << 13) - 1
+    scs = []
+    for b in range(batch):
+        if b % 4 == 3:
+            scs.append(cr.random_field(9000 + b, 1, n, False))                 # ordinary MSM
+        elif b == 8:
+            scs.append(np.zeros((n, 4), np.uint64))                            # all zero: result is infinity
+        else:
+            scs.append(np.tile(cr.int_to_limbs(consts[b]), (n, 1)))            # one giant bucket per window
+    got = cg.msm_g1_batch(h, scs)
+    for b in range(batch):
+        pt = cr.affine_to_ints(cr.g1_to_affine(got[b]))
+        if b % 4 == 3:
+            if b in (3, 35, 63):
+                assert pt == cr.affine_to_ints(cr.g1_to_affine(cg.msm_g1(h, scs[b]))), b
+        elif b == 8:
+            assert pt is None
+        else:
+            assert pt == bn.g1_mul(bn.G1_GEN, consts[b] * geo % bn.R), b
+    # the same skewed MSM alone (32-entry items, bit-plane reduction)
+    assert cr.affine_to_ints(cr.g1_to_affine(cg.msm_g1(h, scs[0]))) == bn.g1_mul(bn.G1_GEN, consts[0] * geo % bn.R)
+    cg.srs_free(h)
+
+
 def test_msm_affine_seq_bases(cg):
     """BASELINE config 5's synthetic bases P_i = [a + i b]G: sum k_i P_i = [sum k_i (a + i b)] G."""
     a, b, n = 12345678901234567890, 987654321987654321, 5000
