@@ -141,11 +141,15 @@ __global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __re
                                                              uint32_t inner, size_t inner_stride, size_t n,
                                                              int montgomery, uint32_t c, uint32_t windows,
                                                              uint32_t nblk, uint32_t batch, size_t srs_n,
-                                                             size_t base_offset, uint32_t* __restrict__ table,
+                                                             size_t base_offset, uint32_t sub_bits,
+                                                             uint32_t* __restrict__ table,
                                                              uint32_t* __restrict__ tloc,
                                                              uint32_t* __restrict__ chunks) {
+  // sub_bits == 0: the tile is sorted by bucket.  sub_bits > 0 (two-level sort for wide windows): it is sorted by
+  // bin = bucket >> sub_bits only, and the low bucket bits ride in bits 24..30 of the entry for msm_sort_level2.
   extern __shared__ uint32_t lds[];
-  const uint32_t half = 1u << (c - 1);
+  const uint32_t half = (1u << (c - 1)) >> sub_bits;  // number of sort keys of this level
+  const uint32_t sub_mask = (1u << sub_bits) - 1;
   uint32_t* hist = lds;              // [half]   counts, then running cursors
   uint32_t* loff = lds + half;       // [half]   tile-local exclusive offsets
   uint32_t* buf = lds + 2 * half;    // [kDigitTile * windows] sorted entries
@@ -169,7 +173,7 @@ __global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __re
     uint32_t carry = 0;
     for (uint32_t w = 0; w < windows; w++) {
       uint32_t d = msm_digit(k, w, c, carry) & 0x7FFFFFFFu;
-      if (d) atomicAdd(&hist[d - 1], 1u);
+      if (d) atomicAdd(&hist[(d - 1) >> sub_bits], 1u);
     }
   }
   __syncthreads();
@@ -210,8 +214,9 @@ __global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __re
       uint32_t d = msm_digit(k, w, c, carry);
       uint32_t mag = d & 0x7FFFFFFFu;
       if (mag) {
-        uint32_t pos = atomicAdd(&hist[mag - 1], 1u);
-        buf[pos] = (uint32_t)((size_t)w * srs_n + base_offset + i) | (d & 0x80000000u);
+        uint32_t pos = atomicAdd(&hist[(mag - 1) >> sub_bits], 1u);
+        buf[pos] = (uint32_t)((size_t)w * srs_n + base_offset + i) | (((mag - 1) & sub_mask) << 24) |
+                   (d & 0x80000000u);
       }
     }
   }
@@ -255,6 +260,93 @@ __global__ __launch_bounds__(kThreads) void msm_scatter_runs(const uint32_t* __r
   const uint32_t* src = chunks + ((size_t)b * nblk + blk) * ((size_t)kDigitTile * windows) + tloc[row];
   uint32_t* dst = sorted + (size_t)b * per + off2[row];
   for (uint32_t e = 0; e < cnt; e++) dst[e] = src[e];
+}
+
+// ---- K4, second level of the two-level sort ---------------------------------------------------------------------
+// Wide windows (c = 15: 16384 buckets, 17 instead of 20 digits per 254-bit scalar) cut the mixed additions by a sixth,
+// but a tile of 1024 scalars then holds about one entry per bucket: a [bucket][tile] table would be six times larger
+// than the entries themselves.  So the tile sort and the run copy above work on bins of 2^sub_bits buckets, and this
+// kernel finishes the job: one workgroup per (batch entry, bin) histograms the low bucket bits of the bin's ~4000
+// entries in LDS, writes the per-bucket counts / offsets, and places every entry (a few KB per bin: the scattered
+// 4-byte stores stay in L2).  Up to kL2Stage entries are staged in LDS between the passes; the rest of an oversized
+// bin (skewed scalars) is simply fetched again, so any bin size works.
+constexpr uint32_t kL2Stage = 6144;  // entries of a bin staged in LDS between the two passes (24 KiB)
+constexpr uint32_t kL2MaxTiles = 72;  // tiles per batch entry the run table in LDS holds (covers n = 2^16 + 3)
+
+__global__ __launch_bounds__(kThreads) void msm_sort_level2(const uint32_t* __restrict__ chunks,
+                                                            const uint32_t* __restrict__ table,
+                                                            const uint32_t* __restrict__ tloc,
+                                                            const uint32_t* __restrict__ off2, size_t per,
+                                                            uint32_t bins, uint32_t nblk, uint32_t windows,
+                                                            uint32_t sub_bits, uint32_t* __restrict__ counts,
+                                                            uint32_t* __restrict__ offsets,
+                                                            uint32_t* __restrict__ sorted) {
+  // The bin's entries are read straight from the tile-sorted chunks (one run per tile, ~140 entries each): the
+  // run-copy pass of the one-level sort is not needed here.
+  __shared__ uint32_t hist[256];
+  __shared__ uint32_t start[256];
+  __shared__ uint32_t run_pre[kL2MaxTiles + 1];  // exclusive prefix of the run lengths
+  __shared__ uint32_t run_src[kL2MaxTiles];      // start of each run inside the chunk buffer of the batch entry
+  __shared__ uint32_t stage[kL2Stage];
+  const uint32_t b = blockIdx.y, bin = blockIdx.x;
+  const uint32_t nsub = 1u << sub_bits;
+  const size_t row0 = ((size_t)b * bins + bin) * nblk;
+  const size_t tile_words = (size_t)kDigitTile * windows;
+  const uint32_t* cbase = chunks + (size_t)b * nblk * tile_words;
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    for (uint32_t t = 0; t < nblk; t++) {
+      run_pre[t] = acc;
+      run_src[t] = (uint32_t)(t * tile_words) + tloc[row0 + t];
+      acc += table[row0 + t];
+    }
+    run_pre[nblk] = acc;
+  }
+  for (uint32_t j = threadIdx.x; j < nsub; j += kThreads) hist[j] = 0;
+  __syncthreads();
+  const uint32_t cnt = run_pre[nblk], off = off2[row0];
+  auto fetch = [&](uint32_t p) {  // p-th entry of the bin: binary search for its run
+    uint32_t lo = 0, hi = nblk;
+    while (hi - lo > 1) {
+      uint32_t mid = (lo + hi) >> 1;
+      if (run_pre[mid] <= p) lo = mid; else hi = mid;
+    }
+    return cbase[run_src[lo] + (p - run_pre[lo])];
+  };
+  for (uint32_t p = threadIdx.x; p < cnt; p += kThreads) {
+    const uint32_t v = fetch(p);
+    if (p < kL2Stage) stage[p] = v;
+    atomicAdd(&hist[(v >> 24) & (nsub - 1)], 1u);
+  }
+  __syncthreads();
+  if (threadIdx.x < 64) {  // exclusive scan of up to 256 counters by one wave
+    const uint32_t per_lane = (nsub + 63) / 64;
+    uint32_t j0 = threadIdx.x * per_lane, run = 0;
+    for (uint32_t t = 0; t < per_lane && j0 + t < nsub; t++) run += hist[j0 + t];
+    uint32_t inc = run;
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t o = __shfl_up(inc, d);
+      if ((int)threadIdx.x >= d) inc += o;
+    }
+    uint32_t pre = inc - run;
+    for (uint32_t t = 0; t < per_lane && j0 + t < nsub; t++) {
+      start[j0 + t] = pre;
+      pre += hist[j0 + t];
+    }
+  }
+  __syncthreads();
+  for (uint32_t j = threadIdx.x; j < nsub; j += kThreads) {
+    const size_t gb = ((size_t)b * bins + bin) * nsub + j;
+    counts[gb] = hist[j];
+    offsets[gb] = off + start[j];
+  }
+  __syncthreads();  // start[] now serves as the placement cursor
+  uint32_t* dst = sorted + (size_t)b * per + off;
+  for (uint32_t p = threadIdx.x; p < cnt; p += kThreads) {
+    const uint32_t v = p < kL2Stage ? stage[p] : fetch(p);
+    const uint32_t pos = atomicAdd(&start[(v >> 24) & (nsub - 1)], 1u);
+    dst[pos] = v & 0x80FFFFFFu;
+  }
 }
 
 // ---- K4: exclusive scan, one workgroup per batch entry ------------------------------------------
@@ -334,11 +426,21 @@ __global__ __launch_bounds__(1024) void msm_sort_items(const uint32_t* __restric
     atomicAdd(&hist[q], items - r);
   }
   __syncthreads();
+  // Even batch entries list their items longest first, odd ones shortest first.  Workgroups go to the 8 XCDs
+  // round-robin and a batch entry's item range is a whole number of workgroups at the prover's sizes, so with one
+  // direction only, XCD 0 would receive the longest workgroup of every entry and XCD 7 the shortest.
   if (threadIdx.x == 0) {
     uint32_t acc = 0;
-    for (int l = (int)kMaxItemLen; l >= 0; l--) {
-      cursor[l] = acc;
-      acc += hist[l];
+    if (b & 1) {
+      for (int l = 0; l <= (int)kMaxItemLen; l++) {
+        cursor[l] = acc;
+        acc += hist[l];
+      }
+    } else {
+      for (int l = (int)kMaxItemLen; l >= 0; l--) {
+        cursor[l] = acc;
+        acc += hist[l];
+      }
     }
   }
   __syncthreads();
@@ -579,6 +681,29 @@ struct WsLayout {
   size_t counts, offsets, keys, ranks, sorted, buckets, partial, item_off, item_base, totals, item_bucket, item_sub, item_pts,
       max_items, table, off2, tloc, chunks, nblk, total;
 };
+
+// which table / sort a launch uses
+constexpr uint32_t kWideCDefault = 15;  // window bits of the large-batch table
+uint32_t wide_c() {
+  static uint32_t v = [] {
+    const char* e = getenv("CAPGPU_MSM_WIDE_C");
+    int x = e ? atoi(e) : (int)kWideCDefault;
+    return (uint32_t)(x >= 14 && x <= 16 ? x : (int)kWideCDefault);
+  }();
+  return v;
+}
+constexpr uint32_t kSubBits = 7;  // buckets per level-1 bin = 128
+struct Plan {
+  uint32_t c, windows, sub_bits;
+  const g1_affine* ext;
+};
+Plan choose_plan(const MsmBases& bases, size_t n, uint32_t batch) {
+  // wide windows pay off once (a) the batch alone gives every CU work, so that the 4x larger bucket set costs two
+  // running-sum additions per bucket instead of a log-depth tree, and (b) buckets still hold several entries
+  if (bases.ext2 && batch >= 32 && n >= 4096 && n <= (size_t)kL2MaxTiles * kDigitTile)
+    return {bases.c2, bases.windows2, kSubBits, bases.ext2};
+  return {bases.c, bases.windows, 0, bases.ext};
+}
 // buckets per msm_reduce_segments thread: 16 keeps >= 64 segments per batch entry from c = 11 up
 uint32_t reduce_seg_len(uint32_t half) { return half >= 1024 ? 16u : (half >= 64 ? half / 64 : 1u); }
 // the running-sum reduction wants >= 16 Ki independent segments (64 waves per XCD); below that the log-depth path
@@ -588,17 +713,23 @@ bool use_segment_reduce(uint32_t half, uint32_t batch) {
 }
 // about 8 waves per SIMD worth of work items (256 CUs x 4 SIMDs x 64 lanes x 8) before items grow beyond the minimum
 uint32_t choose_item_len(size_t entries) {
+  static const size_t cap = [] {
+    const char* e = getenv("CAPGPU_MSM_ITEM_MAX");
+    int x = e ? atoi(e) : (int)kMaxItemLen;
+    return (size_t)(x >= 8 && x <= (int)kMaxItemLen ? x : (int)kMaxItemLen);
+  }();
   size_t l = entries / ((size_t)1 << 19);
-  return (uint32_t)std::min<size_t>(std::max<size_t>(l, kMinItemLen), kMaxItemLen);
+  return (uint32_t)std::min<size_t>(std::max<size_t>(l, std::min<size_t>(kMinItemLen, cap)), cap);
 }
-bool use_local_digits(uint32_t c, size_t n, uint32_t batch) {
-  size_t half = (size_t)1 << (c - 1);
+bool use_local_digits(uint32_t c, size_t n, uint32_t batch, uint32_t sub_bits = 0) {
+  size_t half = ((size_t)1 << (c - 1)) >> sub_bits;
   size_t nblk = (n + kDigitTile - 1) / kDigitTile;
   // LDS: 2 * half counters + kDigitTile * W entries (<= 160 KiB with c <= 14)
   return half <= 8192 && n > 0 && half * nblk * batch <= ((size_t)1 << 28);
 }
-WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t batch) {
+WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t batch, uint32_t sub_bits = 0) {
   WsLayout L{};
+  const size_t bins = ((size_t)1 << (c - 1)) >> sub_bits;  // sort keys of the tile-local level
   size_t half = (size_t)1 << (c - 1);
   size_t per = (size_t)windows * n;
   size_t seg_len = reduce_seg_len((uint32_t)half);
@@ -622,11 +753,12 @@ WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t batch) {
   L.item_bucket = o; o = align_up(o + sizeof(uint32_t) * L.max_items, 256);
   L.item_sub = o;    o = align_up(o + sizeof(uint32_t) * L.max_items, 256);
   L.item_pts = o;    o = align_up(o + sizeof(g1_xyzz) * L.max_items, 256);
-  L.nblk = use_local_digits(c, n, batch) ? (n + kDigitTile - 1) / kDigitTile : 0;
-  L.table = o;       o = align_up(o + sizeof(uint32_t) * half * L.nblk * batch, 256);
-  L.off2 = o;        o = align_up(o + sizeof(uint32_t) * half * L.nblk * batch, 256);
-  L.tloc = o;        o = align_up(o + sizeof(uint32_t) * half * L.nblk * batch, 256);
+  L.nblk = use_local_digits(c, n, batch, sub_bits) ? (n + kDigitTile - 1) / kDigitTile : 0;
+  L.table = o;       o = align_up(o + sizeof(uint32_t) * bins * L.nblk * batch, 256);
+  L.off2 = o;        o = align_up(o + sizeof(uint32_t) * bins * L.nblk * batch, 256);
+  L.tloc = o;        o = align_up(o + sizeof(uint32_t) * bins * L.nblk * batch, 256);
   L.chunks = o;      o = align_up(o + sizeof(uint32_t) * (size_t)kDigitTile * windows * L.nblk * batch, 256);
+
   L.total = o;
   return L;
 }
@@ -662,17 +794,32 @@ int msm_precompute(MsmBases* out, const g1_affine* d_bases, size_t n, uint32_t c
   size_t blocks = (n + kThreads - 1) / kThreads;
   launch("msm_precompute_kernel", msm_precompute_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, out->ext, d_bases, n, c,
                      out->windows);
+  // the wide-window table for large batches (prover-sized commit keys; entries carry 24-bit table indices)
+  const char* env = getenv("CAPGPU_MSM_WIDE");
+  const uint32_t kWideC = wide_c();
+  const uint32_t w2 = msm_num_windows(kWideC);
+  if (!getenv("CAPGPU_MSM_C") && !(env && atoi(env) == 0) && c < kWideC && n >= 4096 &&
+      (size_t)w2 * n < ((size_t)1 << 24)) {
+    e = hipMalloc(&out->ext2, sizeof(g1_affine) * n * w2);
+    if (e != hipSuccess) return (int)e;
+    out->c2 = kWideC;
+    out->windows2 = w2;
+    launch("msm_precompute_kernel", msm_precompute_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, out->ext2,
+           d_bases, n, kWideC, w2);
+  }
   return (int)hipGetLastError();
 }
 
 void msm_free_bases(MsmBases* b) {
   if (b->ext) hipFree(b->ext);
-  b->ext = nullptr;
+  if (b->ext2) hipFree(b->ext2);
+  b->ext = b->ext2 = nullptr;
   b->n = 0;
 }
 
 size_t msm_workspace_bytes(const MsmBases& bases, size_t n, uint32_t batch) {
-  return ws_layout(bases.c, bases.windows, n, batch).total;
+  Plan pl = choose_plan(bases, n, batch);
+  return ws_layout(pl.c, pl.windows, n, batch, pl.sub_bits).total;
 }
 
 int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t outer_stride, uint32_t inner,
@@ -681,9 +828,10 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
   if (inner == 0) inner = 1;
   if (batch == 0) return 0;
   if (offset + n > bases.n) return (int)hipErrorInvalidValue;
-  const uint32_t c = bases.c, W = bases.windows;
+  const Plan pl = choose_plan(bases, n, batch);
+  const uint32_t c = pl.c, W = pl.windows;
   const uint32_t half = 1u << (c - 1);
-  WsLayout L = ws_layout(c, W, n, batch);
+  WsLayout L = ws_layout(c, W, n, batch, pl.sub_bits);
   if (ws_bytes < L.total) return (int)hipErrorInvalidValue;
   char* base = reinterpret_cast<char*>(ws);
   uint32_t* counts = reinterpret_cast<uint32_t*>(base + L.counts);
@@ -702,7 +850,9 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
     uint32_t* off2 = reinterpret_cast<uint32_t*>(base + L.off2);
     uint32_t* tloc = reinterpret_cast<uint32_t*>(base + L.tloc);
     uint32_t* chunk_buf = reinterpret_cast<uint32_t*>(base + L.chunks);
-    size_t lds_bytes = sizeof(uint32_t) * (2 * (size_t)half + (size_t)kDigitTile * W);
+    const uint32_t bins = half >> pl.sub_bits;  // sort keys of the tile-local level (= buckets without a 2nd level)
+    const uint32_t total_bins = bins * batch;
+    size_t lds_bytes = sizeof(uint32_t) * (2 * (size_t)bins + (size_t)kDigitTile * W);
     static bool attr_set = false;
     if (!attr_set) {
       hipFuncSetAttribute(reinterpret_cast<const void*>(msm_digits_local), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -711,15 +861,22 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
     }
     launch("msm_digits_local", msm_digits_local, dim3(nblk * ((batch + 7) / 8) * 8), dim3(kDigitThreads), lds_bytes,
            stream, d_scalars, outer_stride, inner, inner_stride, n, montgomery, c, W, nblk, batch, bases.n, offset,
-           table, tloc, chunk_buf);
-    launch("msm_scan", msm_scan<0>, dim3(batch), dim3(1024), 0, stream, (const uint32_t*)table, off2, half * nblk,
+           pl.sub_bits, table, tloc, chunk_buf);
+    launch("msm_scan", msm_scan<0>, dim3(batch), dim3(1024), 0, stream, (const uint32_t*)table, off2, bins * nblk,
            (uint32_t*)nullptr, 0u);
-    launch("msm_bucket_ranges", msm_bucket_ranges, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0,
-           stream, (const uint32_t*)table, (const uint32_t*)off2, half, nblk, total_buckets, counts, offsets);
-    size_t rows = (size_t)total_buckets * nblk;
-    launch("msm_scatter", msm_scatter_runs, dim3((unsigned)((rows + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
-           (const uint32_t*)chunk_buf, (const uint32_t*)table, (const uint32_t*)tloc, (const uint32_t*)off2, per, half,
-           nblk, W, rows, sorted);
+    if (pl.sub_bits) {
+      // two-level sort: bins are finished per workgroup straight from the tile chunks
+      launch("msm_sort_level2", msm_sort_level2, dim3(bins, batch), dim3(kThreads), 0, stream,
+             (const uint32_t*)chunk_buf, (const uint32_t*)table, (const uint32_t*)tloc, (const uint32_t*)off2, per, bins,
+             nblk, W, pl.sub_bits, counts, offsets, sorted);
+    } else {
+      launch("msm_bucket_ranges", msm_bucket_ranges, dim3((total_bins + kThreads - 1) / kThreads), dim3(kThreads), 0,
+             stream, (const uint32_t*)table, (const uint32_t*)off2, bins, nblk, total_bins, counts, offsets);
+      size_t rows = (size_t)total_bins * nblk;
+      launch("msm_scatter", msm_scatter_runs, dim3((unsigned)((rows + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+             stream, (const uint32_t*)chunk_buf, (const uint32_t*)table, (const uint32_t*)tloc, (const uint32_t*)off2,
+             per, bins, nblk, W, rows, sorted);
+    }
   } else {
     hipError_t e = hipMemsetAsync(counts, 0, sizeof(uint32_t) * (size_t)half * batch, stream);
     if (e != hipSuccess) return (int)e;
@@ -750,7 +907,7 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
          (const uint32_t*)item_base, half, item_len, item_bucket, item_sub);
   if (L.max_items > 0) {
     launch("msm_accumulate", msm_accumulate, dim3((unsigned)((L.max_items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-           stream, bases.ext, (const uint32_t*)sorted, (const uint32_t*)counts, (const uint32_t*)offsets,
+           stream, pl.ext, (const uint32_t*)sorted, (const uint32_t*)counts, (const uint32_t*)offsets,
            (const uint32_t*)item_off, (const uint32_t*)item_base, (const uint32_t*)item_bucket,
            (const uint32_t*)item_sub, per, half, batch, item_len, item_pts);
   }

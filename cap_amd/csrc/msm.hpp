@@ -30,6 +30,10 @@ struct MsmBases {
   uint32_t c = 0;            // window bits
   uint32_t windows = 0;      // W
   g1_affine* ext = nullptr;  // [W][n]: ext[w*n + i] = 2^(c*w) * P_i  (w = 0 is the input itself)
+  // Second table with wider windows for large batches (see msm.hip, "two-level sort"): fewer, larger digits mean
+  // fewer mixed additions per scalar; only worth it when the batch alone fills the chip.  Null when not built.
+  uint32_t c2 = 0, windows2 = 0;
+  g1_affine* ext2 = nullptr;
 };
 
 struct MsmWorkspace {
