@@ -501,7 +501,8 @@ __global__ __launch_bounds__(kThreads) void msm_accumulate(const g1_affine* __re
                                                            const uint32_t* __restrict__ item_bucket,
                                                            const uint32_t* __restrict__ item_sub, size_t per,
                                                            uint32_t half, uint32_t batch, uint32_t item_len,
-                                                           g1_xyzz* __restrict__ item_pts) {
+                                                           g1_xyzz* __restrict__ item_pts,
+                                                           g1_xyzz* __restrict__ buckets) {
   uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
   if (it >= item_base[batch]) return;
   const uint32_t gb = item_bucket[it], j = item_sub[it];
@@ -517,7 +518,9 @@ __global__ __launch_bounds__(kThreads) void msm_accumulate(const g1_affine* __re
     g1a p = G1L::load(ext[v & 0x7FFFFFFFu]);
     acc = G1L::add_mixed(acc, p, (v >> 31) != 0);
   }
-  item_pts[item_base[b] + item_off[gb] + j] = G1L::store(acc);
+  // a bucket made of a single item is final: it goes straight to the bucket array and msm_combine skips it
+  if (items == 1) buckets[gb] = G1L::store(acc);
+  else item_pts[item_base[b] + item_off[gb] + j] = G1L::store(acc);
 }
 
 // ---- K6: bucket reduction by running sums ------------------------------------------------------------------
@@ -609,6 +612,7 @@ __global__ __launch_bounds__(kThreads) void msm_combine(const g1_xyzz* __restric
   uint32_t gb = blockIdx.x * blockDim.x + threadIdx.x;
   if (gb >= total_buckets) return;
   uint32_t items = (counts[gb] + item_len - 1) / item_len;
+  if (items == 1) return;  // written by msm_accumulate
   uint32_t first = item_base[gb / half] + item_off[gb];
   g1x acc = G1L::inf();
   if (items) {
@@ -704,8 +708,11 @@ Plan choose_plan(const MsmBases& bases, size_t n, uint32_t batch) {
     return {bases.c2, bases.windows2, kSubBits, bases.ext2};
   return {bases.c, bases.windows, 0, bases.ext};
 }
-// buckets per msm_reduce_segments thread: 16 keeps >= 64 segments per batch entry from c = 11 up
-uint32_t reduce_seg_len(uint32_t half) { return half >= 1024 ? 16u : (half >= 64 ? half / 64 : 1u); }
+// buckets per msm_reduce_segments thread
+uint32_t reduce_seg_len(uint32_t half) {
+  if (half >= 16384) return 64;  // wide windows: 256 segments per entry keep msm_reduce_final at 4 segments per lane
+  return half >= 1024 ? 16u : (half >= 64 ? half / 64 : 1u);
+}
 // the running-sum reduction wants >= 16 Ki independent segments (64 waves per XCD); below that the log-depth path
 bool use_segment_reduce(uint32_t half, uint32_t batch) {
   uint32_t seg_len = reduce_seg_len(half);
@@ -909,7 +916,8 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
     launch("msm_accumulate", msm_accumulate, dim3((unsigned)((L.max_items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
            stream, pl.ext, (const uint32_t*)sorted, (const uint32_t*)counts, (const uint32_t*)offsets,
            (const uint32_t*)item_off, (const uint32_t*)item_base, (const uint32_t*)item_bucket,
-           (const uint32_t*)item_sub, per, half, batch, item_len, item_pts);
+           (const uint32_t*)item_sub, per, half, batch, item_len, item_pts,
+           reinterpret_cast<g1_xyzz*>(base + L.buckets));
   }
   g1_xyzz* buckets = reinterpret_cast<g1_xyzz*>(base + L.buckets);
   launch("msm_combine", msm_combine, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0, stream,
