@@ -59,7 +59,11 @@ __device__ __forceinline__ uint32_t bitrev32(uint32_t x, uint32_t bits) { return
 __device__ __forceinline__ void lds_ntt(fl* sh, const fl* __restrict__ tw_small, uint32_t log_len, uint32_t log_c) {
   const uint32_t half_tile = 1u << (log_len + log_c - 1);
   const uint32_t cmask = (1u << log_c) - 1;
-  for (uint32_t s = 0; s < log_len; s++) {
+  // the first three (or four) stages as single radix-2 stages: they carry the zero-padding shortcut; the remaining
+  // even number of stages goes two at a time below
+  uint32_t r2 = log_len < 3 ? log_len : (((log_len - 3) & 1) ? 4u : 3u);
+  if (r2 > log_len) r2 = log_len;
+  for (uint32_t s = 0; s < r2; s++) {
     const uint32_t half = 1u << s;
     for (uint32_t b = threadIdx.x; b < half_tile; b += kThreads) {
       uint32_t c = b & cmask;
@@ -83,6 +87,35 @@ __device__ __forceinline__ void lds_ntt(fl* sh, const fl* __restrict__ tw_small,
       fl t = e ? Fr29::mul(v, tw_small[e]) : Fr29::weak_reduce(v);
       sh[i0] = Fr29::normalize(Fr29::add(u, t));
       sh[i1] = Fr29::sub2p(u, t);
+    }
+    __syncthreads();
+  }
+  // radix-4: stages s and s + 1 on four rows j, j + h, j + 2h, j + 3h held in registers - the same four
+  // multiplications as two radix-2 stages, half the LDS traffic, index arithmetic and barriers
+  const uint32_t quarter_tile = half_tile >> 1;
+  for (uint32_t s = r2; s + 1 < log_len; s += 2) {
+    const uint32_t h = 1u << s;
+    const uint32_t step = h << log_c;
+    for (uint32_t g = threadIdx.x; g < quarter_tile; g += kThreads) {
+      const uint32_t c = g & cmask;
+      const uint32_t gg = g >> log_c;
+      const uint32_t pos = gg & (h - 1);
+      const uint32_t j = ((gg >> s) << (s + 2)) + pos;
+      const uint32_t i0 = (j << log_c) + c, i1 = i0 + step, i2 = i1 + step, i3 = i2 + step;
+      fl a = sh[i0], b = sh[i1], cc = sh[i2], d = sh[i3];
+      const fl w1 = tw_small[pos << (log_len - 1 - s)];  // omega^0 = 1 is multiplied like any other twiddle
+      fl t = Fr29::mul(b, w1);
+      fl a1 = Fr29::normalize(Fr29::add(a, t));
+      fl b1 = Fr29::sub2p(a, t);
+      t = Fr29::mul(d, w1);
+      fl c1 = Fr29::normalize(Fr29::add(cc, t));
+      fl d1 = Fr29::sub2p(cc, t);
+      t = Fr29::mul(c1, tw_small[pos << (log_len - 2 - s)]);
+      sh[i0] = Fr29::normalize(Fr29::add(a1, t));
+      sh[i2] = Fr29::sub2p(a1, t);
+      t = Fr29::mul(d1, tw_small[(pos + h) << (log_len - 2 - s)]);
+      sh[i1] = Fr29::normalize(Fr29::add(b1, t));
+      sh[i3] = Fr29::sub2p(b1, t);
     }
     __syncthreads();
   }
