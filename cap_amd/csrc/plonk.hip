@@ -18,6 +18,9 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 #include <vector>
 
@@ -59,26 +62,91 @@ namespace {
 // The per-proof host work between rounds (Keccak transcript, a handful of field operations) is independent across
 // the proofs of a batch; the reference runs it under rayon (src/utils/params_builder.rs:194-226).  A serial loop
 // leaves the GPU idle for ~20 % of a 64-proof step.
-template <class F>
-void parallel_for(uint32_t count, F&& fn) {
-  static const unsigned hw = [] {
+// A persistent pool (workers are created once and parked on a condition variable): spawning 31 threads per call cost
+// about a millisecond, seven times per step, with the GPU idle.
+class HostPool {
+ public:
+  static HostPool& get() {
+    static HostPool p;
+    return p;
+  }
+  unsigned size() const { return nt_; }
+  // runs job(i) for i in [0, count); the caller takes part
+  void run(uint32_t count, const std::function<void(uint32_t)>& job) {
+    std::lock_guard<std::mutex> serial(run_mu_);  // one parallel region at a time
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      job_ = &job;
+      count_ = count;
+      next_.store(0, std::memory_order_relaxed);
+      pending_ = (unsigned)workers_.size();
+      epoch_++;
+    }
+    cv_.notify_all();
+    drain();
+    std::unique_lock<std::mutex> lk(mu_);
+    done_cv_.wait(lk, [&] { return pending_ == 0; });
+    job_ = nullptr;
+  }
+
+ private:
+  HostPool() {
     const char* e = getenv("CAPGPU_HOST_THREADS");
     unsigned v = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
-    return std::min(std::max(v, 1u), 32u);
-  }();
-  const unsigned nt = std::min<unsigned>(hw, count);
-  if (nt <= 1) {
+    nt_ = std::min(std::max(v, 1u), 32u);
+    for (unsigned t = 1; t < nt_; t++) workers_.emplace_back([this] { loop(); });
+  }
+  ~HostPool() {
+    {
+      std::lock_guard<std::mutex> lk(mu_);
+      stop_ = true;
+      epoch_++;
+    }
+    cv_.notify_all();
+    for (auto& w : workers_) w.join();
+  }
+  void drain() {
+    for (;;) {
+      uint32_t i = next_.fetch_add(1, std::memory_order_relaxed);
+      if (i >= count_) break;
+      (*job_)(i);
+    }
+  }
+  void loop() {
+    uint64_t seen = 0;
+    for (;;) {
+      {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_.wait(lk, [&] { return epoch_ != seen; });
+        seen = epoch_;
+        if (stop_) return;
+      }
+      drain();
+      std::lock_guard<std::mutex> lk(mu_);
+      if (--pending_ == 0) done_cv_.notify_one();
+    }
+  }
+  unsigned nt_ = 1;
+  std::vector<std::thread> workers_;
+  std::mutex mu_, run_mu_;
+  std::condition_variable cv_, done_cv_;
+  const std::function<void(uint32_t)>* job_ = nullptr;
+  uint32_t count_ = 0;
+  std::atomic<uint32_t> next_{0};
+  unsigned pending_ = 0;
+  uint64_t epoch_ = 0;
+  bool stop_ = false;
+};
+
+template <class F>
+void parallel_for(uint32_t count, F&& fn) {
+  HostPool& pool = HostPool::get();
+  if (pool.size() <= 1 || count <= 1) {
     for (uint32_t i = 0; i < count; i++) fn(i);
     return;
   }
-  auto work = [&](unsigned t) {
-    for (uint32_t i = t; i < count; i += nt) fn(i);
-  };
-  std::vector<std::thread> th;
-  th.reserve(nt - 1);
-  for (unsigned t = 1; t < nt; t++) th.emplace_back(work, t);
-  work(0);
-  for (auto& x : th) x.join();
+  std::function<void(uint32_t)> job = [&](uint32_t i) { fn(i); };
+  pool.run(count, job);
 }
 
 // ---- launch helpers -----------------------------------------------------------------------------------------
