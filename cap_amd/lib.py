@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "libcapgpu.so")
+_SO = os.environ.get("CAPGPU_LIBRARY") or os.path.join(_HERE, "libcapgpu.so")  # override: A/B builds in tools/
 _lib = None
 
 NUM_WIRE_TYPES = 5
