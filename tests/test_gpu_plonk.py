@@ -81,6 +81,27 @@ def test_batch_vs_c_oracle(cg, tau, log_n, nin, P):
     cg.srs_free(h)
 
 
+def test_batch_large_enough_for_the_wide_window_msm(cg, tau):
+    """With P = 8 proofs of n = 2^12 the 5P-wide commitment launches (wires, quotient splits) take the c = 15 table and
+    the two-level sort, while the P- and 2P-wide ones (z, opening proofs) stay on c = 13: both MSM plans inside one
+    proof, every proof bit-exact vs the CPU restatement."""
+    log_n, nin, P = 12, 9, 8
+    sc = bu.synthetic_circuit(log_n, nin, seed=77)
+    h, pkh, vk = gpu_key(cg, tau, sc)
+    key = cr.PlonkKey(cg.srs_download(h, 0, sc.n + 3), sc.n, nin, sc.selectors_mont(), sc.sigma_mont())
+    ws, ps, bls = [], [], []
+    for p in range(P):
+        w, pubs = sc.witness(300 + p)
+        ws.append(sc.wires_mont(w)); ps.append(pubs_arr(pubs)); bls.append(bu.to_mont_array(bu.blinders(400 + p)))
+    proofs = cg.plonk_prove_batch(pkh, np.stack(ws), np.stack(ps), np.stack(bls), b"wide", P)
+    for p in range(P):
+        rc, comms, evals = key.prove(ws[p], ps[p], bls[p], b"wide")
+        assert rc == 0
+        assert H.proof_points(proofs[p]) == H.cref_proof_points(comms, evals), f"proof {p}"
+    cg.plonk_free_key(pkh)
+    cg.srs_free(h)
+
+
 def test_transfer_note_shape_full_size(cg, tau):
     """BASELINE config 3: the full 2-in/2-out transfer-note proof (n = 2^15, 27 public inputs, 13 MSM of
     ~n+2 points, 7 iNTT(n), 26 coset (i)NTT(8n)) on one MI355X, bit-exact vs the CPU restatement."""
