@@ -207,7 +207,7 @@ struct Carver {
 };
 
 struct BatchWs {
-  fe *wpoly, *pi, *num, *den, *pre, *sfx, *scan_tot, *inv_total, *zpoly, *coset, *pkc, *t, *pows, *pw, *batchpoly,
+  fe *wpoly, *pi, *num, *den, *pre, *sfx, *scan_tot, *inv_total, *zpoly, *coset, *pkc, *t, *pows, *pows_small, *pw, *batchpoly,
       *hbuf, *quot, *evals, *eval_partial, *d_pub, *d_blind;
   Chal* chal;
   Chal* chal29;  // the same challenges in the internal form
@@ -238,6 +238,7 @@ BatchWs carve(void* base, const ProvingKey& K, uint32_t P) {
   w.t = c.take<fe>((size_t)P * m);
   w.pows = c.take<fe>((size_t)P * 4 * ps);
   w.pw = c.take<fe>((size_t)P * 4 * 24);
+  w.pows_small = c.take<fe>((size_t)P * 4 * (kPowLow + (ps + kPowLow - 1) / kPowLow));
   w.batchpoly = c.take<fe>((size_t)P * 2 * ps);
   w.hbuf = c.take<fe>((size_t)P * 2 * ps);
   w.quot = c.take<fe>((size_t)P * 2 * ps);
@@ -421,7 +422,13 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
 
   // ---- round 4: evaluations -------------------------------------------------------------------------------
   CAP_HIP(hipMemcpyAsync(w.pw, pw.data(), sizeof(fe) * pw.size(), hipMemcpyHostToDevice, s));
-  launch("k_powers", k_powers, dim3(cdiv(ps, kThreads), P * 4), dim3(kThreads), 0, s, w.pows, ps, ps, (const fe*)w.pw);
+  {
+    const uint32_t small_len = kPowLow + cdiv(ps, kPowLow);
+    launch("k_powers_small", k_powers_small, dim3(cdiv(small_len, kThreads), P * 4), dim3(kThreads), 0, s, w.pows_small,
+           small_len, (const fe*)w.pw);
+    launch("k_powers", k_powers, dim3(cdiv(ps, kThreads), P * 4), dim3(kThreads), 0, s, w.pows, ps, ps,
+           (const fe*)w.pows_small, small_len);
+  }
   std::vector<EvalDesc> ed((size_t)P * 10);
   for (uint32_t p = 0; p < P; p++) {
     const fe* pz = w.pows + ((size_t)p * 4 + 0) * ps;

@@ -320,22 +320,34 @@ __global__ __launch_bounds__(kThreads) void k_check_degree(const fe* __restrict_
 }
 
 // ---- round 4/5 helpers ---------------------------------------------------------------------------------
-// tables[q][k] = base_q^k, k < len;  pw[q][b] = base_q^(2^b), b < 24
-__global__ __launch_bounds__(kThreads) void k_powers(fe* __restrict__ tables, size_t stride, size_t len,
-                                                     const fe* __restrict__ pw) {
-  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= len) return;
+// tables[q][k] = base_q^k, k < len;  pw[q][b] = base_q^(2^b), b < 24.  Two steps: a small table per base with
+// base^i (i < 256) followed by base^(256 j), each entry by the binary method, then one multiplication per output.
+constexpr uint32_t kPowLow = 256;
+__global__ __launch_bounds__(kThreads) void k_powers_small(fe* __restrict__ small, uint32_t small_len,
+                                                           const fe* __restrict__ pw) {
+  uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= small_len) return;
   uint32_t q = blockIdx.y;
   const fe* b = pw + (size_t)q * 24;
+  const uint32_t e = i < kPowLow ? i : (i - kPowLow) * kPowLow;
   fe r = Fr::one();
   bool started = false;
-  for (int i = 0; (e >> i) != 0; i++) {
-    if ((e >> i) & 1) {
-      r = started ? Fr::mul(r, b[i]) : b[i];
+  for (int k = 0; (e >> k) != 0; k++) {
+    if ((e >> k) & 1) {
+      r = started ? Fr::mul(r, b[k]) : b[k];
       started = true;
     }
   }
-  tables[(size_t)q * stride + e] = r;
+  small[(size_t)q * small_len + i] = r;
+}
+__global__ __launch_bounds__(kThreads) void k_powers(fe* __restrict__ tables, size_t stride, size_t len,
+                                                     const fe* __restrict__ small, uint32_t small_len) {
+  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= len) return;
+  uint32_t q = blockIdx.y;
+  const fe* t = small + (size_t)q * small_len;
+  // blockDim.x == kPowLow: the high factor is the same for the whole workgroup
+  tables[(size_t)q * stride + e] = Fr::mul(t[e & (kPowLow - 1)], t[kPowLow + (e >> 8)]);
 }
 
 struct EvalDesc {
