@@ -35,7 +35,12 @@ uint32_t max_tile_log() {
 struct PassParams {
   const fe* in;
   fe* out;
-  size_t batch_stride;       // elements between consecutive arrays of the batch
+  // array q of the batch starts at (q / group) * outer + (q % group) * inner elements; input elements at or beyond
+  // in_len read as zero (a polynomial shorter than the transform: no padded copy has to exist in memory)
+  size_t in_outer, in_inner, in_len;
+  uint32_t in_group;
+  size_t out_outer, out_inner;
+  uint32_t out_group;
   const fl* tw_small;        // omega_len^i, i < len/2, unpacked limbs
   const fe* tw_full;         // omega_N^e, e < N (col pass twiddles); may be null for row pass
   const fe* pre_scale;       // indexed by global input index, or null
@@ -130,18 +135,24 @@ __global__ __launch_bounds__(kThreads) void ntt_col_pass(PassParams p) {
   const uint32_t t = blockIdx.x;
   const size_t seg = t >> tiles_per_seg_log;
   const uint32_t col0 = (t & ((1u << tiles_per_seg_log) - 1)) << p.log_c;
-  const fe* in = p.in + (size_t)blockIdx.y * p.batch_stride;
-  fe* out = p.out + (size_t)blockIdx.y * p.batch_stride;
+  const fe* in = p.in + (size_t)(blockIdx.y / p.in_group) * p.in_outer + (size_t)(blockIdx.y % p.in_group) * p.in_inner;
+  fe* out = p.out + (size_t)(blockIdx.y / p.out_group) * p.out_outer + (size_t)(blockIdx.y % p.out_group) * p.out_inner;
   const size_t base = (seg << p.log_m) + col0;
   const uint32_t tile = 1u << (p.log_len + p.log_c);
   const uint32_t cmask = (1u << p.log_c) - 1;
   for (uint32_t e = threadIdx.x; e < tile; e += kThreads) {
     uint32_t c = e & cmask, j = e >> p.log_c;
     size_t g = base + ((size_t)j << log_s) + c;
-    const fe raw = in[g];
+    fe raw;
     uint32_t any = 0;
+    if (g < p.in_len) {
+      raw = in[g];
 #pragma unroll
-    for (int k = 0; k < 8; k++) any |= raw.v[k];
+      for (int k = 0; k < 8; k++) any |= raw.v[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) raw.v[k] = 0;
+    }
     fl v = Fr29::load(raw);
     if (p.pre_scale && any) v = Fr29::mul(v, Fr29::load(p.pre_scale[g]));  // zero padding needs no coset scaling
     sh[(bitrev32(j, p.log_len) << p.log_c) + c] = v;
@@ -165,18 +176,24 @@ __global__ __launch_bounds__(kThreads) void ntt_row_pass(PassParams p) {
   const uint32_t t = blockIdx.x;
   const uint32_t k2 = t & ((1u << p.log_n2) - 1);
   const uint32_t r0 = (t >> p.log_n2) << p.log_c;
-  const fe* in = p.in + (size_t)blockIdx.y * p.batch_stride;
-  fe* out = p.out + (size_t)blockIdx.y * p.batch_stride;
+  const fe* in = p.in + (size_t)(blockIdx.y / p.in_group) * p.in_outer + (size_t)(blockIdx.y % p.in_group) * p.in_inner;
+  fe* out = p.out + (size_t)(blockIdx.y / p.out_group) * p.out_outer + (size_t)(blockIdx.y % p.out_group) * p.out_inner;
   const uint32_t tile = 1u << (p.log_len + p.log_c);
   const uint32_t lmask = (1u << p.log_len) - 1;
   const uint32_t cmask = (1u << p.log_c) - 1;
   for (uint32_t e = threadIdx.x; e < tile; e += kThreads) {
     uint32_t j = e & lmask, c = e >> p.log_len;
     size_t g = ((((size_t)(r0 + c) << p.log_n2) + k2) << p.log_len) + j;
-    const fe raw = in[g];
+    fe raw;
     uint32_t any = 0;
+    if (g < p.in_len) {
+      raw = in[g];
 #pragma unroll
-    for (int k = 0; k < 8; k++) any |= raw.v[k];
+      for (int k = 0; k < 8; k++) any |= raw.v[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 8; k++) raw.v[k] = 0;
+    }
     fl v = Fr29::load(raw);
     if (p.pre_scale && any) v = Fr29::mul(v, Fr29::load(p.pre_scale[g]));  // zero padding needs no coset scaling
     sh[(bitrev32(j, p.log_len) << p.log_c) + c] = v;
@@ -362,7 +379,7 @@ void ntt_table_to_internal(fe* out, const fe* in, size_t n, hipStream_t stream) 
 }
 
 int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scratch, size_t stride_elems,
-            uint32_t count, int dir, int coset, hipStream_t stream, int io_form) {
+            uint32_t count, int dir, int coset, hipStream_t stream, int io_form, const NttIo* io) {
   if ((io_form == kNttOutInternal && (dir || !coset)) || (io_form == kNttInInternal && (!dir || !coset)))
     return (int)hipErrorInvalidValue;
   const uint32_t log_n = dom.log_n;
@@ -392,14 +409,34 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
   const fe* tw_full = dir ? dom.tw29_inv : dom.tw29_fwd;
 
   PassParams p{};
-  p.batch_stride = stride_elems;
+  // first-pass input and last-pass output addressing; the passes in between go through the scratch buffer
+  const size_t scratch_stride = io ? ((size_t)1 << log_n) : stride_elems;
+  struct Addr {
+    size_t outer, inner;
+    uint32_t group;
+  };
+  const Addr a_src = io ? Addr{io->src_outer, io->src_inner, io->src_group ? io->src_group : 1u} : Addr{stride_elems, 0, 1};
+  const Addr a_dst = io ? Addr{io->dst_outer, io->dst_inner, io->dst_group ? io->dst_group : 1u} : Addr{stride_elems, 0, 1};
+  const Addr a_tmp = Addr{scratch_stride, 0, 1};
+  const size_t src_len = io ? io->src_len : ~(size_t)0;
+  auto set_in = [&](const Addr& a, size_t len) {
+    p.in_outer = a.outer;
+    p.in_inner = a.inner;
+    p.in_group = a.group;
+    p.in_len = len;
+  };
+  auto set_out = [&](const Addr& a) {
+    p.out_outer = a.outer;
+    p.out_inner = a.inner;
+    p.out_group = a.group;
+  };
   p.log_n = log_n;
   p.tw_full = tw_full;
   p.use_post_scalar = 0;
 
   const fe* pre = (!dir && coset) ? (io_form == kNttOutInternal ? dom.coset29_fwd_x32 : dom.coset29_fwd) : nullptr;
   bool first = true;
-  const fe* cur_in = data;
+  const fe* cur_in = io ? io->src : data;
   // column passes
   uint32_t log_m = log_n;
   for (int d = 0; d < passes - 1; d++) {
@@ -410,6 +447,8 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
     if (log_c > 4) log_c = 4;
     p.in = cur_in;
     p.out = scratch;
+    set_in(first ? a_src : a_tmp, first ? src_len : ~(size_t)0);
+    set_out(a_tmp);
     p.tw_small = reinterpret_cast<const fl*>(tws[log_len]);
     p.pre_scale = first ? pre : nullptr;
     p.post_scale = nullptr;
@@ -433,6 +472,8 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
     if (log_c > 4) log_c = 4;
     p.in = cur_in;
     p.out = data;
+    set_in(first ? a_src : a_tmp, first ? src_len : ~(size_t)0);
+    set_out(a_dst);
     p.tw_small = reinterpret_cast<const fl*>(tws[log_len]);
     p.pre_scale = first ? pre : nullptr;
     p.post_scale = (dir && coset) ? (io_form == kNttInInternal ? dom.coset_inv : dom.coset29_inv) : nullptr;

@@ -61,8 +61,19 @@ fe ntt_root_of_unity(uint32_t log_n);
 // In-place (from the caller's view) batched transform of `count` arrays of 2^log_n
 // elements, array b at data + b * stride_elems.  `scratch` must hold count * 2^log_n
 // elements.  dir: 0 forward, 1 inverse.  coset: 0/1.
+// Optional out-of-place addressing: the transform reads array q of the batch from
+// src + (q / src_group) * src_outer + (q % src_group) * src_inner, treating elements at or beyond src_len as zero (a
+// polynomial shorter than the domain needs no zero-padded copy), and writes it to
+// data + (q / dst_group) * dst_outer + (q % dst_group) * dst_inner.  `scratch` then holds count * 2^log_n elements.
+struct NttIo {
+  const fe* src;
+  size_t src_outer, src_inner, src_len;
+  uint32_t src_group;
+  size_t dst_outer, dst_inner;
+  uint32_t dst_group;
+};
 int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scratch, size_t stride_elems,
-            uint32_t count, int dir, int coset, hipStream_t stream, int io_form = 0);
+            uint32_t count, int dir, int coset, hipStream_t stream, int io_form = 0, const NttIo* io = nullptr);
 
 // out[i] = internal Montgomery form (x * 2^261, canonical) of the arkworks-form value in[i]
 void ntt_table_to_internal(fe* out, const fe* in, size_t n, hipStream_t stream);

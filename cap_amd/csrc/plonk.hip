@@ -183,6 +183,20 @@ int run_ntt(hipStream_t s, uint32_t log_n, fe* data, size_t stride, uint32_t cou
   return CAPGPU_OK;
 }
 
+// out-of-place transform: short inputs are zero-extended on the fly (no padded copy in memory), see NttIo
+int run_ntt_io(hipStream_t s, uint32_t log_n, fe* data, uint32_t count, int dir, int coset, int io_form,
+               const NttIo& io) {
+  Context& c = ctx();
+  const NttDomain* dom = nullptr;
+  int rc = get_domain(log_n, &dom);
+  if (rc) return rc;
+  rc = scratch_reserve(c.ntt_scratch, (sizeof(fe) << log_n) * count);
+  if (rc) return rc;
+  rc = ntt_run(*dom, c.small, data, (fe*)c.ntt_scratch.p, (size_t)1 << log_n, count, dir, coset, s, io_form, &io);
+  if (rc) return hip_fail((hipError_t)rc, "ntt_run");
+  return CAPGPU_OK;
+}
+
 int run_msm(hipStream_t s, const MsmBases& B, const fe* scalars, size_t outer_stride, uint32_t inner,
             size_t inner_stride, size_t n, uint32_t batch, g1_jac* d_out) {
   Context& c = ctx();
@@ -258,8 +272,7 @@ BatchWs carve(void* base, const ProvingKey& K, uint32_t P) {
 
 // the 18 fixed polynomials -> coset evaluations on the 8n domain
 int compute_pk_coset(hipStream_t s, const ProvingKey& K, fe* dst) {
-  pad_copy(s, dst, K.m, 0, K.coef, K.ps, 0, 1, 18, K.n, K.m);
-  return run_ntt(s, K.log_m, dst, K.m, 18, 0, 1, kNttOutInternal);
+  return run_ntt_io(s, K.log_m, dst, 18, 0, 1, kNttOutInternal, NttIo{K.coef, K.ps, 0, K.n, 1, K.m, 0, 1});
 }
 
 int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pub_inputs, size_t num_inputs,
@@ -368,10 +381,16 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
   CAP_HIP(hipMemcpyAsync(w.chal29, chal29.data(), sizeof(Chal) * P, hipMemcpyHostToDevice, s));
 
   // ---- round 3: quotient polynomial ---------------------------------------------------------------------
-  pad_copy(s, w.coset, 7 * m, m, w.wpoly, NW * ps, ps, NW, P * NW, n + 2, m);
-  pad_copy(s, w.coset + 5 * m, 7 * m, 0, w.zpoly, ps, 0, 1, P, n + 3, m);
-  pad_copy(s, w.coset + 6 * m, 7 * m, 0, w.pi, n, 0, 1, P, n, m);
-  if ((rc = run_ntt(s, K.log_m, w.coset, m, P * 7, 0, 1, kNttOutInternal))) return rc;
+  // coset evaluations of the wire, z and public-input polynomials on the 8n domain, straight from their coefficient
+  // arrays (the transform zero-extends them; a padded copy would be 7 x 8n x 32 B per proof written and read back)
+  if ((rc = run_ntt_io(s, K.log_m, w.coset, P * NW, 0, 1, kNttOutInternal,
+                       NttIo{w.wpoly, NW * ps, ps, n + 2, NW, 7 * m, m, NW})))
+    return rc;
+  if ((rc = run_ntt_io(s, K.log_m, w.coset + 5 * m, P, 0, 1, kNttOutInternal,
+                       NttIo{w.zpoly, ps, 0, n + 3, 1, 7 * m, 0, 1})))
+    return rc;
+  if ((rc = run_ntt_io(s, K.log_m, w.coset + 6 * m, P, 0, 1, kNttOutInternal, NttIo{w.pi, n, 0, n, 1, 7 * m, 0, 1})))
+    return rc;
   const fe* pkc = K.pk_coset;
   if (K.recompute) {
     // reference schedule: the 18 selector / sigma polynomials are re-transformed for every proof
