@@ -275,6 +275,17 @@ def main():
                     "traffic": traffic_tab.get(dom) if (P == TRAFFIC_BATCH and log_n == 15 and args.workload == "transfer") else None,
                     "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
                     "share_of_kernel_time": kern_ms[dom] / sum(kern_ms.values())}
+    # SURVEY 8d asks for an integer-ALU fraction beside the HBM one: the path is multiplication-bound.  Mixed additions of
+    # a step = non-zero digits minus one per non-empty bucket (the first entry of a bucket is a copy); one mixed
+    # addition = 8 products + 2 squarings + 9 reductions ~ 10.5 Montgomery multiplications of the lazy 29-bit field,
+    # whose measured ceiling in isolation is 158 G/s (tools/ubench_mlo.hip, profiles/ubench_mlo_r01.txt).
+    alu = None
+    if dom == "msm_accumulate" and args.workload == "transfer" and P >= 32 and n >= 4096:
+        digits, buckets = 17, 1 << 14                       # c = 15 table, 254-bit scalars
+        adds_per_step = P * (13 * ((n + 2) * digits - buckets) + (n + 3 - (n + 2)) * digits)
+        mul_eq = adds_per_step * args.steps * 10.5 / (kern_ms[dom] * 1e-3) / 1e9
+        alu = {"kernel": dom, "achieved": mul_eq, "peak": 158.0, "unit": "G field multiplications/s (equivalent)",
+               "frac": mul_eq / 158.0, "mixed_adds_per_step": adds_per_step}
     top = sorted(kern_ms.items(), key=lambda kv: -kv[1])[:8]
     whole_gbps = ab["total_bytes"] * total_proofs / dt / 1e9
 
@@ -290,6 +301,7 @@ def main():
                    "pk_coset_cache": "18 fixed selector/sigma coset NTTs cached in the proving key (see "
                                      "reference_schedule for the per-proof recompute number)"},
         "roofline": roofline,
+        "alu_roofline": alu,
         "proof_hbm_roofline": {"algorithmic_bytes_per_proof": ab["total_bytes"], "achieved_GBps": whole_gbps,
                                "frac_of_peak": whole_gbps / HBM_PEAK_GBPS},
         "top_kernels_ms": {k: round(v, 3) for k, v in top},
