@@ -293,16 +293,22 @@ __global__ __launch_bounds__(kThreads) void msm_sort_level2(const uint32_t* __re
   const size_t row0 = ((size_t)b * bins + bin) * nblk;
   const size_t tile_words = (size_t)kDigitTile * windows;
   const uint32_t* cbase = chunks + (size_t)b * nblk * tile_words;
-  if (threadIdx.x == 0) {
-    uint32_t acc = 0;
-    for (uint32_t t = 0; t < nblk; t++) {
-      run_pre[t] = acc;
-      run_src[t] = (uint32_t)(t * tile_words) + tloc[row0 + t];
-      acc += table[row0 + t];
-    }
-    run_pre[nblk] = acc;
+  // run table: the loads go out in parallel (a serial walk over ~33 dependent global loads per workgroup was the
+  // critical path of this kernel), the prefix over the LDS copy is cheap
+  for (uint32_t t = threadIdx.x; t < nblk; t += kThreads) {
+    run_src[t] = (uint32_t)(t * tile_words) + tloc[row0 + t];
+    run_pre[t + 1] = table[row0 + t];
   }
   for (uint32_t j = threadIdx.x; j < nsub; j += kThreads) hist[j] = 0;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t acc = 0;
+    run_pre[0] = 0;
+    for (uint32_t t = 1; t <= nblk; t++) {
+      acc += run_pre[t];
+      run_pre[t] = acc;
+    }
+  }
   __syncthreads();
   const uint32_t cnt = run_pre[nblk], off = off2[row0];
   auto fetch = [&](uint32_t p) {  // p-th entry of the bin: binary search for its run
@@ -313,11 +319,19 @@ __global__ __launch_bounds__(kThreads) void msm_sort_level2(const uint32_t* __re
     }
     return cbase[run_src[lo] + (p - run_pre[lo])];
   };
-  for (uint32_t p = threadIdx.x; p < cnt; p += kThreads) {
-    const uint32_t v = fetch(p);
-    if (p < kL2Stage) stage[p] = v;
-    atomicAdd(&hist[(v >> 24) & (nsub - 1)], 1u);
+  // pass A: the first kL2Stage entries stay in registers (24 per thread), the tail of an oversized bin is re-fetched
+  constexpr int kPerThread = kL2Stage / kThreads;
+  const uint32_t staged = cnt < kL2Stage ? cnt : kL2Stage;
+  uint32_t ev[kPerThread];
+#pragma unroll
+  for (int i = 0; i < kPerThread; i++) {
+    const uint32_t p = threadIdx.x + i * kThreads;
+    if (p < staged) {
+      ev[i] = fetch(p);
+      atomicAdd(&hist[(ev[i] >> 24) & (nsub - 1)], 1u);
+    }
   }
+  for (uint32_t p = kL2Stage + threadIdx.x; p < cnt; p += kThreads) atomicAdd(&hist[(fetch(p) >> 24) & (nsub - 1)], 1u);
   __syncthreads();
   if (threadIdx.x < 64) {  // exclusive scan of up to 256 counters by one wave
     const uint32_t per_lane = (nsub + 63) / 64;
@@ -341,12 +355,19 @@ __global__ __launch_bounds__(kThreads) void msm_sort_level2(const uint32_t* __re
     offsets[gb] = off + start[j];
   }
   __syncthreads();  // start[] now serves as the placement cursor
+  // pass B: entries are placed in LDS (positions beyond the stage go straight to HBM) and leave with coalesced stores
   uint32_t* dst = sorted + (size_t)b * per + off;
-  for (uint32_t p = threadIdx.x; p < cnt; p += kThreads) {
-    const uint32_t v = p < kL2Stage ? stage[p] : fetch(p);
+  auto place = [&](uint32_t v) {
     const uint32_t pos = atomicAdd(&start[(v >> 24) & (nsub - 1)], 1u);
-    dst[pos] = v & 0x80FFFFFFu;
-  }
+    if (pos < kL2Stage) stage[pos] = v & 0x80FFFFFFu;
+    else dst[pos] = v & 0x80FFFFFFu;
+  };
+#pragma unroll
+  for (int i = 0; i < kPerThread; i++)
+    if (threadIdx.x + i * kThreads < staged) place(ev[i]);
+  for (uint32_t p = kL2Stage + threadIdx.x; p < cnt; p += kThreads) place(fetch(p));
+  __syncthreads();
+  for (uint32_t p = threadIdx.x; p < staged; p += kThreads) dst[p] = stage[p];
 }
 
 // ---- K4: exclusive scan, one workgroup per batch entry ------------------------------------------
