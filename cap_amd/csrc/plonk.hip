@@ -490,7 +490,7 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
     int t = 0;
     auto add_term = [&](const fe* poly, const fe& sc, size_t len) {
       T[t].poly = poly;
-      T[t].scalar = sc;
+      T[t].scalar = Fr29::pack(Fr29::canonical(Fr29::from_ext(sc)));  // internal form: k_lincomb is on the lazy field
       T[t].len = (uint32_t)len;
       t++;
     };

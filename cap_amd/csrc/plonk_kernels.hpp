@@ -403,17 +403,27 @@ struct LinTerm {
 };
 
 // out[p][k] = sum_t terms[p][t].scalar * terms[p][t].poly[k]   (k < terms[p][t].len), k < out_len
+// Scalars arrive in the internal form of the lazy field (x * 2^261), polynomials in arkworks' form, so every product
+// is back in arkworks' form; six products share one Montgomery reduction.
 __global__ __launch_bounds__(kThreads) void k_lincomb(const LinTerm* __restrict__ terms, uint32_t nterms,
                                                       fe* __restrict__ out, size_t out_stride, size_t out_len) {
+  using F = Fr29;
   size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (k >= out_len) return;
   uint32_t p = blockIdx.y;
   const LinTerm* T = terms + (size_t)p * nterms;
-  fe acc = Fr::zero();
-  for (uint32_t t = 0; t < nterms; t++) {
-    if (k < T[t].len) acc = Fr::add(acc, Fr::mul(T[t].scalar, T[t].poly[k]));
+  fl total = F::zero();
+  for (uint32_t t0 = 0; t0 < nterms; t0 += 6) {
+    ColAcc acc;
+    acc.clear();
+#pragma unroll
+    for (uint32_t u = 0; u < 6; u++) {
+      const uint32_t t = t0 + u;
+      if (t < nterms && k < T[t].len) acc.mad(F::load(T[t].scalar), F::load(T[t].poly[k]));
+    }
+    total = F::normalize(F::add(total, acc.reduce()));
   }
-  out[(size_t)p * out_stride + k] = acc;
+  out[(size_t)p * out_stride + k] = F::pack(F::canonical(total));
 }
 
 // h[q][k] = f[q][k] * pows[tab(q)][k];  tab(q) = (q/2)*4 + (q%2)      (q = proof*2 + {zeta, zeta*omega})
