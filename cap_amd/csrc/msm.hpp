@@ -12,11 +12,18 @@
 //    fall into ONE bucket set, so the per-window running-sum reductions and the
 //    254 sequential doublings of the window combine (ruinous on a 64-lane SIMT
 //    machine where one field multiplication is ~1 us of latency) disappear;
+//  * two such tables: c = 13 for a single MSM (few buckets, log-depth reduction)
+//    and c = 15 for batches of >= 32 MSMs (17 instead of 20 mixed additions per
+//    254-bit scalar; the 4x larger bucket set costs two running-sum additions per
+//    bucket because the batch alone fills the chip);
 //  * signed digits halve the bucket count (2^(c-1) buckets);
-//  * bucket lists are built with a counting sort (histogram ranks + scan +
-//    scatter), accumulated with S lanes per bucket and merged by wavefront
-//    shuffles, and the weighted bucket sum  sum_j j*B_j  is evaluated bit-plane
-//    wise so that its dependency depth is logarithmic.
+//  * bucket lists come from a counting sort done per 1024-scalar tile in LDS, a
+//    table scan and run copies (c = 13), or - when a tile holds only about one
+//    entry per bucket (c = 15) - a tile sort on 128-bucket bins followed by a
+//    per-bin LDS sort that reads the tile chunks directly;
+//  * the unit of parallelism is a work item (a slice of one bucket's list), the
+//    items of a launch are ordered by length and alternate direction per MSM so
+//    that lanes of a wave, and the eight XCDs, finish together.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
