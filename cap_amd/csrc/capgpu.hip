@@ -63,6 +63,19 @@ int get_domain(uint32_t log_n, const NttDomain** out) {
   return CAPGPU_OK;
 }
 
+int get_domain3(uint32_t log_m, const Ntt3Domain** out) {
+  Context& c = ctx();
+  auto it = c.domains3.find(log_m);
+  if (it == c.domains3.end()) {
+    Ntt3Domain d;
+    int rc = ntt3_build_domain(&d, log_m, c.stream);
+    if (rc) return hip_fail((hipError_t)rc, "ntt3_build_domain");
+    it = c.domains3.emplace(log_m, d).first;
+  }
+  *out = &it->second;
+  return CAPGPU_OK;
+}
+
 namespace {
 
 // ---- SRS generation kernels ---------------------------------------------------------------
@@ -233,6 +246,8 @@ void capgpu_shutdown(void) {
   c.srs.clear();
   for (auto& kv : c.domains) ntt_free_domain(&kv.second);
   c.domains.clear();
+  for (auto& kv : c.domains3) ntt3_free_domain(&kv.second);
+  c.domains3.clear();
   ntt_free_small_tables(&c.small);
   for (Scratch* s : {&c.ntt_scratch, &c.msm_ws, &c.stage_a, &c.stage_b}) {
     if (s->p) hipFree(s->p);

@@ -32,6 +32,7 @@ struct Context {
   hipStream_t stream = nullptr;  // the stream work is enqueued on (own_stream unless capgpu_set_stream)
   NttSmallTables small;
   std::map<uint32_t, NttDomain> domains;
+  std::map<uint32_t, Ntt3Domain> domains3;  // N = 3 * 2^log_m (the prover's quotient domain)
   std::map<uint64_t, SrsEntry> srs;
   std::map<uint64_t, std::shared_ptr<ProvingKey>> keys;
   uint64_t next_handle = 1;
@@ -47,6 +48,7 @@ int hip_fail(hipError_t e, const char* what);  // records message, returns CAPGP
 int scratch_reserve(Scratch& s, size_t bytes);
 // cached domain tables for 2^log_n
 int get_domain(uint32_t log_n, const NttDomain** out);
+int get_domain3(uint32_t log_m, const Ntt3Domain** out);
 // builds the window table of `n` device-resident affine bases (arkworks form, (0,0) = infinity) and registers it
 int register_srs(g1_affine* d_bases, size_t n, uint64_t* handle_out);
 int find_srs(uint64_t h, const MsmBases** out);

@@ -39,6 +39,11 @@ struct PassParams {
   // in_len read as zero (a polynomial shorter than the transform: no padded copy has to exist in memory)
   size_t in_outer, in_inner, in_len;
   uint32_t in_group;
+  uint32_t in_es;            // element stride of the first-pass input (decimated transforms); 1 = contiguous
+  // second grouping level of the input (decimated transforms of grouped polynomials): array q = (q2, a) with
+  // a = q % in_group the decimation phase and q2 = q / in_group placed at (q2 / in_group2) * in_outer + (q2 % in_group2) * in_inner2
+  size_t in_inner2;
+  uint32_t in_group2;
   size_t out_outer, out_inner;
   uint32_t out_group;
   const fl* tw_small;        // omega_len^i, i < len/2, unpacked limbs
@@ -135,7 +140,9 @@ __global__ __launch_bounds__(kThreads) void ntt_col_pass(PassParams p) {
   const uint32_t t = blockIdx.x;
   const size_t seg = t >> tiles_per_seg_log;
   const uint32_t col0 = (t & ((1u << tiles_per_seg_log) - 1)) << p.log_c;
-  const fe* in = p.in + (size_t)(blockIdx.y / p.in_group) * p.in_outer + (size_t)(blockIdx.y % p.in_group) * p.in_inner;
+  const uint32_t q2 = blockIdx.y / p.in_group;
+  const fe* in = p.in + (size_t)(q2 / p.in_group2) * p.in_outer + (size_t)(q2 % p.in_group2) * p.in_inner2 +
+                 (size_t)(blockIdx.y % p.in_group) * p.in_inner;
   fe* out = p.out + (size_t)(blockIdx.y / p.out_group) * p.out_outer + (size_t)(blockIdx.y % p.out_group) * p.out_inner;
   const size_t base = (seg << p.log_m) + col0;
   const uint32_t tile = 1u << (p.log_len + p.log_c);
@@ -145,8 +152,10 @@ __global__ __launch_bounds__(kThreads) void ntt_col_pass(PassParams p) {
     size_t g = base + ((size_t)j << log_s) + c;
     fe raw;
     uint32_t any = 0;
-    if (g < p.in_len) {
-      raw = in[g];
+    // position inside the source array (decimated input: every in_es-th element, starting at the group offset)
+    const size_t sg = p.in_es == 1 ? g : g * p.in_es + (size_t)(blockIdx.y % p.in_group) * p.in_inner;
+    if (sg < p.in_len) {
+      raw = p.in_es == 1 ? in[g] : in[g * p.in_es];
 #pragma unroll
       for (int k = 0; k < 8; k++) any |= raw.v[k];
     } else {
@@ -154,7 +163,7 @@ __global__ __launch_bounds__(kThreads) void ntt_col_pass(PassParams p) {
       for (int k = 0; k < 8; k++) raw.v[k] = 0;
     }
     fl v = Fr29::load(raw);
-    if (p.pre_scale && any) v = Fr29::mul(v, Fr29::load(p.pre_scale[g]));  // zero padding needs no coset scaling
+    if (p.pre_scale && any) v = Fr29::mul(v, Fr29::load(p.pre_scale[sg]));  // zero padding needs no coset scaling
     sh[(bitrev32(j, p.log_len) << p.log_c) + c] = v;
   }
   __syncthreads();
@@ -176,7 +185,9 @@ __global__ __launch_bounds__(kThreads) void ntt_row_pass(PassParams p) {
   const uint32_t t = blockIdx.x;
   const uint32_t k2 = t & ((1u << p.log_n2) - 1);
   const uint32_t r0 = (t >> p.log_n2) << p.log_c;
-  const fe* in = p.in + (size_t)(blockIdx.y / p.in_group) * p.in_outer + (size_t)(blockIdx.y % p.in_group) * p.in_inner;
+  const uint32_t q2 = blockIdx.y / p.in_group;
+  const fe* in = p.in + (size_t)(q2 / p.in_group2) * p.in_outer + (size_t)(q2 % p.in_group2) * p.in_inner2 +
+                 (size_t)(blockIdx.y % p.in_group) * p.in_inner;
   fe* out = p.out + (size_t)(blockIdx.y / p.out_group) * p.out_outer + (size_t)(blockIdx.y % p.out_group) * p.out_inner;
   const uint32_t tile = 1u << (p.log_len + p.log_c);
   const uint32_t lmask = (1u << p.log_len) - 1;
@@ -186,8 +197,10 @@ __global__ __launch_bounds__(kThreads) void ntt_row_pass(PassParams p) {
     size_t g = ((((size_t)(r0 + c) << p.log_n2) + k2) << p.log_len) + j;
     fe raw;
     uint32_t any = 0;
-    if (g < p.in_len) {
-      raw = in[g];
+    // position inside the source array (decimated input: every in_es-th element, starting at the group offset)
+    const size_t sg = p.in_es == 1 ? g : g * p.in_es + (size_t)(blockIdx.y % p.in_group) * p.in_inner;
+    if (sg < p.in_len) {
+      raw = p.in_es == 1 ? in[g] : in[g * p.in_es];
 #pragma unroll
       for (int k = 0; k < 8; k++) any |= raw.v[k];
     } else {
@@ -195,7 +208,7 @@ __global__ __launch_bounds__(kThreads) void ntt_row_pass(PassParams p) {
       for (int k = 0; k < 8; k++) raw.v[k] = 0;
     }
     fl v = Fr29::load(raw);
-    if (p.pre_scale && any) v = Fr29::mul(v, Fr29::load(p.pre_scale[g]));  // zero padding needs no coset scaling
+    if (p.pre_scale && any) v = Fr29::mul(v, Fr29::load(p.pre_scale[sg]));  // zero padding needs no coset scaling
     sh[(bitrev32(j, p.log_len) << p.log_c) + c] = v;
   }
   __syncthreads();
@@ -237,6 +250,39 @@ __global__ void powers_table(fe* out, size_t n, const fe* __restrict__ pw, fe sc
     }
   }
   out[e] = r;
+}
+
+// ---- radix-3 stage of the N = 3 M transforms -------------------------------------------------------------------
+// y: [count][3][M] sub-transform outputs (lazy, internal form).  out: array q at (q / group) * outer + (q % group) * inner.
+//   X[k + M b] = Y0 + w3^b T1 + w3^(2b) T2,  T1 = omega_N^k Y1[k], T2 = omega_N^(2k) Y2[k];  with w3^2 = -1 - w3:
+//   X[k] = Y0 + T1 + T2,  X[k + M] = Y0 - T2 + D,  X[k + 2M] = Y0 - T1 - D,  D = w3 (T1 - T2)     (3 multiplications)
+// post != null (inverse transform): every output is multiplied by post[index] (an arkworks-form integer table, which
+// takes internal-form data to arkworks' form) and leaves canonical; otherwise outputs leave weakly reduced.
+__global__ __launch_bounds__(kThreads) void ntt3_combine(const fe* __restrict__ y, fe* __restrict__ out, size_t out_outer,
+                                                         size_t out_inner, uint32_t out_group, size_t m_len,
+                                                         const fe* __restrict__ tw, fe w3, const fe* __restrict__ post) {
+  using F = Fr29;
+  const size_t k = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= m_len) return;
+  const uint32_t q = blockIdx.y;
+  const fe* yq = y + (size_t)q * 3 * m_len;
+  fe* o = out + (size_t)(q / out_group) * out_outer + (size_t)(q % out_group) * out_inner;
+  const fl y0 = F::load(yq[k]);
+  const fl t1 = F::mul(F::load(yq[m_len + k]), F::load(tw[k]));
+  const fl t2 = F::mul(F::load(yq[2 * m_len + k]), F::load(tw[2 * k]));
+  const fl d = F::mul(F::sub(t1, t2), F::load(w3));
+  fl x0 = F::normalize(F::add(F::add(y0, t1), t2));
+  fl x1 = F::normalize(F::add(F::sub(y0, t2), d));
+  fl x2 = F::sub(F::sub(y0, t1), d);
+  if (post) {
+    o[k] = F::pack(F::canonical(F::mul(x0, F::load(post[k]))));
+    o[m_len + k] = F::pack(F::canonical(F::mul(x1, F::load(post[m_len + k]))));
+    o[2 * m_len + k] = F::pack(F::canonical(F::mul(x2, F::load(post[2 * m_len + k]))));
+  } else {
+    o[k] = F::store(x0);
+    o[m_len + k] = F::store(x1);
+    o[2 * m_len + k] = F::store(x2);
+  }
 }
 
 fe host_root_of_unity(uint32_t log_n) {
@@ -419,12 +465,20 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
   const Addr a_dst = io ? Addr{io->dst_outer, io->dst_inner, io->dst_group ? io->dst_group : 1u} : Addr{stride_elems, 0, 1};
   const Addr a_tmp = Addr{scratch_stride, 0, 1};
   const size_t src_len = io ? io->src_len : ~(size_t)0;
-  auto set_in = [&](const Addr& a, size_t len) {
+  auto set_in = [&](const Addr& a, size_t len, uint32_t es) {
     p.in_outer = a.outer;
     p.in_inner = a.inner;
     p.in_group = a.group;
     p.in_len = len;
+    p.in_es = es;
+    p.in_group2 = 1;
+    p.in_inner2 = 0;
+    if (&a == &a_src && io && io->src_group2 > 1) {
+      p.in_group2 = io->src_group2;
+      p.in_inner2 = io->src_inner2;
+    }
   };
+  const uint32_t src_es = io && io->src_elem_stride ? io->src_elem_stride : 1;
   auto set_out = [&](const Addr& a) {
     p.out_outer = a.outer;
     p.out_inner = a.inner;
@@ -435,6 +489,7 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
   p.use_post_scalar = 0;
 
   const fe* pre = (!dir && coset) ? (io_form == kNttOutInternal ? dom.coset29_fwd_x32 : dom.coset29_fwd) : nullptr;
+  if (io && io->pre_scale) pre = io->pre_scale;
   bool first = true;
   const fe* cur_in = io ? io->src : data;
   // column passes
@@ -447,7 +502,7 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
     if (log_c > 4) log_c = 4;
     p.in = cur_in;
     p.out = scratch;
-    set_in(first ? a_src : a_tmp, first ? src_len : ~(size_t)0);
+    set_in(first ? a_src : a_tmp, first ? src_len : ~(size_t)0, first ? src_es : 1);
     set_out(a_tmp);
     p.tw_small = reinterpret_cast<const fl*>(tws[log_len]);
     p.pre_scale = first ? pre : nullptr;
@@ -472,14 +527,14 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
     if (log_c > 4) log_c = 4;
     p.in = cur_in;
     p.out = data;
-    set_in(first ? a_src : a_tmp, first ? src_len : ~(size_t)0);
+    set_in(first ? a_src : a_tmp, first ? src_len : ~(size_t)0, first ? src_es : 1);
     set_out(a_dst);
     p.tw_small = reinterpret_cast<const fl*>(tws[log_len]);
     p.pre_scale = first ? pre : nullptr;
     p.post_scale = (dir && coset) ? (io_form == kNttInInternal ? dom.coset_inv : dom.coset29_inv) : nullptr;
     p.use_post_scalar = (dir && !coset) ? 1 : 0;
     p.post_scalar = dom.n_inv29;
-    p.lazy_out = io_form == kNttOutInternal ? 1 : 0;
+    p.lazy_out = (io_form == kNttOutInternal || (io && io->lazy_out)) ? 1 : 0;
     p.log_len = log_len;
     p.log_c = log_c;
     p.log_n1 = log_n1;
@@ -488,6 +543,121 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
     size_t lds = sizeof(fl) << (log_len + log_c);
     launch("ntt_row_pass", ntt_row_pass, dim3((unsigned)tiles, count), dim3(kThreads), lds, stream, p);
   }
+  return (int)hipGetLastError();
+}
+
+// ---- N = 3 * 2^k ------------------------------------------------------------------------------------------------
+namespace {
+// (r - 1) / 3, little-endian 32-bit words
+void exponent_third(uint32_t e[8]) {
+  uint32_t t[8];
+  for (int i = 0; i < 8; i++) t[i] = FrP::MOD[i];
+  t[0] -= 1;  // r is odd and r - 1 is divisible by 3 (r - 1 = 2^28 * 3^2 * ...)
+  uint64_t rem = 0;
+  for (int i = 7; i >= 0; i--) {
+    uint64_t cur = (rem << 32) | t[i];
+    e[i] = (uint32_t)(cur / 3);
+    rem = cur % 3;
+  }
+}
+}  // namespace
+
+int ntt3_build_domain(Ntt3Domain* d, uint32_t log_m, hipStream_t stream) {
+  d->log_m = log_m;
+  const size_t M = (size_t)1 << log_m, N = 3 * M;
+  // omega_N = omega_3 * omega_M^c, 3c = 1 mod M
+  uint32_t e3[8];
+  exponent_third(e3);
+  const fe g = host_from_u64(5);
+  const fe w3gen = Fr::pow(g, e3);  // a primitive cube root of unity
+  size_t c = (M % 3 == 2) ? (M + 1) / 3 : (2 * M + 1) / 3;
+  if (M == 1) c = 1;
+  uint32_t ec[8] = {(uint32_t)c, (uint32_t)((uint64_t)c >> 32), 0, 0, 0, 0, 0, 0};
+  const fe wN = Fr::mul(w3gen, Fr::pow(host_root_of_unity(log_m), ec));
+  d->omega = wN;
+  uint32_t eM[8] = {(uint32_t)M, (uint32_t)((uint64_t)M >> 32), 0, 0, 0, 0, 0, 0};
+  const fe w3 = Fr::pow(wN, eM);
+  auto to_internal = [](const fe& a) { return Fr29::pack(Fr29::canonical(Fr29::from_ext(a))); };
+  d->w3_29 = to_internal(w3);
+  d->w3inv_29 = to_internal(Fr::inv(w3));
+  hipError_t e;
+  for (fe** t : {&d->tw_ext, &d->tw29, &d->tw29_inv, &d->coset29_x32, &d->coset_inv_ext})
+    if ((e = hipMalloc(t, sizeof(fe) * N)) != hipSuccess) return (int)e;
+  int rc;
+  if ((rc = build_powers(d->tw_ext, N, wN, nullptr, stream))) return rc;
+  if ((rc = build_powers(d->tw29_inv, N, Fr::inv(wN), nullptr, stream))) return rc;
+  const fe k32 = host_from_u64(32);
+  if ((rc = build_powers(d->coset29_x32, N, g, &k32, stream))) return rc;
+  const fe third = Fr::inv(host_from_u64(3));
+  if ((rc = build_powers(d->coset_inv_ext, N, Fr::inv(g), &third, stream))) return rc;
+  const unsigned blocks = (unsigned)((N + 255) / 256);
+  launch("table_to_internal", table_to_internal, dim3(blocks), dim3(256), 0, stream, d->tw29, (const fe*)d->tw_ext, N);
+  launch("table_to_internal", table_to_internal, dim3(blocks), dim3(256), 0, stream, d->tw29_inv,
+         (const fe*)d->tw29_inv, N);
+  launch("table_to_internal", table_to_internal, dim3(blocks), dim3(256), 0, stream, d->coset29_x32,
+         (const fe*)d->coset29_x32, N);
+  return (int)hipStreamSynchronize(stream);
+}
+
+void ntt3_free_domain(Ntt3Domain* d) {
+  for (fe** t : {&d->tw_ext, &d->tw29, &d->tw29_inv, &d->coset29_x32, &d->coset_inv_ext}) {
+    if (*t) hipFree(*t);
+    *t = nullptr;
+  }
+}
+
+int ntt3_forward(const Ntt3Domain& d3, const NttDomain& dom_m, const NttSmallTables& small, fe* data, NttIo io,
+                 uint32_t count, fe* scratch, hipStream_t stream) {
+  if (dom_m.log_n != d3.log_m) return (int)hipErrorInvalidValue;
+  const size_t M = (size_t)1 << d3.log_m;
+  fe* y = scratch;                            // [count][3][M]
+  fe* sub_scratch = scratch + (size_t)count * 3 * M;
+  // three decimated sub-transforms per polynomial, in one batched launch: array 3 q + a reads src_q[3 j + a]
+  NttIo sub{};
+  sub.src = io.src;
+  sub.src_outer = io.src_outer;
+  sub.src_inner = 1;
+  sub.src_group = 3;
+  sub.src_group2 = io.src_group ? io.src_group : 1;  // the caller's own grouping moves one level up
+  sub.src_inner2 = io.src_inner;
+  sub.src_len = io.src_len;
+  sub.src_elem_stride = 3;
+  sub.pre_scale = d3.coset29_x32;
+  sub.lazy_out = 1;
+  sub.dst_outer = M;
+  sub.dst_inner = 0;
+  sub.dst_group = 1;
+  int rc = ntt_run(dom_m, small, y, sub_scratch, M, count * 3, 0, 0, stream, 0, &sub);
+  if (rc) return rc;
+  launch("ntt3_combine", ntt3_combine, dim3((unsigned)((M + kThreads - 1) / kThreads), count), dim3(kThreads), 0, stream,
+         (const fe*)y, data, io.dst_outer, io.dst_inner, io.dst_group ? io.dst_group : 1u, M, (const fe*)d3.tw29, d3.w3_29,
+         (const fe*)nullptr);
+  return (int)hipGetLastError();
+}
+
+int ntt3_inverse(const Ntt3Domain& d3, const NttDomain& dom_m, const NttSmallTables& small, fe* data, uint32_t count,
+                 fe* scratch, hipStream_t stream) {
+  if (dom_m.log_n != d3.log_m) return (int)hipErrorInvalidValue;
+  const size_t M = (size_t)1 << d3.log_m, N = 3 * M;
+  fe* y = scratch;
+  fe* sub_scratch = scratch + (size_t)count * 3 * M;
+  NttIo sub{};
+  sub.src = data;
+  sub.src_outer = N;
+  sub.src_inner = 1;
+  sub.src_group = 3;
+  sub.src_len = N;
+  sub.src_elem_stride = 3;
+  sub.lazy_out = 1;
+  sub.dst_outer = M;
+  sub.dst_inner = 0;
+  sub.dst_group = 1;
+  // inverse sub-transforms (their 1 / M is applied inside), then the radix-3 stage with inverse twiddles and the
+  // coset / 1/3 / form-changing table
+  int rc = ntt_run(dom_m, small, y, sub_scratch, M, count * 3, 1, 0, stream, 0, &sub);
+  if (rc) return rc;
+  launch("ntt3_combine", ntt3_combine, dim3((unsigned)((M + kThreads - 1) / kThreads), count), dim3(kThreads), 0, stream,
+         (const fe*)y, data, N, (size_t)0, 1u, M, (const fe*)d3.tw29_inv, d3.w3inv_29, (const fe*)d3.coset_inv_ext);
   return (int)hipGetLastError();
 }
 

@@ -197,6 +197,36 @@ int run_ntt_io(hipStream_t s, uint32_t log_n, fe* data, uint32_t count, int dir,
   return CAPGPU_OK;
 }
 
+// the quotient domain: N = 6n = 3 * 2^(log n + 1) points (ntt.hpp)
+int quot_domains(uint32_t log_mm, const Ntt3Domain** d3, const NttDomain** dm) {
+  int rc = get_domain3(log_mm, d3);
+  if (rc) return rc;
+  return get_domain(log_mm, dm);
+}
+// coset evaluations on the 6n domain of `count` polynomials read through io (one polynomial family per call)
+int run_ntt3_fwd(hipStream_t s, uint32_t log_mm, fe* data, uint32_t count, const NttIo& io) {
+  Context& c = ctx();
+  const Ntt3Domain* d3 = nullptr;
+  const NttDomain* dm = nullptr;
+  int rc = quot_domains(log_mm, &d3, &dm);
+  if (rc) return rc;
+  if ((rc = scratch_reserve(c.ntt_scratch, (sizeof(fe) << log_mm) * 6 * count))) return rc;
+  rc = ntt3_forward(*d3, *dm, c.small, data, io, count, (fe*)c.ntt_scratch.p, s);
+  if (rc) return hip_fail((hipError_t)rc, "ntt3_forward");
+  return CAPGPU_OK;
+}
+int run_ntt3_inv(hipStream_t s, uint32_t log_mm, fe* data, uint32_t count) {
+  Context& c = ctx();
+  const Ntt3Domain* d3 = nullptr;
+  const NttDomain* dm = nullptr;
+  int rc = quot_domains(log_mm, &d3, &dm);
+  if (rc) return rc;
+  if ((rc = scratch_reserve(c.ntt_scratch, (sizeof(fe) << log_mm) * 6 * count))) return rc;
+  rc = ntt3_inverse(*d3, *dm, c.small, data, count, (fe*)c.ntt_scratch.p, s);
+  if (rc) return hip_fail((hipError_t)rc, "ntt3_inverse");
+  return CAPGPU_OK;
+}
+
 int run_msm(hipStream_t s, const MsmBases& B, const fe* scalars, size_t outer_stride, uint32_t inner,
             size_t inner_stride, size_t n, uint32_t batch, g1_jac* d_out) {
   Context& c = ctx();
@@ -272,7 +302,7 @@ BatchWs carve(void* base, const ProvingKey& K, uint32_t P) {
 
 // the 18 fixed polynomials -> coset evaluations on the 8n domain
 int compute_pk_coset(hipStream_t s, const ProvingKey& K, fe* dst) {
-  return run_ntt_io(s, K.log_m, dst, 18, 0, 1, kNttOutInternal, NttIo{K.coef, K.ps, 0, K.n, 1, K.m, 0, 1});
+  return run_ntt3_fwd(s, K.log_m, dst, 18, NttIo{K.coef, K.ps, 0, K.n, 1, K.m, 0, 1});
 }
 
 int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pub_inputs, size_t num_inputs,
@@ -298,9 +328,10 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
     K.ws_bytes = need;
   }
   BatchWs w = carve(K.ws, K, P);
-  const NttDomain *dom_n = nullptr, *dom_m = nullptr;
+  const NttDomain* dom_n = nullptr;
+  const Ntt3Domain* dom_q = nullptr;
   if ((rc = get_domain(K.log_n, &dom_n))) return rc;
-  if ((rc = get_domain(K.log_m, &dom_m))) return rc;
+  if ((rc = get_domain3(K.log_m, &dom_q))) return rc;
 
   // ---- transcripts (host) --------------------------------------------------------------------------------
   std::vector<SolidityTranscript> tr(P);
@@ -383,14 +414,9 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
   // ---- round 3: quotient polynomial ---------------------------------------------------------------------
   // coset evaluations of the wire, z and public-input polynomials on the 8n domain, straight from their coefficient
   // arrays (the transform zero-extends them; a padded copy would be 7 x 8n x 32 B per proof written and read back)
-  if ((rc = run_ntt_io(s, K.log_m, w.coset, P * NW, 0, 1, kNttOutInternal,
-                       NttIo{w.wpoly, NW * ps, ps, n + 2, NW, 7 * m, m, NW})))
-    return rc;
-  if ((rc = run_ntt_io(s, K.log_m, w.coset + 5 * m, P, 0, 1, kNttOutInternal,
-                       NttIo{w.zpoly, ps, 0, n + 3, 1, 7 * m, 0, 1})))
-    return rc;
-  if ((rc = run_ntt_io(s, K.log_m, w.coset + 6 * m, P, 0, 1, kNttOutInternal, NttIo{w.pi, n, 0, n, 1, 7 * m, 0, 1})))
-    return rc;
+  if ((rc = run_ntt3_fwd(s, K.log_m, w.coset, P * NW, NttIo{w.wpoly, NW * ps, ps, n + 2, NW, 7 * m, m, NW}))) return rc;
+  if ((rc = run_ntt3_fwd(s, K.log_m, w.coset + 5 * m, P, NttIo{w.zpoly, ps, 0, n + 3, 1, 7 * m, 0, 1}))) return rc;
+  if ((rc = run_ntt3_fwd(s, K.log_m, w.coset + 6 * m, P, NttIo{w.pi, n, 0, n, 1, 7 * m, 0, 1}))) return rc;
   const fe* pkc = K.pk_coset;
   if (K.recompute) {
     // reference schedule: the 18 selector / sigma polynomials are re-transformed for every proof
@@ -399,8 +425,8 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
     pkc = w.pkc;
   }
   launch("k_quotient", k_quotient, dim3(P, cdiv(m, kThreads)), dim3(kThreads), 0, s, pkc, (const fe*)w.coset,
-         (const fe*)dom_m->tw29_fwd, (const fe*)K.inv_nx1, (const Chal*)w.chal29, K.qc29, m, w.t);
-  if ((rc = run_ntt(s, K.log_m, w.t, m, P, 1, 1, kNttInInternal))) return rc;
+         (const fe*)dom_q->tw29, (const fe*)K.inv_nx1, (const Chal*)w.chal29, K.qc29, m, w.t);
+  if ((rc = run_ntt3_inv(s, K.log_m, w.t, P))) return rc;
   {
     size_t lo = NW * (n + 1) + 3;  // first index that must be zero: degree is exactly 5(n+1)+2
     launch("k_check_degree", k_check_degree, dim3(cdiv(m - (lo - 1), kThreads), P), dim3(kThreads), 0, s,
@@ -564,11 +590,11 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
 // ---- proving-key construction shared by preprocess and the blob loader -------------------------------------
 int key_init(ProvingKey& K, size_t n, size_t num_inputs, uint64_t srs_handle) {
   K.n = n;
-  K.m = 8 * n;
+  K.m = 6 * n;  // quotient domain: 3 * 2^(log n + 1) points
   K.ps = n + 8;
   while (((size_t)1 << K.log_n) < n) K.log_n++;
-  K.log_m = K.log_n + 3;
-  if (K.log_m > 27) {
+  K.log_m = K.log_n + 1;  // log2 of the power-of-two factor of m
+  if (K.log_m > 25) {
     set_error("capgpu_plonk_preprocess: domain too large");
     return CAPGPU_ERR_INVALID_ARG;
   }
@@ -593,16 +619,19 @@ int key_finish_tables(hipStream_t s, ProvingKey& K) {
   {
     uint32_t e_n[8] = {(uint32_t)n, (uint32_t)((uint64_t)n >> 32), 0, 0, 0, 0, 0, 0};
     fe gn = Fr::pow(K.qc.g, e_n);
-    fe w8 = Fr::pow(ntt_root_of_unity(K.log_m), e_n);  // omega_m^n: primitive 8th root of unity
+    const Ntt3Domain* dq = nullptr;
+    if ((rc = get_domain3(K.log_m, &dq))) return rc;
+    fe w6 = Fr::pow(dq->omega, e_n);  // omega_m^n: a primitive 6th root of unity (m = 6n)
     fe x = gn;
-    for (int i = 0; i < 8; i++) {
+    for (int i = 0; i < 8; i++) K.qc.zh_inv[i] = Fr::zero();
+    for (int i = 0; i < 6; i++) {
       K.qc.zh_inv[i] = Fr::inv(Fr::sub(x, Fr::one()));
-      x = Fr::mul(x, w8);
+      x = Fr::mul(x, w6);
     }
   }
-  const NttDomain* dom_m = nullptr;
-  if ((rc = get_domain(K.log_m, &dom_m))) return rc;
-  launch("k_inv_nx1", k_inv_nx1, dim3(cdiv(m, kThreads)), dim3(kThreads), 0, s, K.inv_nx1, (const fe*)dom_m->tw_fwd,
+  const Ntt3Domain* dom_m = nullptr;
+  if ((rc = get_domain3(K.log_m, &dom_m))) return rc;
+  launch("k_inv_nx1", k_inv_nx1, dim3(cdiv(m, kThreads)), dim3(kThreads), 0, s, K.inv_nx1, (const fe*)dom_m->tw_ext,
          K.qc.g, fr_from_u64((uint64_t)n), m);
   ntt_table_to_internal(K.inv_nx1, K.inv_nx1, m, s);
   {
@@ -659,8 +688,8 @@ int capgpu_plonk_preprocess(uint64_t srs_handle, size_t n, size_t num_inputs, co
   CAP_CHECK_INIT();
   Context& c = ctx();
   std::lock_guard<std::recursive_mutex> lk(c.mu);
-  if (!selectors || !sigma_evals || !pk_handle_out || n < 4 || (n & (n - 1)) || num_inputs >= n) {
-    set_error("capgpu_plonk_preprocess: bad argument (n must be a power of two >= 4, num_inputs < n)");
+  if (!selectors || !sigma_evals || !pk_handle_out || n < 8 || (n & (n - 1)) || num_inputs >= n) {
+    set_error("capgpu_plonk_preprocess: bad argument (n must be a power of two >= 8, num_inputs < n)");
     return CAPGPU_ERR_INVALID_ARG;
   }
   const MsmBases* B = nullptr;
@@ -814,7 +843,7 @@ int capgpu_plonk_key_deserialize(const uint8_t* bytes, size_t len, uint64_t* srs
   if (!tag) return fail("unexpected end of input");
   if (*tag) return fail("plookup proving keys are not supported");
   const size_t n = vk.domain_size;
-  if (n < 4 || (n & (n - 1)) || vk.num_inputs >= n) return fail("domain_size must be a power of two above num_inputs");
+  if (n < 8 || (n & (n - 1)) || vk.num_inputs >= n) return fail("domain_size must be a power of two above num_inputs");
   if (n_ck < n + 3) return fail("commit key shorter than domain_size + 3");
   for (int i = 0; i < 18; i++)
     if (polys[i].len > n) return fail("polynomial longer than the domain");

@@ -29,7 +29,7 @@ struct Chal {
 struct QuotConst {
   fe g;           // coset generator 5 (Montgomery)
   fe k[NW];       // wire-subset separators
-  fe zh_inv[8];   // 1 / ((g * w_m^i)^n - 1), i mod 8
+  fe zh_inv[8];   // 1 / ((g * w_m^i)^n - 1), i mod 6 (m = 6n: six distinct values)
 };
 
 // dst[(q/inner)*dst_outer + (q%inner)*dst_inner + k] = k < len ? src[(q/inner)*src_outer + (q%inner)*src_inner + k] : 0
@@ -203,7 +203,8 @@ __global__ __launch_bounds__(kThreads) void k_perm_finish(const fe* __restrict__
   z[(size_t)p * zstride + j] = v;
 }
 
-// ---- round 3: fused quotient evaluation on the coset of size m = 8n ----------------------------------
+// ---- round 3: fused quotient evaluation on the coset of size m = 6n ----------------------------------
+// (jf-plonk uses 8n; the quotient has degree < 5n + 8, so 6n = 3 * 2^(log n + 1) points determine it - ntt.hpp)
 // All inputs are in the internal Montgomery form of the lazy 29-bit field (x * 2^261): the forward coset NTTs emit
 // it (kNttOutInternal) and the inverse coset NTT that follows consumes it (kNttInInternal).
 // pkc: [18][m] coset evaluations of 13 selectors then 5 sigmas (shared by all proofs)
@@ -272,7 +273,8 @@ __global__ __launch_bounds__(kThreads) void k_quotient(const fe* __restrict__ pk
   {
     fl x = F::mul(F::load(qc.g), F::load(tw_m[i]));
     fl bx = F::mul(beta, x);
-    fl a = zx, b = F::load(c[5 * m + ((i + 8) & (m - 1))]);
+    const size_t inext = i + 6 < m ? i + 6 : i + 6 - m;  // x * omega_n = the point six steps further on the 6n coset
+    fl a = zx, b = F::load(c[5 * m + inext]);
     fl wg = F::add(w0, gamma);
     a = F::mul(a, F::normalize(F::add(wg, bx)));
     b = F::mul(b, F::normalize(F::add(wg, F::mul(beta, sel(NS + 0)))));
@@ -292,7 +294,7 @@ __global__ __launch_bounds__(kThreads) void k_quotient(const fe* __restrict__ pk
   }
   // (gate + alpha * perm) / Z_H  +  alpha^2 (z - 1) / (n (x - 1)) : two products, one reduction
   fl l1a = F::mul(F::load(chal[p].alpha2), F::sub(zx, F::one()));
-  fl r = F::mul_add_mul(total, F::load(qc.zh_inv[i & 7]), l1a, F::load(inv_nx1[i]));
+  fl r = F::mul_add_mul(total, F::load(qc.zh_inv[i % 6]), l1a, F::load(inv_nx1[i]));
   t_out[(size_t)p * m + i] = F::store(r);
 }
 
