@@ -249,10 +249,10 @@ def main():
         # K5: 96 B per (point, scalar) pair handled by the launch (64 B affine base + 32 B scalar)
         "msm_accumulate": ab["msm_bytes"] * P,
         # K2: 64 B per element per transform; a transform of 2^11..2^20 elements is one column + one row pass
-        "ntt_col_pass": 0.5 * (64 * (7 * n + 8 * 8 * n)) * P,
-        "ntt_row_pass": 0.5 * (64 * (7 * n + 8 * 8 * n)) * P,
-        # K8: 26 arrays of 8n elements (25 in, 1 out) x 32 B
-        "k_quotient": 26 * 8 * n * 32 * P,
+        "ntt_col_pass": 0.5 * (64 * (7 * n + 8 * 6 * n)) * P,
+        "ntt_row_pass": 0.5 * (64 * (7 * n + 8 * 6 * n)) * P,
+        # K8: 26 arrays of 6n elements (25 in, 1 out) x 32 B (jf-plonk's 8n domain would be a third more)
+        "k_quotient": 26 * 6 * n * 32 * P,
     }
     traffic_tab = {}
     try:

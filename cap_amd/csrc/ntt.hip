@@ -83,7 +83,7 @@ __device__ __forceinline__ void lds_ntt(fl* sh, const fl* __restrict__ tw_small,
       uint32_t i0 = (j << log_c) + c, i1 = ((j + half) << log_c) + c;
       fl u = sh[i0], v = sh[i1];
       if (s < 3) {
-        // zero-padded inputs (a degree-n polynomial on the 8n coset: 7 of the prover's 8 large transforms): the rows
+        // zero-padded inputs (a degree-n polynomial evaluated on a much larger coset: most of the prover's transforms): the rows
         // beyond len/8 are zero, so in the first three stages every odd operand is zero and the butterfly is a copy
         uint32_t any = 0;
 #pragma unroll

@@ -5,8 +5,9 @@
 // and :113, src/proof/freeze.rs:102 and :151 (algorithm: SURVEY.md §3.2 / Appendix A).
 // The host keeps only what is O(1) per proof: the Keccak transcript, the challenge
 // arithmetic and Jacobian -> affine of the 13 commitments.  All O(n) work - 7 iNTT(n),
-// 26 coset (i)NTT(8n), 13 MSM, grand product, quotient, evaluations, linearisation,
-// openings - runs on the GPU without leaving HBM between rounds.
+// the coset transforms of the quotient step (jf-plonk: 26 of size 8n; here 8 of size 6n per
+// proof, the 18 key columns being cached), 13 MSM, grand product, quotient, evaluations,
+// linearisation, openings - runs on the GPU without leaving HBM between rounds.
 //
 // MI355X-first choices: a batch of P proofs is proved in lockstep so that every launch
 // is P times larger (13 MSMs become 5 launches of 5P / P / 5P / 2P MSMs; NTTs are
@@ -300,7 +301,7 @@ BatchWs carve(void* base, const ProvingKey& K, uint32_t P) {
   return w;
 }
 
-// the 18 fixed polynomials -> coset evaluations on the 8n domain
+// the 18 fixed polynomials -> coset evaluations on the 6n quotient domain
 int compute_pk_coset(hipStream_t s, const ProvingKey& K, fe* dst) {
   return run_ntt3_fwd(s, K.log_m, dst, 18, NttIo{K.coef, K.ps, 0, K.n, 1, K.m, 0, 1});
 }
@@ -412,8 +413,8 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
   CAP_HIP(hipMemcpyAsync(w.chal29, chal29.data(), sizeof(Chal) * P, hipMemcpyHostToDevice, s));
 
   // ---- round 3: quotient polynomial ---------------------------------------------------------------------
-  // coset evaluations of the wire, z and public-input polynomials on the 8n domain, straight from their coefficient
-  // arrays (the transform zero-extends them; a padded copy would be 7 x 8n x 32 B per proof written and read back)
+  // coset evaluations of the wire, z and public-input polynomials on the 6n quotient domain, straight from their
+  // coefficient arrays (the transform zero-extends them: no padded copies are written and read back)
   if ((rc = run_ntt3_fwd(s, K.log_m, w.coset, P * NW, NttIo{w.wpoly, NW * ps, ps, n + 2, NW, 7 * m, m, NW}))) return rc;
   if ((rc = run_ntt3_fwd(s, K.log_m, w.coset + 5 * m, P, NttIo{w.zpoly, ps, 0, n + 3, 1, 7 * m, 0, 1}))) return rc;
   if ((rc = run_ntt3_fwd(s, K.log_m, w.coset + 6 * m, P, NttIo{w.pi, n, 0, n, 1, 7 * m, 0, 1}))) return rc;
