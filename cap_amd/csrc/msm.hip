@@ -415,6 +415,96 @@ __global__ __launch_bounds__(1024) void msm_scan(const uint32_t* __restrict__ co
   if (totals && threadIdx.x == 0) totals[blockIdx.x] = carry_s;
 }
 
+// ---- K4 for long tables (a single large MSM): the same exclusive scan in three parallel steps --------------------
+// One workgroup per batch entry walks its table serially in 8192-element strides; that is fine when a launch holds
+// hundreds of entries, but a single 2^17-point MSM has a 524 288-row table and spent 0.55 ms in that walk.  Here every
+// 8192-element segment is scanned by its own workgroup, the segment totals are scanned, and the bases are added.
+constexpr uint32_t kScanSeg = 8192;
+__global__ __launch_bounds__(1024) void msm_scan_seg(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
+                                                     uint32_t nb, uint32_t nseg, uint32_t* __restrict__ seg_tot) {
+  __shared__ uint32_t sh[1024];
+  const uint32_t b = blockIdx.y, sg = blockIdx.x;
+  const uint32_t* cnt = counts + (size_t)b * nb;
+  uint32_t* off = offsets + (size_t)b * nb;
+  const uint32_t idx0 = sg * kScanSeg + threadIdx.x * 8;
+  uint32_t v[8], run = 0;
+#pragma unroll
+  for (uint32_t t = 0; t < 8; t++) {
+    v[t] = run;
+    run += idx0 + t < nb ? cnt[idx0 + t] : 0;
+  }
+  sh[threadIdx.x] = run;
+  __syncthreads();
+  for (uint32_t d = 1; d < 1024; d <<= 1) {
+    uint32_t add = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+    __syncthreads();
+    sh[threadIdx.x] += add;
+    __syncthreads();
+  }
+  const uint32_t pre = sh[threadIdx.x] - run;
+#pragma unroll
+  for (uint32_t t = 0; t < 8; t++)
+    if (idx0 + t < nb) off[idx0 + t] = pre + v[t];
+  if (threadIdx.x == 1023) seg_tot[(size_t)b * nseg + sg] = sh[1023];
+}
+__global__ __launch_bounds__(1024) void msm_scan_tot(uint32_t* __restrict__ seg_tot, uint32_t nseg) {
+  __shared__ uint32_t sh[1024];
+  __shared__ uint32_t carry_s;
+  uint32_t* t = seg_tot + (size_t)blockIdx.x * nseg;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < nseg; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t x = i < nseg ? t[i] : 0;
+    sh[threadIdx.x] = x;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+      uint32_t add = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += add;
+      __syncthreads();
+    }
+    const uint32_t carry = carry_s;
+    if (i < nseg) t[i] = carry + sh[threadIdx.x] - x;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + sh[1023];
+    __syncthreads();
+  }
+}
+__global__ __launch_bounds__(1024) void msm_scan_add(uint32_t* __restrict__ offsets, uint32_t nb, uint32_t nseg,
+                                                     const uint32_t* __restrict__ seg_tot) {
+  const uint32_t b = blockIdx.y, sg = blockIdx.x;
+  const uint32_t base = seg_tot[(size_t)b * nseg + sg];
+  uint32_t* off = offsets + (size_t)b * nb;
+  for (uint32_t i = sg * kScanSeg + threadIdx.x; i < (sg + 1) * kScanSeg && i < nb; i += 1024) off[i] += base;
+}
+
+// bucket = sum of its work items, G lanes per bucket: lanes take items, a shuffle tree adds them up.  For the
+// single-MSM path, where a bucket has tens of items and there are only a few thousand buckets (one thread per bucket
+// is then a 20-deep serial chain on 64 waves: 1.2 ms for 2^17 points).
+template <int G>
+__global__ __launch_bounds__(kThreads) void msm_combine_wave(const g1_xyzz* __restrict__ item_pts,
+                                                             const uint32_t* __restrict__ counts,
+                                                             const uint32_t* __restrict__ item_off,
+                                                             const uint32_t* __restrict__ item_base, uint32_t half,
+                                                             uint32_t total_buckets, uint32_t item_len,
+                                                             g1_xyzz* __restrict__ buckets) {
+  const uint32_t gb = (blockIdx.x * blockDim.x + threadIdx.x) / G, lane = threadIdx.x % G;
+  // whole groups leave together (total_buckets * G threads are launched in whole groups), so the shuffles below
+  // always see their partners
+  if (gb >= total_buckets) return;
+  const uint32_t items = (counts[gb] + item_len - 1) / item_len;
+  const uint32_t first = item_base[gb / half] + item_off[gb];
+  g1x acc = G1L::inf();
+  if (items != 1)  // single-item buckets were written by msm_accumulate
+    for (uint32_t j = lane; j < items; j += G) acc = G1L::add(acc, G1L::load(item_pts[first + j]));
+  for (int d = G / 2; d >= 1; d >>= 1) {
+    g1x o = shfl_down_pt(acc, d);
+    if (lane + d < G) acc = G1L::add(acc, o);
+  }
+  if (lane == 0 && items != 1) buckets[gb] = G1L::store(acc);
+}
+
 // item_base[b] = sum of totals[0..b), item_base[batch] = number of work items of the whole launch
 __global__ void msm_item_bases(const uint32_t* __restrict__ totals, uint32_t batch, uint32_t* __restrict__ item_base) {
   if (blockIdx.x != 0 || threadIdx.x != 0) return;
@@ -704,7 +794,7 @@ size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
   size_t counts, offsets, keys, ranks, sorted, buckets, partial, item_off, item_base, totals, item_bucket, item_sub, item_pts,
-      max_items, table, off2, tloc, chunks, nblk, total;
+      max_items, table, off2, tloc, chunks, nblk, seg_tot, total;
 };
 
 // which table / sort a launch uses
@@ -786,6 +876,10 @@ WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t batch, uint3
   L.off2 = o;        o = align_up(o + sizeof(uint32_t) * bins * L.nblk * batch, 256);
   L.tloc = o;        o = align_up(o + sizeof(uint32_t) * bins * L.nblk * batch, 256);
   L.chunks = o;      o = align_up(o + sizeof(uint32_t) * (size_t)kDigitTile * windows * L.nblk * batch, 256);
+  {
+    size_t rows = std::max<size_t>(bins * L.nblk, half);
+    L.seg_tot = o;   o = align_up(o + sizeof(uint32_t) * ((rows + kScanSeg - 1) / kScanSeg) * batch, 256);
+  }
 
   L.total = o;
   return L;
@@ -871,6 +965,19 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
   const size_t per = (size_t)W * n;
   const uint32_t seg_len = reduce_seg_len(half), nseg = (half + seg_len - 1) / seg_len;
   const uint32_t total_buckets = half * batch;
+  // exclusive scan of `nb` counters per batch entry: one workgroup per entry, or - for the long table of a single
+  // large MSM - segments in parallel
+  uint32_t* seg_tot = reinterpret_cast<uint32_t*>(base + L.seg_tot);
+  auto scan_counts = [&](const uint32_t* in, uint32_t* out, uint32_t nb) {
+    if (nb <= 4 * kScanSeg) {
+      launch("msm_scan", msm_scan<0>, dim3(batch), dim3(1024), 0, stream, in, out, nb, (uint32_t*)nullptr, 0u);
+      return;
+    }
+    const uint32_t ns = (nb + kScanSeg - 1) / kScanSeg;
+    launch("msm_scan_seg", msm_scan_seg, dim3(ns, batch), dim3(1024), 0, stream, in, out, nb, ns, seg_tot);
+    launch("msm_scan_tot", msm_scan_tot, dim3(batch), dim3(1024), 0, stream, seg_tot, ns);
+    launch("msm_scan_add", msm_scan_add, dim3(ns, batch), dim3(1024), 0, stream, out, nb, ns, (const uint32_t*)seg_tot);
+  };
 
   if (L.nblk) {
     const uint32_t nblk = (uint32_t)L.nblk;
@@ -890,8 +997,7 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
     launch("msm_digits_local", msm_digits_local, dim3(nblk * ((batch + 7) / 8) * 8), dim3(kDigitThreads), lds_bytes,
            stream, d_scalars, outer_stride, inner, inner_stride, n, montgomery, c, W, nblk, batch, bases.n, offset,
            pl.sub_bits, table, tloc, chunk_buf);
-    launch("msm_scan", msm_scan<0>, dim3(batch), dim3(1024), 0, stream, (const uint32_t*)table, off2, bins * nblk,
-           (uint32_t*)nullptr, 0u);
+    scan_counts(table, off2, bins * nblk);
     if (pl.sub_bits) {
       // two-level sort: bins are finished per workgroup straight from the tile chunks
       launch("msm_sort_level2", msm_sort_level2, dim3(bins, batch), dim3(kThreads), 0, stream,
@@ -913,8 +1019,7 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
       launch("msm_digits_hist", msm_digits_hist, dim3((unsigned)((nt + kThreads - 1) / kThreads)), dim3(kThreads), 0,
              stream, d_scalars, outer_stride, inner, inner_stride, n, batch, montgomery, c, W, counts, keys, ranks);
     }
-    launch("msm_scan", msm_scan<0>, dim3(batch), dim3(1024), 0, stream, (const uint32_t*)counts, offsets, half,
-           (uint32_t*)nullptr, 0u);
+    scan_counts(counts, offsets, half);
     if (n > 0) {
       size_t ne = per * batch;
       launch("msm_scatter", msm_scatter, dim3((unsigned)((ne + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
@@ -941,9 +1046,18 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
            reinterpret_cast<g1_xyzz*>(base + L.buckets));
   }
   g1_xyzz* buckets = reinterpret_cast<g1_xyzz*>(base + L.buckets);
-  launch("msm_combine", msm_combine, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0, stream,
-         (const g1_xyzz*)item_pts, (const uint32_t*)counts, (const uint32_t*)item_off, (const uint32_t*)item_base, half,
-         total_buckets, item_len, buckets);
+  if (use_segment_reduce(half, batch))
+    launch("msm_combine", msm_combine, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0, stream,
+           (const g1_xyzz*)item_pts, (const uint32_t*)counts, (const uint32_t*)item_off, (const uint32_t*)item_base, half,
+           total_buckets, item_len, buckets);
+  else if (total_buckets <= 8192)  // few buckets with many items each: a wavefront per bucket
+    launch("msm_combine", msm_combine_wave<64>, dim3((unsigned)(((size_t)total_buckets * 64 + kThreads - 1) / kThreads)),
+           dim3(kThreads), 0, stream, (const g1_xyzz*)item_pts, (const uint32_t*)counts, (const uint32_t*)item_off,
+           (const uint32_t*)item_base, half, total_buckets, item_len, buckets);
+  else  // a quarter wavefront per bucket
+    launch("msm_combine", msm_combine_wave<16>, dim3((unsigned)(((size_t)total_buckets * 16 + kThreads - 1) / kThreads)),
+           dim3(kThreads), 0, stream, (const g1_xyzz*)item_pts, (const uint32_t*)counts, (const uint32_t*)item_off,
+           (const uint32_t*)item_base, half, total_buckets, item_len, buckets);
   if (use_segment_reduce(half, batch)) {
     launch("msm_reduce_segments", msm_reduce_segments, dim3((nseg * batch + kThreads - 1) / kThreads), dim3(kThreads),
            0, stream, (const g1_xyzz*)buckets, half, seg_len, nseg, batch, partial);
