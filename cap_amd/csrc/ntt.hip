@@ -391,20 +391,12 @@ int ntt_build_domain(NttDomain* d, uint32_t log_n, hipStream_t stream) {
            (const fe*)src[k], n);
   }
   d->n_inv29 = Fr29::pack(Fr29::canonical(Fr29::from_ext(d->n_inv)));
-  // 5^i * 2^266 = internal form of (5^i * 32): build 32 * 5^i in arkworks form, then convert
-  {
-    fe k32 = host_from_u64(32);
-    if ((e = hipMalloc(&d->coset29_fwd_x32, sizeof(fe) * n)) != hipSuccess) return (int)e;
-    if ((rc = build_powers(d->coset29_fwd_x32, n, g, &k32, stream))) return rc;
-    launch("table_to_internal", table_to_internal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
-           d->coset29_fwd_x32, (const fe*)d->coset29_fwd_x32, n);
-  }
   if ((e = hipStreamSynchronize(stream)) != hipSuccess) return (int)e;
-  // omega^j (tw_fwd) is still read in arkworks' form by other kernels; coset_inv doubles as the internal -> arkworks
-  // scaling table of the inverse coset transform
+  // only omega^j (tw_fwd) is still read in arkworks' form (by the prover's elementwise kernels)
   hipFree(d->tw_inv);
   hipFree(d->coset_fwd);
-  d->tw_inv = d->coset_fwd = nullptr;
+  hipFree(d->coset_inv);
+  d->tw_inv = d->coset_fwd = d->coset_inv = nullptr;
   return 0;
 }
 
@@ -413,10 +405,10 @@ void ntt_free_domain(NttDomain* d) {
   if (d->tw_inv) hipFree(d->tw_inv);
   if (d->coset_fwd) hipFree(d->coset_fwd);
   if (d->coset_inv) hipFree(d->coset_inv);
-  for (fe* t : {d->tw29_fwd, d->tw29_inv, d->coset29_fwd, d->coset29_inv, d->coset29_fwd_x32})
+  for (fe* t : {d->tw29_fwd, d->tw29_inv, d->coset29_fwd, d->coset29_inv})
     if (t) hipFree(t);
   d->tw_fwd = d->tw_inv = d->coset_fwd = d->coset_inv = nullptr;
-  d->tw29_fwd = d->tw29_inv = d->coset29_fwd = d->coset29_inv = d->coset29_fwd_x32 = nullptr;
+  d->tw29_fwd = d->tw29_inv = d->coset29_fwd = d->coset29_inv = nullptr;
 }
 
 void ntt_table_to_internal(fe* out, const fe* in, size_t n, hipStream_t stream) {
@@ -425,9 +417,7 @@ void ntt_table_to_internal(fe* out, const fe* in, size_t n, hipStream_t stream) 
 }
 
 int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scratch, size_t stride_elems,
-            uint32_t count, int dir, int coset, hipStream_t stream, int io_form, const NttIo* io) {
-  if ((io_form == kNttOutInternal && (dir || !coset)) || (io_form == kNttInInternal && (!dir || !coset)))
-    return (int)hipErrorInvalidValue;
+            uint32_t count, int dir, int coset, hipStream_t stream, const NttIo* io) {
   const uint32_t log_n = dom.log_n;
   if (count == 0) return 0;
   if (log_n == 0) {
@@ -488,7 +478,7 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
   p.tw_full = tw_full;
   p.use_post_scalar = 0;
 
-  const fe* pre = (!dir && coset) ? (io_form == kNttOutInternal ? dom.coset29_fwd_x32 : dom.coset29_fwd) : nullptr;
+  const fe* pre = (!dir && coset) ? dom.coset29_fwd : nullptr;
   if (io && io->pre_scale) pre = io->pre_scale;
   bool first = true;
   const fe* cur_in = io ? io->src : data;
@@ -531,10 +521,10 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
     set_out(a_dst);
     p.tw_small = reinterpret_cast<const fl*>(tws[log_len]);
     p.pre_scale = first ? pre : nullptr;
-    p.post_scale = (dir && coset) ? (io_form == kNttInInternal ? dom.coset_inv : dom.coset29_inv) : nullptr;
+    p.post_scale = (dir && coset) ? dom.coset29_inv : nullptr;
     p.use_post_scalar = (dir && !coset) ? 1 : 0;
     p.post_scalar = dom.n_inv29;
-    p.lazy_out = (io_form == kNttOutInternal || (io && io->lazy_out)) ? 1 : 0;
+    p.lazy_out = (io && io->lazy_out) ? 1 : 0;
     p.log_len = log_len;
     p.log_c = log_c;
     p.log_n1 = log_n1;
@@ -627,7 +617,7 @@ int ntt3_forward(const Ntt3Domain& d3, const NttDomain& dom_m, const NttSmallTab
   sub.dst_outer = M;
   sub.dst_inner = 0;
   sub.dst_group = 1;
-  int rc = ntt_run(dom_m, small, y, sub_scratch, M, count * 3, 0, 0, stream, 0, &sub);
+  int rc = ntt_run(dom_m, small, y, sub_scratch, M, count * 3, 0, 0, stream, &sub);
   if (rc) return rc;
   launch("ntt3_combine", ntt3_combine, dim3((unsigned)((M + kThreads - 1) / kThreads), count), dim3(kThreads), 0, stream,
          (const fe*)y, data, io.dst_outer, io.dst_inner, io.dst_group ? io.dst_group : 1u, M, (const fe*)d3.tw29, d3.w3_29,
@@ -654,7 +644,7 @@ int ntt3_inverse(const Ntt3Domain& d3, const NttDomain& dom_m, const NttSmallTab
   sub.dst_group = 1;
   // inverse sub-transforms (their 1 / M is applied inside), then the radix-3 stage with inverse twiddles and the
   // coset / 1/3 / form-changing table
-  int rc = ntt_run(dom_m, small, y, sub_scratch, M, count * 3, 1, 0, stream, 0, &sub);
+  int rc = ntt_run(dom_m, small, y, sub_scratch, M, count * 3, 1, 0, stream, &sub);
   if (rc) return rc;
   launch("ntt3_combine", ntt3_combine, dim3((unsigned)((M + kThreads - 1) / kThreads), count), dim3(kThreads), 0, stream,
          (const fe*)y, data, N, (size_t)0, 1u, M, (const fe*)d3.tw29_inv, d3.w3inv_29, (const fe*)d3.coset_inv_ext);

@@ -28,15 +28,7 @@ struct NttDomain {
   fe* coset29_fwd = nullptr;
   fe* coset29_inv = nullptr;
   fe n_inv29;
-  // form-changing coset tables (kNttOutInternal / kNttInInternal below)
-  fe* coset29_fwd_x32 = nullptr;  // 5^i * 2^266: forward coset transform of arkworks-form data -> internal-form output
-                                  // (coset_inv, the arkworks-form table n^-1 5^-i 2^256, does the reverse on the way back)
 };
-
-// io_form flags of ntt_run: the quotient kernel works on internal-form (x * 2^261) data; the transforms feeding and
-// draining it change the form for free through their coset-scaling multiplication.
-constexpr int kNttOutInternal = 1;  // forward coset transform: arkworks-form input, internal-form output
-constexpr int kNttInInternal = 2;   // inverse coset transform: internal-form input, arkworks-form (canonical) output
 
 // Small-size twiddles shared by every domain (internal form): fwd[s] -> omega_{2^s}^i, i < 2^(s-1), s <= kMaxLogTile
 constexpr int kMaxLogTile = 11;
@@ -80,7 +72,7 @@ struct NttIo {
   int lazy_out = 0;               // leave results weakly reduced (< 2r) instead of canonical
 };
 int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scratch, size_t stride_elems,
-            uint32_t count, int dir, int coset, hipStream_t stream, int io_form = 0, const NttIo* io = nullptr);
+            uint32_t count, int dir, int coset, hipStream_t stream, const NttIo* io = nullptr);
 
 // ---- transforms of size N = 3 * 2^k -------------------------------------------------------------------------
 // The quotient polynomial of the prover has degree < 5n + 8, so a coset of 6n = 3 * 2^(log n + 1) points carries it;

@@ -172,28 +172,14 @@ void scan_exclusive(hipStream_t s, const fe* in, fe* out, size_t len, size_t str
   }
 }
 
-int run_ntt(hipStream_t s, uint32_t log_n, fe* data, size_t stride, uint32_t count, int dir, int coset, int io_form = 0) {
+int run_ntt(hipStream_t s, uint32_t log_n, fe* data, size_t stride, uint32_t count, int dir, int coset) {
   Context& c = ctx();
   const NttDomain* dom = nullptr;
   int rc = get_domain(log_n, &dom);
   if (rc) return rc;
   rc = scratch_reserve(c.ntt_scratch, sizeof(fe) * stride * count);
   if (rc) return rc;
-  rc = ntt_run(*dom, c.small, data, (fe*)c.ntt_scratch.p, stride, count, dir, coset, s, io_form);
-  if (rc) return hip_fail((hipError_t)rc, "ntt_run");
-  return CAPGPU_OK;
-}
-
-// out-of-place transform: short inputs are zero-extended on the fly (no padded copy in memory), see NttIo
-int run_ntt_io(hipStream_t s, uint32_t log_n, fe* data, uint32_t count, int dir, int coset, int io_form,
-               const NttIo& io) {
-  Context& c = ctx();
-  const NttDomain* dom = nullptr;
-  int rc = get_domain(log_n, &dom);
-  if (rc) return rc;
-  rc = scratch_reserve(c.ntt_scratch, (sizeof(fe) << log_n) * count);
-  if (rc) return rc;
-  rc = ntt_run(*dom, c.small, data, (fe*)c.ntt_scratch.p, (size_t)1 << log_n, count, dir, coset, s, io_form, &io);
+  rc = ntt_run(*dom, c.small, data, (fe*)c.ntt_scratch.p, stride, count, dir, coset, s);
   if (rc) return hip_fail((hipError_t)rc, "ntt_run");
   return CAPGPU_OK;
 }

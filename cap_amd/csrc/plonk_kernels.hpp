@@ -206,7 +206,7 @@ __global__ __launch_bounds__(kThreads) void k_perm_finish(const fe* __restrict__
 // ---- round 3: fused quotient evaluation on the coset of size m = 6n ----------------------------------
 // (jf-plonk uses 8n; the quotient has degree < 5n + 8, so 6n = 3 * 2^(log n + 1) points determine it - ntt.hpp)
 // All inputs are in the internal Montgomery form of the lazy 29-bit field (x * 2^261): the forward coset NTTs emit
-// it (kNttOutInternal) and the inverse coset NTT that follows consumes it (kNttInInternal).
+// it (ntt3_forward) and the inverse coset NTT that follows consumes it (ntt3_inverse).
 // pkc: [18][m] coset evaluations of 13 selectors then 5 sigmas (shared by all proofs)
 // cos: [P][7][m] coset evaluations of 5 wires, z, pi;   tw_m: omega_m^i;   inv_nx1: 1 / (n (x_i - 1))
 // Sums of products share one Montgomery reduction (at most 6 products per 64-bit column accumulator).
