@@ -77,21 +77,24 @@ def msm_leg(cg, bu, torch, dist, rank, world, log_n, iters=5, coll_dev="cuda"):
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
+    # the timed region is the whole sharded MSM: local Pippenger, the one exchange step (all-gather of a 96-byte
+    # partial per rank) and the G - 1 additions of the partials
     t0 = time.perf_counter()
     for _ in range(iters):
         cg.msm_g1_dev(srs, d_sc, n, d_out=d_out)
+        part = d_out.to_numpy()                    # synchronises: the partial sum leaves the device here
+        if dist is not None:
+            parts = par.all_gather_points(part, device=coll_dev)
+            total = cg.g1_sum(parts)
+        else:
+            total = part
     cg.sync()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
-    part = d_out.to_numpy()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        parts = par.all_gather_points(part, device=coll_dev)
-        total = cg.g1_sum(parts)
-    else:
-        total = part
     ok = None
     if rank == 0:
         s0, s1 = _weighted_sums(sc, 0)
@@ -135,7 +138,7 @@ def main():
                     help="nccl (= RCCL, the real multi-GPU path); gloo only to exercise the N>1 logic on a 1-GPU box "
                          "together with CAPGPU_BENCH_DEVICE=0")
     ap.add_argument("--no-msm", action="store_true")
-    ap.add_argument("--msm-log-n", type=int, default=20, help="size of the sharded MSM leg (24 = BASELINE config 5)")
+    ap.add_argument("--msm-log-n", type=int, default=22, help="size of the sharded MSM leg (24 = BASELINE config 5)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

@@ -11,7 +11,8 @@ from cap_amd import bench_utils as bu  # noqa: E402
 
 cg.init(0)
 out = {}
-for log_n in (17, 20):
+import os
+for log_n in [int(x) for x in os.environ.get('MSM_LOGS','17,20').split(',')]:
     n = 1 << log_n
     h = cg.srs_generate(0x1234567, n)
     rng = np.random.default_rng(log_n)
