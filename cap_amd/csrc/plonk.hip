@@ -338,7 +338,17 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
     hj.resize(count);
     CAP_HIP(hipMemcpyAsync(hj.data(), w.comms, sizeof(g1_jac) * count, hipMemcpyDeviceToHost, s));
     CAP_HIP(hipStreamSynchronize(s));
-    batch_to_affine(hj, ha);
+    // Jacobian -> affine on the host while the GPU waits for the next challenge: chunks of 64 points (one shared
+    // inversion each) spread over the pool instead of one serial pass over up to 5P points
+    ha.resize(count);
+    const uint32_t chunk = 64, nchunks = (count + chunk - 1) / chunk;
+    parallel_for(nchunks, [&](uint32_t ci) {
+      const uint32_t lo = ci * chunk, hi = std::min(count, lo + chunk);
+      std::vector<g1_jac> in(hj.begin() + lo, hj.begin() + hi);
+      std::vector<g1_affine> out;
+      batch_to_affine(in, out);
+      std::copy(out.begin(), out.end(), ha.begin() + lo);
+    });
     return CAPGPU_OK;
   };
 
