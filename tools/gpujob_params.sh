@@ -3,4 +3,4 @@
 tag=$1
 mkdir -p gpurun_out
 python tools/gpu_time_params.py > gpurun_out/params_timing_$tag.json 2> gpurun_out/params_timing_$tag.err; cat gpurun_out/params_timing_$tag.json; tail -3 gpurun_out/params_timing_$tag.err
-bash tools/gpujob5.sh $tag
+bash tools/gpujob_main.sh $tag
