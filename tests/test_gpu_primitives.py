@@ -210,6 +210,29 @@ def test_msm_skewed_scalars_in_a_large_batch(cg, tau):
     cg.srs_free(h)
 
 
+@pytest.mark.parametrize("n,batch,offset", [(4096, 32, 0), (5000, 33, 7), (20011, 40, 100), (65539, 32, 0)])
+def test_msm_wide_window_path_vs_single_path(cg, tau, n, batch, offset):
+    """Batches of >= 32 MSMs over >= 4096 points take the c = 15 table and the two-level sort; the same MSMs run one
+    at a time take c = 13 and the bit-plane reduction.  Odd sizes, a base offset, Montgomery-form scalars; one member
+    of every batch is also checked against the known-tau identity."""
+    h = cg.srs_generate(tau, n + offset)
+    rng = np.random.default_rng(n + batch)
+    sc = rng.integers(0, 1 << 63, size=(batch, n, 4), dtype=np.uint64) * 2 + rng.integers(0, 2, size=(batch, n, 4), dtype=np.uint64)
+    sc[:, :, 3] &= np.uint64((1 << 60) - 1)                     # < 2^252: canonical
+    sc[1, :17] = 0                                               # a run of zero scalars
+    got = cg.msm_g1_batch(h, [sc[b] for b in range(batch)], offsets=[offset] * batch)
+    for b in (0, 1, batch // 2, batch - 1):
+        one = cg.msm_g1(h, sc[b], offset=offset)
+        assert np.array_equal(cr.g1_to_affine(got[b]), cr.g1_to_affine(one)), b
+    ks = [int(w[0]) | int(w[1]) << 64 | int(w[2]) << 128 | int(w[3]) << 192 for w in sc[0]]
+    acc, x = 0, pow(tau, offset, bn.R)
+    for k in ks:
+        acc = (acc + k * x) % bn.R
+        x = x * tau % bn.R
+    assert cr.affine_to_ints(cr.g1_to_affine(got[0])) == bn.g1_mul(bn.G1_GEN, acc)
+    cg.srs_free(h)
+
+
 def test_msm_affine_seq_bases(cg):
     """BASELINE config 5's synthetic bases P_i = [a + i b]G: sum k_i P_i = [sum k_i (a + i b)] G."""
     a, b, n = 12345678901234567890, 987654321987654321, 5000
