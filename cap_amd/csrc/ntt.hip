@@ -46,6 +46,9 @@ struct PassParams {
   uint32_t in_group2;
   size_t out_outer, out_inner;
   uint32_t out_group;
+  size_t out_inner2;         // second grouping level of the output, like in_group2 / in_inner2
+  uint32_t out_group2;
+  size_t pre_inner;          // the pre-scale table of array q starts at (q % in_group) * pre_inner
   const fl* tw_small;        // omega_len^i, i < len/2, unpacked limbs
   const fe* tw_full;         // omega_N^e, e < N (col pass twiddles); may be null for row pass
   const fe* pre_scale;       // indexed by global input index, or null
@@ -143,7 +146,9 @@ __global__ __launch_bounds__(kThreads) void ntt_col_pass(PassParams p) {
   const uint32_t q2 = blockIdx.y / p.in_group;
   const fe* in = p.in + (size_t)(q2 / p.in_group2) * p.in_outer + (size_t)(q2 % p.in_group2) * p.in_inner2 +
                  (size_t)(blockIdx.y % p.in_group) * p.in_inner;
-  fe* out = p.out + (size_t)(blockIdx.y / p.out_group) * p.out_outer + (size_t)(blockIdx.y % p.out_group) * p.out_inner;
+  const uint32_t o2 = blockIdx.y / p.out_group;
+  fe* out = p.out + (size_t)(o2 / p.out_group2) * p.out_outer + (size_t)(o2 % p.out_group2) * p.out_inner2 +
+            (size_t)(blockIdx.y % p.out_group) * p.out_inner;
   const size_t base = (seg << p.log_m) + col0;
   const uint32_t tile = 1u << (p.log_len + p.log_c);
   const uint32_t cmask = (1u << p.log_c) - 1;
@@ -163,7 +168,8 @@ __global__ __launch_bounds__(kThreads) void ntt_col_pass(PassParams p) {
       for (int k = 0; k < 8; k++) raw.v[k] = 0;
     }
     fl v = Fr29::load(raw);
-    if (p.pre_scale && any) v = Fr29::mul(v, Fr29::load(p.pre_scale[sg]));  // zero padding needs no coset scaling
+    if (p.pre_scale && any)  // zero padding needs no coset scaling
+      v = Fr29::mul(v, Fr29::load(p.pre_scale[sg + (size_t)(blockIdx.y % p.in_group) * p.pre_inner]));
     sh[(bitrev32(j, p.log_len) << p.log_c) + c] = v;
   }
   __syncthreads();
@@ -188,7 +194,9 @@ __global__ __launch_bounds__(kThreads) void ntt_row_pass(PassParams p) {
   const uint32_t q2 = blockIdx.y / p.in_group;
   const fe* in = p.in + (size_t)(q2 / p.in_group2) * p.in_outer + (size_t)(q2 % p.in_group2) * p.in_inner2 +
                  (size_t)(blockIdx.y % p.in_group) * p.in_inner;
-  fe* out = p.out + (size_t)(blockIdx.y / p.out_group) * p.out_outer + (size_t)(blockIdx.y % p.out_group) * p.out_inner;
+  const uint32_t o2 = blockIdx.y / p.out_group;
+  fe* out = p.out + (size_t)(o2 / p.out_group2) * p.out_outer + (size_t)(o2 % p.out_group2) * p.out_inner2 +
+            (size_t)(blockIdx.y % p.out_group) * p.out_inner;
   const uint32_t tile = 1u << (p.log_len + p.log_c);
   const uint32_t lmask = (1u << p.log_len) - 1;
   const uint32_t cmask = (1u << p.log_c) - 1;
@@ -208,7 +216,8 @@ __global__ __launch_bounds__(kThreads) void ntt_row_pass(PassParams p) {
       for (int k = 0; k < 8; k++) raw.v[k] = 0;
     }
     fl v = Fr29::load(raw);
-    if (p.pre_scale && any) v = Fr29::mul(v, Fr29::load(p.pre_scale[sg]));  // zero padding needs no coset scaling
+    if (p.pre_scale && any)  // zero padding needs no coset scaling
+      v = Fr29::mul(v, Fr29::load(p.pre_scale[sg + (size_t)(blockIdx.y % p.in_group) * p.pre_inner]));
     sh[(bitrev32(j, p.log_len) << p.log_c) + c] = v;
   }
   __syncthreads();
@@ -473,7 +482,14 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
     p.out_outer = a.outer;
     p.out_inner = a.inner;
     p.out_group = a.group;
+    p.out_group2 = 1;
+    p.out_inner2 = 0;
+    if (&a == &a_dst && io && io->dst_group2 > 1) {
+      p.out_group2 = io->dst_group2;
+      p.out_inner2 = io->dst_inner2;
+    }
   };
+  p.pre_inner = io ? io->pre_inner : 0;
   p.log_n = log_n;
   p.tw_full = tw_full;
   p.use_post_scalar = 0;
@@ -563,34 +579,40 @@ int ntt3_build_domain(Ntt3Domain* d, uint32_t log_m, hipStream_t stream) {
   size_t c = (M % 3 == 2) ? (M + 1) / 3 : (2 * M + 1) / 3;
   if (M == 1) c = 1;
   uint32_t ec[8] = {(uint32_t)c, (uint32_t)((uint64_t)c >> 32), 0, 0, 0, 0, 0, 0};
-  const fe wN = Fr::mul(w3gen, Fr::pow(host_root_of_unity(log_m), ec));
+  const fe wM = host_root_of_unity(log_m);
+  const fe wN = Fr::mul(w3gen, Fr::pow(wM, ec));
   d->omega = wN;
   uint32_t eM[8] = {(uint32_t)M, (uint32_t)((uint64_t)M >> 32), 0, 0, 0, 0, 0, 0};
   const fe w3 = Fr::pow(wN, eM);
   auto to_internal = [](const fe& a) { return Fr29::pack(Fr29::canonical(Fr29::from_ext(a))); };
-  d->w3_29 = to_internal(w3);
   d->w3inv_29 = to_internal(Fr::inv(w3));
   hipError_t e;
-  for (fe** t : {&d->tw_ext, &d->tw29, &d->tw29_inv, &d->coset29_x32, &d->coset_inv_ext})
-    if ((e = hipMalloc(t, sizeof(fe) * N)) != hipSuccess) return (int)e;
+  if ((e = hipMalloc(&d->xs_ext, sizeof(fe) * N)) != hipSuccess) return (int)e;
+  if ((e = hipMalloc(&d->xs29, sizeof(fe) * N)) != hipSuccess) return (int)e;
+  if ((e = hipMalloc(&d->pre3, sizeof(fe) * N)) != hipSuccess) return (int)e;
+  if ((e = hipMalloc(&d->tw29_inv, sizeof(fe) * 2 * M)) != hipSuccess) return (int)e;
+  if ((e = hipMalloc(&d->coset_inv_ext, sizeof(fe) * N)) != hipSuccess) return (int)e;
   int rc;
-  if ((rc = build_powers(d->tw_ext, N, wN, nullptr, stream))) return rc;
-  if ((rc = build_powers(d->tw29_inv, N, Fr::inv(wN), nullptr, stream))) return rc;
   const fe k32 = host_from_u64(32);
-  if ((rc = build_powers(d->coset29_x32, N, g, &k32, stream))) return rc;
+  fe s_a = g;  // 5 * omega_N^a
+  for (int a = 0; a < 3; a++) {
+    if ((rc = build_powers(d->xs_ext + (size_t)a * M, M, wM, &s_a, stream))) return rc;   // s_a * omega_M^k
+    if ((rc = build_powers(d->pre3 + (size_t)a * M, M, s_a, &k32, stream))) return rc;     // 32 * s_a^i
+    s_a = Fr::mul(s_a, wN);
+  }
+  if ((rc = build_powers(d->tw29_inv, 2 * M, Fr::inv(wN), nullptr, stream))) return rc;
   const fe third = Fr::inv(host_from_u64(3));
   if ((rc = build_powers(d->coset_inv_ext, N, Fr::inv(g), &third, stream))) return rc;
   const unsigned blocks = (unsigned)((N + 255) / 256);
-  launch("table_to_internal", table_to_internal, dim3(blocks), dim3(256), 0, stream, d->tw29, (const fe*)d->tw_ext, N);
-  launch("table_to_internal", table_to_internal, dim3(blocks), dim3(256), 0, stream, d->tw29_inv,
-         (const fe*)d->tw29_inv, N);
-  launch("table_to_internal", table_to_internal, dim3(blocks), dim3(256), 0, stream, d->coset29_x32,
-         (const fe*)d->coset29_x32, N);
+  launch("table_to_internal", table_to_internal, dim3(blocks), dim3(256), 0, stream, d->xs29, (const fe*)d->xs_ext, N);
+  launch("table_to_internal", table_to_internal, dim3(blocks), dim3(256), 0, stream, d->pre3, (const fe*)d->pre3, N);
+  launch("table_to_internal", table_to_internal, dim3((unsigned)((2 * M + 255) / 256)), dim3(256), 0, stream,
+         d->tw29_inv, (const fe*)d->tw29_inv, 2 * M);
   return (int)hipStreamSynchronize(stream);
 }
 
 void ntt3_free_domain(Ntt3Domain* d) {
-  for (fe** t : {&d->tw_ext, &d->tw29, &d->tw29_inv, &d->coset29_x32, &d->coset_inv_ext}) {
+  for (fe** t : {&d->xs_ext, &d->xs29, &d->pre3, &d->tw29_inv, &d->coset_inv_ext}) {
     if (*t) hipFree(*t);
     *t = nullptr;
   }
@@ -600,29 +622,25 @@ int ntt3_forward(const Ntt3Domain& d3, const NttDomain& dom_m, const NttSmallTab
                  uint32_t count, fe* scratch, hipStream_t stream) {
   if (dom_m.log_n != d3.log_m) return (int)hipErrorInvalidValue;
   const size_t M = (size_t)1 << d3.log_m;
-  fe* y = scratch;                            // [count][3][M]
-  fe* sub_scratch = scratch + (size_t)count * 3 * M;
-  // three decimated sub-transforms per polynomial, in one batched launch: array 3 q + a reads src_q[3 j + a]
+  if (io.src_len > M) return (int)hipErrorInvalidValue;
+  // array 3 q + a: the same polynomial q, pre-scaled by the powers of s_a, transformed, written to block a
   NttIo sub{};
   sub.src = io.src;
   sub.src_outer = io.src_outer;
-  sub.src_inner = 1;
+  sub.src_inner = 0;
   sub.src_group = 3;
   sub.src_group2 = io.src_group ? io.src_group : 1;  // the caller's own grouping moves one level up
   sub.src_inner2 = io.src_inner;
   sub.src_len = io.src_len;
-  sub.src_elem_stride = 3;
-  sub.pre_scale = d3.coset29_x32;
+  sub.pre_scale = d3.pre3;
+  sub.pre_inner = M;
   sub.lazy_out = 1;
-  sub.dst_outer = M;
-  sub.dst_inner = 0;
-  sub.dst_group = 1;
-  int rc = ntt_run(dom_m, small, y, sub_scratch, M, count * 3, 0, 0, stream, &sub);
-  if (rc) return rc;
-  launch("ntt3_combine", ntt3_combine, dim3((unsigned)((M + kThreads - 1) / kThreads), count), dim3(kThreads), 0, stream,
-         (const fe*)y, data, io.dst_outer, io.dst_inner, io.dst_group ? io.dst_group : 1u, M, (const fe*)d3.tw29, d3.w3_29,
-         (const fe*)nullptr);
-  return (int)hipGetLastError();
+  sub.dst_outer = io.dst_outer;
+  sub.dst_inner = M;
+  sub.dst_group = 3;
+  sub.dst_group2 = io.dst_group ? io.dst_group : 1;
+  sub.dst_inner2 = io.dst_inner;
+  return ntt_run(dom_m, small, data, scratch, M, count * 3, 0, 0, stream, &sub);
 }
 
 int ntt3_inverse(const Ntt3Domain& d3, const NttDomain& dom_m, const NttSmallTables& small, fe* data, uint32_t count,
@@ -634,15 +652,14 @@ int ntt3_inverse(const Ntt3Domain& d3, const NttDomain& dom_m, const NttSmallTab
   NttIo sub{};
   sub.src = data;
   sub.src_outer = N;
-  sub.src_inner = 1;
+  sub.src_inner = M;  // block a of array q
   sub.src_group = 3;
-  sub.src_len = N;
-  sub.src_elem_stride = 3;
+  sub.src_len = M;
   sub.lazy_out = 1;
   sub.dst_outer = M;
   sub.dst_inner = 0;
   sub.dst_group = 1;
-  // inverse sub-transforms (their 1 / M is applied inside), then the radix-3 stage with inverse twiddles and the
+  // inverse sub-transforms of the three blocks (their 1 / M is applied inside), then the radix-3 stage with the
   // coset / 1/3 / form-changing table
   int rc = ntt_run(dom_m, small, y, sub_scratch, M, count * 3, 1, 0, stream, &sub);
   if (rc) return rc;

@@ -68,37 +68,45 @@ struct NttIo {
   uint32_t src_elem_stride = 1;
   uint32_t src_group2 = 1;        // second grouping level above src_group (see PassParams::in_group2)
   size_t src_inner2 = 0;
+  uint32_t dst_group2 = 1;        // the same for the output
+  size_t dst_inner2 = 0;
+  size_t pre_inner = 0;           // pre-scale table of array q: pre_scale + (q % src_group) * pre_inner
   const fe* pre_scale = nullptr;  // overrides the coset table of the domain (internal form)
   int lazy_out = 0;               // leave results weakly reduced (< 2r) instead of canonical
 };
 int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scratch, size_t stride_elems,
             uint32_t count, int dir, int coset, hipStream_t stream, const NttIo* io = nullptr);
 
-// ---- transforms of size N = 3 * 2^k -------------------------------------------------------------------------
-// The quotient polynomial of the prover has degree < 5n + 8, so a coset of 6n = 3 * 2^(log n + 1) points carries it;
-// jf-plonk evaluates on 8n only because it wants a power of two.  One such transform = three power-of-two transforms
-// of the decimated input (x[3j + a], a = 0, 1, 2) followed by one radix-3 stage:
-//   X[k + M b] = Y_0[k] + w3^b omega_N^k Y_1[k] + w3^(2b) omega_N^(2k) Y_2[k],   M = 2^k, w3 = omega_N^M.
-// omega_N = omega_3 * omega_M^c with 3c = 1 (mod M): then omega_N^3 = omega_M (the sub-transforms are the ordinary
-// ones) and omega_N^6 = omega_{M/2} (a shift by six points multiplies x by the generator of the size-n domain).
+// ---- evaluation on N = 3 * 2^k points ------------------------------------------------------------------------
+// The quotient polynomial of the prover has degree < 5n + 8, so 6n = 3 * 2^(log n + 1) points carry it; jf-plonk
+// evaluates on 8n only because it wants a power of two.  With M = 2^k = 2n and omega_N = omega_3 * omega_M^c,
+// 3c = 1 (mod M)  (so omega_N^3 = omega_M and omega_N^6 = omega_n), the coset 5 <omega_N> is the union of the three
+// cosets s_a <omega_M>, s_a = 5 omega_N^a, a = 0, 1, 2, and the evaluations are kept in that order:
+//   index a M + k  <->  the point s_a omega_M^k          ("next row", x omega_n, is index a M + (k + 2 mod M)).
+// Forward: the evaluations of a polynomial with at most M coefficients on the three cosets are three ordinary
+// M-point coset transforms of the SAME zero-extended input - no radix-3 stage, no strided access.
+// Inverse (the quotient, up to 3M coefficients): three ordinary inverse transforms of the blocks, then one radix-3
+// stage:  t[k + M b] = 5^-(k + M b) / 3 * (Y0[k] + w3^-b omega_N^-k Y1[k] + w3^-2b omega_N^-2k Y2[k]),  w3 = omega_N^M.
 struct Ntt3Domain {
   uint32_t log_m = 0;           // M = 2^log_m, N = 3 M
-  fe* tw_ext = nullptr;         // omega_N^i, i < N, arkworks form
-  fe* tw29 = nullptr;           // omega_N^i, internal form
-  fe* tw29_inv = nullptr;       // omega_N^-i, internal form
-  fe* coset29_x32 = nullptr;    // 32 * 5^i, internal form: forward pre-scale, arkworks-form data in, internal out
-  fe* coset_inv_ext = nullptr;  // 5^-i / 3 as an arkworks-form integer: inverse post-scale, internal in, arkworks out
-  fe w3_29, w3inv_29;           // omega_N^M and its inverse, internal form
+  fe* xs_ext = nullptr;         // the N points in the order above, arkworks form
+  fe* xs29 = nullptr;           // the same, internal form
+  fe* pre3 = nullptr;           // [3][M]: 32 * s_a^i, internal form: pre-scale of the forward sub-transform a
+                                //         (arkworks-form coefficients in, internal-form evaluations out)
+  fe* tw29_inv = nullptr;       // omega_N^-i, i < 2M, internal form (inverse radix-3 stage)
+  fe* coset_inv_ext = nullptr;  // 5^-i / 3, i < N, as an arkworks-form integer: internal-form data in, arkworks out
+  fe w3inv_29;                  // omega_N^-M, internal form
   fe omega;                     // omega_N, arkworks form (host)
 };
 int ntt3_build_domain(Ntt3Domain* d, uint32_t log_m, hipStream_t stream);
 void ntt3_free_domain(Ntt3Domain* d);
-// Forward coset transform (generator 5) of `count` polynomials: arkworks-form coefficients read through `io`
-// (zero-extended beyond io.src_len; io.src_elem_stride / pre_scale / lazy_out are set here), internal-form
-// evaluations (weakly reduced) written through io's dst addressing.  dom_m: the 2^log_m domain.  scratch: 6 N count.
+// Forward: `count` polynomials (arkworks-form coefficients read through `io`, zero-extended beyond io.src_len <= M) ->
+// internal-form evaluations (weakly reduced) in the block order above, written through io's dst addressing.
+// dom_m: the 2^log_m domain.  scratch: 3 M count elements.
 int ntt3_forward(const Ntt3Domain& d3, const NttDomain& dom_m, const NttSmallTables& small, fe* data, NttIo io,
                  uint32_t count, fe* scratch, hipStream_t stream);
-// Inverse coset transform in place: data[q * N .. +N) internal-form evaluations -> arkworks-form coefficients.
+// Inverse in place: data[q * N .. +N) internal-form evaluations (block order) -> arkworks-form coefficients (natural
+// order, canonical).  scratch: 6 M count elements.
 int ntt3_inverse(const Ntt3Domain& d3, const NttDomain& dom_m, const NttSmallTables& small, fe* data, uint32_t count,
                  fe* scratch, hipStream_t stream);
 

@@ -422,7 +422,7 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
     pkc = w.pkc;
   }
   launch("k_quotient", k_quotient, dim3(P, cdiv(m, kThreads)), dim3(kThreads), 0, s, pkc, (const fe*)w.coset,
-         (const fe*)dom_q->tw29, (const fe*)K.inv_nx1, (const Chal*)w.chal29, K.qc29, m, w.t);
+         (const fe*)dom_q->xs29, (const fe*)K.inv_nx1, (const Chal*)w.chal29, K.qc29, m, w.t);
   if ((rc = run_ntt3_inv(s, K.log_m, w.t, P))) return rc;
   {
     size_t lo = NW * (n + 1) + 3;  // first index that must be zero: degree is exactly 5(n+1)+2
@@ -628,8 +628,8 @@ int key_finish_tables(hipStream_t s, ProvingKey& K) {
   }
   const Ntt3Domain* dom_m = nullptr;
   if ((rc = get_domain3(K.log_m, &dom_m))) return rc;
-  launch("k_inv_nx1", k_inv_nx1, dim3(cdiv(m, kThreads)), dim3(kThreads), 0, s, K.inv_nx1, (const fe*)dom_m->tw_ext,
-         K.qc.g, fr_from_u64((uint64_t)n), m);
+  launch("k_inv_nx1", k_inv_nx1, dim3(cdiv(m, kThreads)), dim3(kThreads), 0, s, K.inv_nx1, (const fe*)dom_m->xs_ext,
+         fr_from_u64((uint64_t)n), m);
   ntt_table_to_internal(K.inv_nx1, K.inv_nx1, m, s);
   {
     auto conv = [](const fe& a) { return Fr29::pack(Fr29::canonical(Fr29::from_ext(a))); };

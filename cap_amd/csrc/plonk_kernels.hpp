@@ -226,7 +226,7 @@ struct ColAcc {
 };
 
 __global__ __launch_bounds__(kThreads) void k_quotient(const fe* __restrict__ pkc, const fe* __restrict__ cos,
-                                                       const fe* __restrict__ tw_m,
+                                                       const fe* __restrict__ xs,
                                                        const fe* __restrict__ inv_nx1,
                                                        const Chal* __restrict__ chal, QuotConst qc, size_t m,
                                                        fe* __restrict__ t_out) {
@@ -236,6 +236,8 @@ __global__ __launch_bounds__(kThreads) void k_quotient(const fe* __restrict__ pk
   size_t i = (size_t)blockIdx.y * blockDim.x + threadIdx.x;
   if (i >= m) return;
   const uint32_t p = blockIdx.x;
+  const uint32_t mm = (uint32_t)(m / 3);                                  // block length M (uniform: scalar unit)
+  const uint32_t blk = (i >= mm ? 1u : 0u) + (i >= 2 * (size_t)mm ? 1u : 0u);  // which of the three cosets
   const fe* c = cos + (size_t)p * 7 * m;
   auto sel = [&](int s) { return F::load(pkc[(size_t)s * m + i]); };
   fl w0 = F::load(c[i]), w1 = F::load(c[m + i]), w2 = F::load(c[2 * m + i]), w3 = F::load(c[3 * m + i]),
@@ -271,9 +273,11 @@ __global__ __launch_bounds__(kThreads) void k_quotient(const fe* __restrict__ pk
   const fl beta = F::load(chal[p].beta), gamma = F::load(chal[p].gamma);
   const fl zx = F::load(c[5 * m + i]);
   {
-    fl x = F::mul(F::load(qc.g), F::load(tw_m[i]));
+    fl x = F::load(xs[i]);  // the point itself (internal form): s_a * omega_M^k at index a * M + k
     fl bx = F::mul(beta, x);
-    const size_t inext = i + 6 < m ? i + 6 : i + 6 - m;  // x * omega_n = the point six steps further on the 6n coset
+    // index a M + k (ntt.hpp): x * omega_n = x * omega_M^2 is two steps further inside the same block of M = m / 3
+    const uint32_t k1 = (uint32_t)i - blk * mm;
+    const size_t inext = (size_t)blk * mm + ((k1 + 2) & (mm - 1));
     fl a = zx, b = F::load(c[5 * m + inext]);
     fl wg = F::add(w0, gamma);
     a = F::mul(a, F::normalize(F::add(wg, bx)));
@@ -294,17 +298,18 @@ __global__ __launch_bounds__(kThreads) void k_quotient(const fe* __restrict__ pk
   }
   // (gate + alpha * perm) / Z_H  +  alpha^2 (z - 1) / (n (x - 1)) : two products, one reduction
   fl l1a = F::mul(F::load(chal[p].alpha2), F::sub(zx, F::one()));
-  fl r = F::mul_add_mul(total, F::load(qc.zh_inv[i % 6]), l1a, F::load(inv_nx1[i]));
+  // x^n depends on the block and on the parity of k only: (s_a omega_M^k)^n = s_a^n (-1)^k = (5 omega_N^(3k + a))^n
+  const uint32_t zi = 3 * (((uint32_t)i - blk * mm) & 1) + blk;  // < 6
+  fl r = F::mul_add_mul(total, F::load(qc.zh_inv[zi]), l1a, F::load(inv_nx1[i]));
   t_out[(size_t)p * m + i] = F::store(r);
 }
 
-// out[i] = 1 / (n * (g * w_m^i - 1))   (one-time table of the proving key)
-__global__ __launch_bounds__(kThreads) void k_inv_nx1(fe* __restrict__ out, const fe* __restrict__ tw_m, fe g,
-                                                      fe n_mont, size_t m) {
+// out[i] = 1 / (n * (x_i - 1))   (one-time table of the proving key; xs = the points of the quotient domain)
+__global__ __launch_bounds__(kThreads) void k_inv_nx1(fe* __restrict__ out, const fe* __restrict__ xs, fe n_mont,
+                                                      size_t m) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= m) return;
-  fe x = Fr::mul(g, tw_m[i]);
-  out[i] = Fr::inv(Fr::mul(n_mont, Fr::sub(x, Fr::one())));
+  out[i] = Fr::inv(Fr::mul(n_mont, Fr::sub(xs[i], Fr::one())));
 }
 
 // flags[p] |= 1 if any coefficient at index >= lo is non-zero; |= 2 if coefficient lo-1 is zero

@@ -25,6 +25,11 @@ def test_root_of_unity_of_order_6n():
         assert pow(w, big, R) == 1 and pow(w, big // 2, R) != 1 and pow(w, big // 3, R) != 1   # order exactly 6n
         assert pow(w, 3, R) == bn.root_of_unity(log_n + 1)      # the three sub-transforms are ordinary 2n-point ones
         assert pow(w, 6, R) == bn.root_of_unity(log_n)          # six points further = the next row of the circuit
+        if log_n <= 4:
+            # the kernels keep the 6n points as three cosets of the 2n-point domain, block a = 5 w^a <omega_2n>
+            g, wm = bn.FR_GENERATOR, bn.root_of_unity(log_n + 1)
+            blocks = {g * pow(w, a, R) % R * pow(wm, k, R) % R for a in range(3) for k in range(m_small)}
+            assert blocks == {g * pow(w, i, R) % R for i in range(big)}
 
 
 def test_quotient_from_the_6n_coset_equals_the_oracles():
