@@ -334,10 +334,16 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
 
   std::vector<g1_jac> hj;
   std::vector<g1_affine> ha;
-  auto fetch_comms = [&](uint32_t count) -> int {
+  // `keep_busy` enqueues work that does not depend on the next challenge: it runs on the GPU while the host turns the
+  // commitments into challenges
+  auto fetch_comms = [&](uint32_t count, const std::function<int()>& keep_busy = nullptr) -> int {
     hj.resize(count);
     CAP_HIP(hipMemcpyAsync(hj.data(), w.comms, sizeof(g1_jac) * count, hipMemcpyDeviceToHost, s));
     CAP_HIP(hipStreamSynchronize(s));
+    if (keep_busy) {
+      int brc = keep_busy();
+      if (brc) return brc;
+    }
     // Jacobian -> affine on the host while the GPU waits for the next challenge: chunks of 64 points (one shared
     // inversion each) spread over the pool instead of one serial pass over up to 5P points
     ha.resize(count);
@@ -360,7 +366,14 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
   pad_copy(s, w.pi, n, 0, w.d_pub, num_inputs, 0, 1, P, num_inputs, n);
   if ((rc = run_ntt(s, K.log_n, w.pi, n, P, 1, 0))) return rc;
   if ((rc = run_msm(s, *B, w.wpoly, ps, 1, 0, n + 2, P * NW, w.comms))) return rc;
-  if ((rc = fetch_comms(P * NW))) return rc;
+  // round 3's coset evaluations of the wire and public-input polynomials (on the 6n quotient domain, straight from
+  // their coefficient arrays: the transform zero-extends them) depend on nothing the transcript still has to produce
+  if ((rc = fetch_comms(P * NW, [&]() -> int {
+         int r = run_ntt3_fwd(s, K.log_m, w.coset, P * NW, NttIo{w.wpoly, NW * ps, ps, n + 2, NW, 7 * m, m, NW});
+         if (r) return r;
+         return run_ntt3_fwd(s, K.log_m, w.coset + 6 * m, P, NttIo{w.pi, n, 0, n, 1, 7 * m, 0, 1});
+       })))
+    return rc;
   std::vector<Chal> chal(P);
   parallel_for(P, [&](uint32_t p) {
     for (int i = 0; i < NW; i++) {
@@ -390,7 +403,10 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
   if ((rc = run_ntt(s, K.log_n, w.zpoly, ps, P, 1, 0))) return rc;
   launch("k_blind", k_blind, dim3(P), dim3(64), 0, s, w.zpoly, ps, n, (const fe*)w.d_blind, 1u, 10u, 3u, P);
   if ((rc = run_msm(s, *B, w.zpoly, ps, 1, 0, n + 3, P, w.comms))) return rc;
-  if ((rc = fetch_comms(P))) return rc;
+  if ((rc = fetch_comms(P, [&]() -> int {  // likewise the coset evaluations of z
+         return run_ntt3_fwd(s, K.log_m, w.coset + 5 * m, P, NttIo{w.zpoly, ps, 0, n + 3, 1, 7 * m, 0, 1});
+       })))
+    return rc;
   parallel_for(P, [&](uint32_t p) {
     append_g1(tr[p], ha[p]);
     affine_to_words(ha[p], proofs[p].prod_perm_poly_comm);
@@ -408,12 +424,7 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
   });
   CAP_HIP(hipMemcpyAsync(w.chal29, chal29.data(), sizeof(Chal) * P, hipMemcpyHostToDevice, s));
 
-  // ---- round 3: quotient polynomial ---------------------------------------------------------------------
-  // coset evaluations of the wire, z and public-input polynomials on the 6n quotient domain, straight from their
-  // coefficient arrays (the transform zero-extends them: no padded copies are written and read back)
-  if ((rc = run_ntt3_fwd(s, K.log_m, w.coset, P * NW, NttIo{w.wpoly, NW * ps, ps, n + 2, NW, 7 * m, m, NW}))) return rc;
-  if ((rc = run_ntt3_fwd(s, K.log_m, w.coset + 5 * m, P, NttIo{w.zpoly, ps, 0, n + 3, 1, 7 * m, 0, 1}))) return rc;
-  if ((rc = run_ntt3_fwd(s, K.log_m, w.coset + 6 * m, P, NttIo{w.pi, n, 0, n, 1, 7 * m, 0, 1}))) return rc;
+  // ---- round 3: quotient polynomial (its seven coset transforms were enqueued behind the round 1 and 2 MSMs) ------
   const fe* pkc = K.pk_coset;
   if (K.recompute) {
     // reference schedule: the 18 selector / sigma polynomials are re-transformed for every proof
