@@ -153,6 +153,35 @@ def test_abi_vk_rejects_malformed_blobs(mutate):
         prm.deserialize_verifying_key(bytes(blob))
 
 
+def test_abi_vk_parser_survives_random_corruption():
+    """Byte flips, truncations and length-prefix edits never crash the host-side parser: it returns a key or the
+    serialization error (what ark-serialize's InvalidData becomes), nothing else."""
+    blob = bytes.fromhex(G["vk"])
+    rng = np.random.default_rng(2024)
+    outcomes = {"ok": 0, "rejected": 0}
+    for trial in range(120):
+        b = bytearray(blob)
+        kind = trial % 4
+        if kind == 0:
+            for pos in rng.integers(0, len(b), size=int(rng.integers(1, 4))):
+                b[pos] ^= 1 << int(rng.integers(0, 8))
+        elif kind == 1:
+            b = b[:int(rng.integers(0, len(b)))]
+        elif kind == 2:
+            off = [0, 8, 16, 16 + 8 + 5 * 32, 16 + 8 + 5 * 32 + 8 + 13 * 32][int(rng.integers(0, 5))]
+            b[off:off + 8] = int(rng.integers(0, 1 << 62)).to_bytes(8, "little")
+        else:
+            b += bytes(rng.integers(0, 256, size=int(rng.integers(1, 40)), dtype=np.uint8))   # trailing bytes are fine
+        try:
+            vk, *_rest, used = cglib.plonk_vk_deserialize(bytes(b))
+            assert used <= len(b)
+            outcomes["ok"] += 1
+        except cglib.CapGpuError as e:
+            assert e.code == cglib.CAPGPU_ERR_SERIALIZATION
+            outcomes["rejected"] += 1
+    assert outcomes["rejected"] > 40 and outcomes["ok"] >= 30      # appended bytes / harmless flips parse, the rest not
+
+
 def test_default_paths_follow_the_reference(monkeypatch, tmp_path):
     monkeypatch.setenv("CAP_UNIV_PARAM_DIR", str(tmp_path))
     d = tmp_path / "data"
@@ -273,6 +302,45 @@ def test_proving_key_blob_vs_oracle(cg, tau):
     for k in (pk, pk2):
         cg.plonk_free_key(k.handle)
         cg.srs_free(k.srs.handle)
+
+
+@pytest.mark.gpu
+def test_blob_parsers_survive_random_corruption(cg):
+    """Same for the device-backed parsers (UniversalSrs, ProvingKey): error or success, never a crash or a HIP fault,
+    and every handle a successful parse returns is usable and can be freed."""
+    rng = np.random.default_rng(7)
+    for name, parse in (("srs", lambda b: cg.srs_deserialize(b)[:1]),
+                        ("proving_key", lambda b: cg.plonk_key_deserialize(b)[:2])):
+        blob = bytes.fromhex(G[name])
+        ok = bad = 0
+        for trial in range(60):
+            b = bytearray(blob)
+            kind = trial % 3
+            if kind == 0:
+                for pos in rng.integers(0, len(b), size=int(rng.integers(1, 4))):
+                    b[pos] ^= 1 << int(rng.integers(0, 8))
+            elif kind == 1:
+                b = b[:int(rng.integers(0, len(b)))]
+            else:
+                pos = int(rng.integers(0, len(b) - 8))
+                b[pos:pos + 8] = int(rng.integers(0, 1 << 62)).to_bytes(8, "little")
+            try:
+                handles = parse(bytes(b))
+                ok += 1
+                if name == "srs":
+                    assert cg.srs_size(handles[0]) > 0
+                    cg.srs_free(handles[0])
+                else:
+                    cg.plonk_free_key(handles[1])
+                    cg.srs_free(handles[0])
+            except cg.CapGpuError as e:
+                assert e.code in (cg.CAPGPU_ERR_SERIALIZATION, -1), (name, trial, e)
+                bad += 1
+        assert bad > 20, (name, ok, bad)
+    # the library is still healthy afterwards
+    h = cg.srs_deserialize(bytes.fromhex(G["srs"]))[0]
+    assert cg.srs_size(h) == 35
+    cg.srs_free(h)
 
 
 @pytest.mark.gpu
