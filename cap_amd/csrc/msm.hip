@@ -137,6 +137,35 @@ __device__ __forceinline__ uint32_t msm_digit(const fe& k, uint32_t w, uint32_t 
   return v;
 }
 
+// Compile-time window size: with the loop over the windows unrolled every limb index is a constant and the scalar
+// stays in registers (with a run-time c the compiler indexes it through scratch memory: two scratch loads per digit).
+template <uint32_t C, uint32_t W>
+__device__ __forceinline__ uint32_t msm_digit_ct(const fe& k, uint32_t& carry) {
+  constexpr uint32_t half = 1u << (C - 1), mask = (1u << C) - 1;
+  constexpr uint32_t bit = W * C, limb = bit >> 5, off = bit & 31;
+  uint32_t v = 0;
+  if constexpr (limb < 8) {
+    uint64_t two = (uint64_t)k.v[limb];
+    if constexpr (limb + 1 < 8) two |= (uint64_t)k.v[limb + 1] << 32;
+    v = (uint32_t)(two >> off) & mask;
+  }
+  v += carry;
+  if (v > half) {
+    carry = 1;
+    return ((1u << C) - v) | 0x80000000u;
+  }
+  carry = 0;
+  return v;
+}
+template <uint32_t C, uint32_t W, uint32_t NW>
+__device__ __forceinline__ void all_digits(const fe& k, uint32_t& carry, uint32_t (&d)[NW]) {
+  if constexpr (W < NW) {
+    d[W] = msm_digit_ct<C, W>(k, carry);
+    all_digits<C, W + 1, NW>(k, carry, d);
+  }
+}
+
+template <uint32_t CT>  // CT = 13 / 15: window size known at compile time; 0: taken from the argument c
 __global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __restrict__ scalars, size_t outer_stride,
                                                              uint32_t inner, size_t inner_stride, size_t n,
                                                              int montgomery, uint32_t c, uint32_t windows,
@@ -165,15 +194,27 @@ __global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __re
   const fe* sc = scalars + (size_t)(b / inner) * outer_stride + (size_t)(b % inner) * inner_stride;
   static_assert(kDigitTile == kDigitThreads, "one scalar per thread: it stays in registers between the passes");
   const size_t i = (size_t)blk * kDigitTile + threadIdx.x;
+  // CT != 0: the digits are extracted once, with compile-time limb indices, and live in registers across both passes
+  constexpr uint32_t NWIN = CT ? (256 + CT - 1) / CT + (256 % CT == 0 ? 1 : 0) : 1;
+  uint32_t dg[NWIN];
   fe k;
   if (i < n) {
     k = sc[i];
     if (montgomery) k = Fr::from_mont(k);
     // pass A: histogram
     uint32_t carry = 0;
-    for (uint32_t w = 0; w < windows; w++) {
-      uint32_t d = msm_digit(k, w, c, carry) & 0x7FFFFFFFu;
-      if (d) atomicAdd(&hist[(d - 1) >> sub_bits], 1u);
+    if constexpr (CT != 0) {
+      all_digits<CT, 0, NWIN>(k, carry, dg);
+#pragma unroll
+      for (uint32_t w = 0; w < NWIN; w++) {
+        const uint32_t d = dg[w] & 0x7FFFFFFFu;
+        if (d) atomicAdd(&hist[(d - 1) >> sub_bits], 1u);
+      }
+    } else {
+      for (uint32_t w = 0; w < windows; w++) {
+        uint32_t d = msm_digit(k, w, c, carry) & 0x7FFFFFFFu;
+        if (d) atomicAdd(&hist[(d - 1) >> sub_bits], 1u);
+      }
     }
   }
   __syncthreads();
@@ -210,14 +251,19 @@ __global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __re
   // pass B: place the table indices
   if (i < n) {
     uint32_t carry = 0;
-    for (uint32_t w = 0; w < windows; w++) {
-      uint32_t d = msm_digit(k, w, c, carry);
-      uint32_t mag = d & 0x7FFFFFFFu;
+    auto place = [&](uint32_t w, uint32_t d) {
+      const uint32_t mag = d & 0x7FFFFFFFu;
       if (mag) {
         uint32_t pos = atomicAdd(&hist[(mag - 1) >> sub_bits], 1u);
         buf[pos] = (uint32_t)((size_t)w * srs_n + base_offset + i) | (((mag - 1) & sub_mask) << 24) |
                    (d & 0x80000000u);
       }
+    };
+    if constexpr (CT != 0) {
+#pragma unroll
+      for (uint32_t w = 0; w < NWIN; w++) place(w, dg[w]);
+    } else {
+      for (uint32_t w = 0; w < windows; w++) place(w, msm_digit(k, w, c, carry));
     }
   }
   __syncthreads();
@@ -990,11 +1036,14 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
     size_t lds_bytes = sizeof(uint32_t) * (2 * (size_t)bins + (size_t)kDigitTile * W);
     static bool attr_set = false;
     if (!attr_set) {
-      hipFuncSetAttribute(reinterpret_cast<const void*>(msm_digits_local), hipFuncAttributeMaxDynamicSharedMemorySize,
-                          160 * 1024 - 64);
+      for (const void* f : {reinterpret_cast<const void*>(msm_digits_local<0>),
+                            reinterpret_cast<const void*>(msm_digits_local<13>),
+                            reinterpret_cast<const void*>(msm_digits_local<15>)})
+        hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
       attr_set = true;
     }
-    launch("msm_digits_local", msm_digits_local, dim3(nblk * ((batch + 7) / 8) * 8), dim3(kDigitThreads), lds_bytes,
+    auto digits_kernel = c == 13 ? msm_digits_local<13> : (c == 15 ? msm_digits_local<15> : msm_digits_local<0>);
+    launch("msm_digits_local", digits_kernel, dim3(nblk * ((batch + 7) / 8) * 8), dim3(kDigitThreads), lds_bytes,
            stream, d_scalars, outer_stride, inner, inner_stride, n, montgomery, c, W, nblk, batch, bases.n, offset,
            pl.sub_bits, table, tloc, chunk_buf);
     scan_counts(table, off2, bins * nblk);
