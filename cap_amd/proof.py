@@ -55,6 +55,32 @@ class VerifyingKey:
     beta_h: np.ndarray | None = None
 
 
+# Domain sizes the reference pins for BN254 (test_compute_srs_size, src/utils/mod.rs:136-193; gate count of
+# Transfer(2, 6, 10): src/proof/transfer.rs:602-603).  The real function builds the circuit and reads its evaluation
+# domain (src/utils/mod.rs:89-113); circuit construction is CPU-side and out of scope, so only the
+# pinned shapes are known here.
+_PINNED_PARAM_SIZES = {
+    ("transfer", 3, 5, 26): 65538,
+    ("transfer", 2, 2, 10): 32770,
+    ("transfer", 2, 6, 10): 32770,
+    ("mint", 0, 0, 26): 16386,
+    ("freeze", 2, 0, 5): 16386,
+    ("freeze", 5, 0, 26): 65538,
+}
+
+
+def compute_universal_param_size(note_type: str, num_inputs: int, num_outputs: int, tree_depth: int) -> int:
+    """src/utils/mod.rs:89-113: evaluation-domain size of the note's circuit + 2 (zero-knowledge blinding), i.e. the
+    `max_degree` to pass to `universal_setup`.  Known for the shapes the reference's tests pin; anything else needs the
+    circuit builder and raises like the reference does when the circuit cannot be built."""
+    try:
+        return _PINNED_PARAM_SIZES[(note_type.lower(), num_inputs, num_outputs, tree_depth)]
+    except KeyError:
+        raise TxnApiError.FailedSnark(
+            f"domain size of {note_type}({num_inputs}, {num_outputs}, depth {tree_depth}) is not pinned by the "
+            "reference's tests; it takes the circuit builder (out of scope) to compute it") from None
+
+
 def universal_setup(max_degree: int, tau: int) -> UniversalSrs:
     """SRS [tau^i] G for i <= max_degree, generated and kept on the device.
     (The reference samples tau from its rng; benches use test_rng, benches/transfer.rs:71.)"""

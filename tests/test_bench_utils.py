@@ -48,3 +48,21 @@ def test_shard_ranges_partition():
             sizes = [hi - lo for lo, hi in spans]
             assert max(sizes) - min(sizes) <= 1
     assert sorted(sum((par.shard_proofs(64, r, 8) for r in range(8)), [])) == list(range(64))
+
+
+def test_param_sizes_pinned_by_the_reference():
+    """src/utils/mod.rs:136-193 (test_compute_srs_size, BN254 values) and the shapes the benchmark synthesises."""
+    import pytest
+    from cap_amd import proof
+    assert proof.compute_universal_param_size("Transfer", 3, 5, 26) == 65538
+    assert proof.compute_universal_param_size("Transfer", 2, 2, 10) == 32770
+    assert proof.compute_universal_param_size("Mint", 0, 0, 26) == 16386
+    assert proof.compute_universal_param_size("Freeze", 2, 0, 5) == 16386
+    assert proof.compute_universal_param_size("Freeze", 5, 0, 26) == 65538
+    with pytest.raises(proof.TxnApiError):
+        proof.compute_universal_param_size("Transfer", 7, 7, 3)
+    # the synthetic circuits of the benchmark have exactly these domains: size - 2 = 2^log_n
+    assert (1 << bu.NOTE_SHAPES["transfer_2x2"][0]) + 2 == proof.compute_universal_param_size("transfer", 2, 2, 10)
+    assert (1 << bu.NOTE_SHAPES["transfer_2x2_d26"][0]) + 2 == proof.compute_universal_param_size("transfer", 3, 5, 26)
+    assert (1 << bu.NOTE_SHAPES["mint"][0]) + 2 == proof.compute_universal_param_size("mint", 0, 0, 26)
+    assert (1 << bu.NOTE_SHAPES["freeze_2"][0]) + 2 == proof.compute_universal_param_size("freeze", 2, 0, 5)
