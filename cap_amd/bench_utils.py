@@ -35,18 +35,29 @@ K = [
 ]
 ROOT_28 = pow(5, (R - 1) >> 28, R)
 
+def transfer_num_public_inputs(n_in: int, n_out: int) -> int:
+    """TransferPublicInput::to_scalars (src/proof/transfer.rs:443-458): merkle root, native asset code, valid_until,
+    fee, one nullifier per input, one commitment per output, then the viewing memo = ElGamal ciphertext of
+    [asset code, 12 values per non-fee input, 4 per non-fee output] (src/structs.rs:1300-1385; VIEWABLE_DATA_LEN = 12,
+    src/constants.rs:17-28) with its 2-scalar ephemeral key.  2-in/2-out -> 27 (the value the verifier contract pins)."""
+    return 4 + n_in + n_out + 2 + 1 + 12 * (n_in - 1) + 4 * (n_out - 1)
+
+
 # note shapes: (log2 domain size, number of public inputs)
 #   transfer 2-in/2-out: n = 2^15 at depth 10 (src/utils/mod.rs:149-153), 27 public inputs
 #     (src/proof/transfer.rs:443-458); depth 26 may need 2^16 (SURVEY §6) - both are benchmarked
 #   mint depth 26: n = 2^14 (src/utils/mod.rs:160-165), 22 public inputs (src/proof/mint.rs:262-277)
-#   freeze 2 inputs: n = 2^14 (src/utils/mod.rs:172-177), 3 + 2k public inputs (src/proof/freeze.rs:331-344)
+#   freeze k inputs: n = 2^14 for k = 2 (src/utils/mod.rs:172-177), 3 + 2k public inputs (src/proof/freeze.rs:331-344)
+#   the reference's largest pinned shapes, Transfer(3, 5, 26) and Freeze(5, 26), need 2^16 (src/utils/mod.rs:139-187)
 NOTE_SHAPES = {
-    "transfer_2x2": (15, 27),
-    "transfer_2x2_d26": (16, 27),
-    "transfer_2x3": (15, 28),
+    "transfer_2x2": (15, transfer_num_public_inputs(2, 2)),
+    "transfer_2x2_d26": (16, transfer_num_public_inputs(2, 2)),
+    "transfer_2x3": (15, transfer_num_public_inputs(2, 3)),      # generate_txns' shape (params_builder.rs:74-76)
+    "transfer_3x5_d26": (16, transfer_num_public_inputs(3, 5)),
     "mint": (14, 22),
     "freeze_2": (14, 7),
     "freeze_3": (15, 9),
+    "freeze_5_d26": (16, 13),
 }
 
 
@@ -229,6 +240,34 @@ def synthetic_circuit(log_n: int, num_inputs: int, seed: int = 2, fill: float = 
 def note_circuit(kind: str, seed: int = 2) -> SyntheticCircuit:
     log_n, num_inputs = NOTE_SHAPES[kind]
     return synthetic_circuit(log_n, num_inputs, seed)
+
+
+def weighted_scalar_sums(sc: np.ndarray, lo: int = 0):
+    """(sum k_i, sum (lo + i) k_i) for canonical scalars (n, 4) uint64 - exact, numpy on 16-bit pieces.  With bases
+    P_i = [a + i b] G (capgpu_srs_generate_affine_seq) the MSM must equal [a * s0 + b * s1] G: the full-size known
+    answer of BASELINE config 5."""
+    sc = np.ascontiguousarray(sc, dtype=np.uint64).reshape(-1, 4)
+    n = sc.shape[0]
+    pieces = sc.view(np.uint16).reshape(n, 16)
+    s0 = s1 = 0
+    blk_len = 1 << 18
+    for start in range(0, n, blk_len):
+        blk = pieces[start:start + blk_len].astype(np.uint64)
+        idx = np.arange(start, start + blk.shape[0], dtype=np.uint64) + np.uint64(lo)
+        col = blk.sum(axis=0)
+        wcol = (blk * idx[:, None]).sum(axis=0)        # < 2^18 * 2^16 * 2^25: fits 64 bits
+        s0 += sum(int(col[j]) << (16 * j) for j in range(16))
+        s1 += sum(int(wcol[j]) << (16 * j) for j in range(16))
+    return s0, s1
+
+
+def random_canonical_scalars(seed: int, n: int) -> np.ndarray:
+    """n uniformly random canonical scalars below 2^253 (< r), (n, 4) uint64 - numpy speed for 2^24 of them."""
+    rng = np.random.default_rng(seed)
+    sc = rng.integers(0, 1 << 63, size=(n, 4), dtype=np.uint64) * np.uint64(2) + \
+        rng.integers(0, 2, size=(n, 4), dtype=np.uint64)
+    sc[:, 3] &= np.uint64((1 << 61) - 1)
+    return sc
 
 
 def blinders(seed: int, count: int = 13):

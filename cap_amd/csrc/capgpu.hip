@@ -23,6 +23,10 @@ Profiler& profiler() {
   static Profiler p;
   return p;
 }
+LaunchError& launch_error() {
+  static LaunchError e;
+  return e;
+}
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -33,6 +37,15 @@ int hip_fail(hipError_t e, const char* what) {
   set_error("capgpu: HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
   (void)hipGetLastError();
   return e == hipErrorOutOfMemory ? CAPGPU_ERR_OOM : CAPGPU_ERR_HIP;
+}
+
+int take_launch_error() {
+  LaunchError& le = launch_error();
+  if (le.code == hipSuccess) return CAPGPU_OK;
+  set_error("capgpu: launch of kernel %s failed: HIP error %d (%s)", le.kernel ? le.kernel : "?", (int)le.code,
+            hipGetErrorString(le.code));
+  le = LaunchError{};
+  return CAPGPU_ERR_HIP;
 }
 
 int scratch_reserve(Scratch& s, size_t bytes) {
@@ -183,6 +196,12 @@ int register_srs(g1_affine* d_bases, size_t n, uint64_t* handle_out) {
   return CAPGPU_OK;
 }
 
+SrsEntry* find_srs_entry(uint64_t h) {
+  Context& c = ctx();
+  auto it = c.srs.find(h);
+  return it == c.srs.end() ? nullptr : &it->second;
+}
+
 int find_srs(uint64_t h, const MsmBases** out) {
   Context& c = ctx();
   auto it = c.srs.find(h);
@@ -330,17 +349,15 @@ int capgpu_srs_upload(const void* bases, size_t n, size_t stride_bytes, int coor
     memcpy(&packed[i], src + i * stride_bytes, 64);
     if (stride_bytes == 72 && src[i * stride_bytes + 64]) memset(&packed[i], 0, 64);  // infinity flag
   }
-  g1_affine* d = nullptr;
-  CAP_HIP(hipMalloc(&d, sizeof(g1_affine) * (n ? n : 1)));
+  DevTmp<g1_affine> d;
+  CAP_HIP(d.alloc(n));
   CAP_HIP(hipMemcpyAsync(d, packed.data(), sizeof(g1_affine) * n, hipMemcpyHostToDevice, c.stream));
   if (!coords_montgomery && n) {
     size_t cnt = 2 * n;
     launch("fq_to_mont_kernel", fq_to_mont_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c.stream,
-           reinterpret_cast<fe*>(d), cnt);
+           reinterpret_cast<fe*>(d.p), cnt);
   }
-  int rc = register_srs(d, n, handle_out);
-  hipFree(d);
-  return rc;
+  return register_srs(d, n, handle_out);
 }
 
 static int srs_generate_common(int mode, const uint64_t a[4], const uint64_t b[4], size_t n, uint64_t* handle_out) {
@@ -351,9 +368,9 @@ static int srs_generate_common(int mode, const uint64_t a[4], const uint64_t b[4
   }
   Context& c = ctx();
   std::lock_guard<std::recursive_mutex> lk(c.mu);
-  g1_affine* d = nullptr;
-  CAP_HIP(hipMalloc(&d, sizeof(g1_affine) * n));
-  fe* d_tab = nullptr;
+  DevTmp<g1_affine> d;
+  CAP_HIP(d.alloc(n));
+  DevTmp<fe> d_tab, d_pw;
   fe am = Fr::to_mont(fe_from_u64x4(a));
   fe bm = b ? Fr::to_mont(fe_from_u64x4(b)) : Fr::zero();
   if (mode == 0) {
@@ -363,22 +380,17 @@ static int srs_generate_common(int mode, const uint64_t a[4], const uint64_t b[4
       pw[i] = x;
       x = Fr::sqr(x);
     }
-    fe* d_pw = nullptr;
-    CAP_HIP(hipMalloc(&d_pw, sizeof(fe) * 64));
-    CAP_HIP(hipMalloc(&d_tab, sizeof(fe) * n));
+    CAP_HIP(d_pw.alloc(64));
+    CAP_HIP(d_tab.alloc(n));
     CAP_HIP(hipMemcpyAsync(d_pw, pw.data(), sizeof(fe) * 64, hipMemcpyHostToDevice, c.stream));
-    launch("fr_powers_kernel", fr_powers_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, d_tab, n,
-           d_pw);
+    launch("fr_powers_kernel", fr_powers_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, d_tab.p, n,
+           (const fe*)d_pw.p);
     CAP_HIP(hipStreamSynchronize(c.stream));
-    hipFree(d_pw);
   }
-  launch("srs_fixed_base_kernel", srs_fixed_base_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, d,
-         n, mode, d_tab, am, bm);
+  launch("srs_fixed_base_kernel", srs_fixed_base_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream,
+         d.p, n, mode, (const fe*)d_tab.p, am, bm);
   CAP_HIP(hipStreamSynchronize(c.stream));
-  if (d_tab) hipFree(d_tab);
-  int rc = register_srs(d, n, handle_out);
-  hipFree(d);
-  return rc;
+  return register_srs(d, n, handle_out);
 }
 int capgpu_srs_generate(const uint64_t tau[4], size_t n, uint64_t* handle_out) {
   return srs_generate_common(0, tau, nullptr, n, handle_out);
@@ -459,7 +471,7 @@ int capgpu_msm_g1_dev(uint64_t srs_handle, size_t offset, const void* d_scalars,
   rc = msm_run(B, offset, (const fe*)d_scalars, scalar_stride, 1, 0, n, (uint32_t)count, scalars_montgomery,
                (g1_jac*)d_out_xyz, c.msm_ws.p, c.msm_ws.cap, c.stream);
   if (rc) return hip_fail((hipError_t)rc, "msm_run");
-  return CAPGPU_OK;
+  return take_launch_error();
 }
 
 int capgpu_msm_g1_batch(uint64_t srs_handle, const size_t* offsets, const uint64_t* const* scalars, const size_t* ns,
@@ -530,7 +542,7 @@ int capgpu_ntt_fr_dev(void* d_data, size_t stride_elems, int count, uint32_t log
   if (rc) return rc;
   rc = ntt_run(*dom, c.small, (fe*)d_data, (fe*)c.ntt_scratch.p, stride, (uint32_t)count, dir, coset, c.stream);
   if (rc) return hip_fail((hipError_t)rc, "ntt_run");
-  return CAPGPU_OK;
+  return take_launch_error();
 }
 
 int capgpu_ntt_fr_batch(uint64_t* const* data, int count, uint32_t log_n, int dir, int coset) {

@@ -76,6 +76,24 @@ class Profiler {
 
 Profiler& profiler();
 
+// First failed kernel launch since the last take_launch_error(): a bad launch configuration (grid too large, too much
+// LDS) is reported by the entry point that issued it instead of surfacing at some later synchronisation.
+struct LaunchError {
+  hipError_t code = hipSuccess;
+  const char* kernel = nullptr;
+};
+LaunchError& launch_error();
+inline void note_launch(const char* name) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    LaunchError& le = launch_error();
+    if (le.code == hipSuccess) {
+      le.code = e;
+      le.kernel = name;
+    }
+  }
+}
+
 template <class K, class... A>
 inline void launch(const char* name, K kernel, dim3 grid, dim3 block, size_t lds, hipStream_t stream, A... args) {
   Profiler& p = profiler();
@@ -86,6 +104,7 @@ inline void launch(const char* name, K kernel, dim3 grid, dim3 block, size_t lds
   } else {
     hipLaunchKernelGGL(kernel, grid, block, lds, stream, args...);
   }
+  note_launch(name);
 }
 
 }  // namespace cap

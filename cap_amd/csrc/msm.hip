@@ -951,6 +951,7 @@ uint32_t msm_num_windows(uint32_t c) {
   return w;
 }
 
+void msm_free_bases(MsmBases* b);
 int msm_precompute(MsmBases* out, const g1_affine* d_bases, size_t n, uint32_t c, hipStream_t stream) {
   out->n = n;
   out->c = c;
@@ -969,7 +970,11 @@ int msm_precompute(MsmBases* out, const g1_affine* d_bases, size_t n, uint32_t c
   if (!getenv("CAPGPU_MSM_C") && !(env && atoi(env) == 0) && c < kWideC && n >= 4096 &&
       (size_t)w2 * n < ((size_t)1 << 24)) {
     e = hipMalloc(&out->ext2, sizeof(g1_affine) * n * w2);
-    if (e != hipSuccess) return (int)e;
+    if (e != hipSuccess) {
+      (void)hipStreamSynchronize(stream);
+      msm_free_bases(out);  // do not leave the first table behind on the out-of-memory path
+      return (int)e;
+    }
     out->c2 = kWideC;
     out->windows2 = w2;
     launch("msm_precompute_kernel", msm_precompute_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, out->ext2,

@@ -82,6 +82,8 @@ inline g2_affine g2_generator() {
 }
 inline bool g2_on_curve(const g2_affine& q) {
   if (q.inf) return true;
+  // canonical coordinates only (arkworks never holds a value >= p; Fq::mul would reduce one silently)
+  if (Fq::geq_mod(q.x.c0) || Fq::geq_mod(q.x.c1) || Fq::geq_mod(q.y.c0) || Fq::geq_mod(q.y.c1)) return false;
   fq2 lhs = f2_mul(q.y, q.y);
   fq2 rhs = f2_add(f2_mul(f2_mul(q.x, q.x), q.x), f2_const(B2));
   return f2_eq(lhs, rhs);

@@ -232,15 +232,14 @@ int capgpu_g1_decompress(const uint8_t* in, size_t n, uint64_t* out_xy) {
   if (n == 0) return CAPGPU_OK;
   Context& c = ctx();
   std::lock_guard<std::recursive_mutex> lk(c.mu);
-  g1_affine* d = nullptr;
-  CAP_HIP(hipMalloc(&d, sizeof(g1_affine) * n));
+  DevTmp<g1_affine> d;
+  CAP_HIP(d.alloc(n));
   int rc = decompress_g1(in, n, d, c.stream);
   if (rc == CAPGPU_OK) {
     hipError_t e = hipMemcpyAsync(out_xy, d, sizeof(g1_affine) * n, hipMemcpyDeviceToHost, c.stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c.stream);
     if (e != hipSuccess) rc = hip_fail(e, "copy of decompressed points");
   }
-  hipFree(d);
   return rc;
 }
 
@@ -253,12 +252,10 @@ int capgpu_g1_compress(const uint64_t* xy, size_t n, uint8_t* out) {
   if (n == 0) return CAPGPU_OK;
   Context& c = ctx();
   std::lock_guard<std::recursive_mutex> lk(c.mu);
-  g1_affine* d = nullptr;
-  CAP_HIP(hipMalloc(&d, sizeof(g1_affine) * n));
+  DevTmp<g1_affine> d;
+  CAP_HIP(d.alloc(n));
   hipError_t e = hipMemcpyAsync(d, xy, sizeof(g1_affine) * n, hipMemcpyHostToDevice, c.stream);
-  int rc = e == hipSuccess ? compress_g1(d, 0, n, out, c.stream) : hip_fail(e, "upload of points");
-  hipFree(d);
-  return rc;
+  return e == hipSuccess ? compress_g1(d, 0, n, out, c.stream) : hip_fail(e, "upload of points");
 }
 
 // UniversalSrs<Bn254> = ark_poly_commit::kzg10::UniversalParams: powers_of_g: Vec<G1>, powers_of_gamma_g:
@@ -279,8 +276,9 @@ int capgpu_srs_deserialize(const uint8_t* bytes, size_t len, size_t max_degree, 
     const uint8_t* g_bytes = rd.take(32 * n_g);
     if (!rd.count(40, &n_gamma)) goto truncated;
     std::vector<uint8_t> gamma(32 * n_gamma);
+    std::vector<uint64_t> gamma_deg(n_gamma);
     for (uint64_t i = 0; i < n_gamma; i++) {
-      rd.u64();  // the degree this power belongs to
+      gamma_deg[i] = rd.u64();  // the degree this power belongs to
       const uint8_t* v = rd.take(32);
       if (!v) goto truncated;
       memcpy(&gamma[32 * i], v, 32);
@@ -294,11 +292,14 @@ int capgpu_srs_deserialize(const uint8_t* bytes, size_t len, size_t max_degree, 
       return CAPGPU_ERR_SERIALIZATION;
     }
     if (!rd.count(72, &n_neg)) goto truncated;
+    std::vector<uint8_t> neg_h;
     for (uint64_t i = 0; i < n_neg; i++) {
+      const uint8_t* entry = bytes + rd.pos;
       rd.u64();
       const uint8_t* v = rd.take(64);
       g2_affine q;
       if (!v) goto truncated;
+      neg_h.insert(neg_h.end(), entry, entry + 72);
       if (!g2_decompress(v, &q)) {
         set_error("capgpu_srs_deserialize: neg_powers_of_h[%llu] is not a valid compressed G2 point",
                   (unsigned long long)i);
@@ -311,13 +312,19 @@ int capgpu_srs_deserialize(const uint8_t* bytes, size_t len, size_t max_degree, 
     }
     // every point is validated like ark-serialize does; only the requested prefix stays resident
     size_t keep = max_degree ? std::min<size_t>(n_g, max_degree + 1) : (size_t)n_g;
-    g1_affine* d = nullptr;
-    CAP_HIP(hipMalloc(&d, sizeof(g1_affine) * std::max<size_t>(n_g, n_gamma)));
+    DevTmp<g1_affine> d;
+    CAP_HIP(d.alloc(std::max<size_t>(n_g, n_gamma)));
     int rc = n_gamma ? decompress_g1(gamma.data(), n_gamma, d, c.stream) : CAPGPU_OK;
     if (rc == CAPGPU_OK) rc = decompress_g1(g_bytes, n_g, d, c.stream);
     if (rc == CAPGPU_OK) rc = register_srs(d, keep, handle_out);
-    hipFree(d);
     if (rc) return rc;
+    // the hiding powers and the negative powers of h are not used by this (non-hiding) prover, but a reference-side
+    // consumer of a re-stored file indexes them (jf-plonk `trim`): they stay with the handle, validated, verbatim
+    if (SrsEntry* e = find_srs_entry(*handle_out)) {
+      e->gamma_deg = std::move(gamma_deg);
+      e->gamma_pts = std::move(gamma);
+      e->neg_h = std::move(neg_h);
+    }
     if (h_out) g2_to_words(h, h_out);
     if (beta_h_out) g2_to_words(beta_h, beta_h_out);
     if (consumed_out) *consumed_out = rd.pos;
@@ -340,21 +347,33 @@ int capgpu_srs_serialize(uint64_t handle, const uint64_t h[16], const uint64_t b
     set_error("capgpu_srs_serialize: bad argument");
     return CAPGPU_ERR_INVALID_ARG;
   }
-  const size_t need = 8 + 32 * B->n + 8 + 64 + 64 + 8;
+  const SrsEntry* E = find_srs_entry(handle);
+  const size_t n_gamma = E ? E->gamma_pts.size() / 32 : 0, n_neg = E ? E->neg_h.size() / 72 : 0;
+  const size_t need = 8 + 32 * B->n + 8 + 40 * n_gamma + 64 + 64 + 8 + 72 * n_neg;
   *len_out = need;
   if (!out) return CAPGPU_OK;  // size query
   if (cap < need) {
     set_error("capgpu_srs_serialize: buffer of %zu bytes, %zu needed", cap, need);
     return CAPGPU_ERR_INVALID_ARG;
   }
-  uint64_t n64 = B->n, zero = 0;
+  uint64_t n64 = B->n;
   memcpy(out, &n64, 8);
   if ((rc = compress_g1(B->ext, 1, B->n, out + 8, c.stream))) return rc;  // window 0 of the table = the bases
   uint8_t* p = out + 8 + 32 * B->n;
-  memcpy(p, &zero, 8);  // powers_of_gamma_g: none (non-hiding commitments only)
-  g2_compress(g2_from_words(h), p + 8);
-  g2_compress(g2_from_words(beta_h), p + 72);
-  memcpy(p + 136, &zero, 8);  // neg_powers_of_h: none
+  // powers_of_gamma_g / neg_powers_of_h: what the blob this handle was loaded from held (none for an SRS generated
+  // here: commitments are non-hiding, see the limitation note in include/capgpu.h)
+  n64 = n_gamma;
+  memcpy(p, &n64, 8);
+  p += 8;
+  for (size_t i = 0; i < n_gamma; i++, p += 40) {
+    memcpy(p, &E->gamma_deg[i], 8);
+    memcpy(p + 8, &E->gamma_pts[32 * i], 32);
+  }
+  g2_compress(g2_from_words(h), p);
+  g2_compress(g2_from_words(beta_h), p + 64);
+  n64 = n_neg;
+  memcpy(p + 128, &n64, 8);
+  if (n_neg) memcpy(p + 136, E->neg_h.data(), 72 * n_neg);
   return CAPGPU_OK;
 }
 

@@ -592,7 +592,7 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
     affine_to_words(ha[p * 2], proofs[p].opening_proof);
     affine_to_words(ha[p * 2 + 1], proofs[p].shifted_opening_proof);
   }
-  return CAPGPU_OK;
+  return take_launch_error();
 }
 
 // ---- proving-key construction shared by preprocess and the blob loader -------------------------------------
@@ -712,31 +712,29 @@ int capgpu_plonk_preprocess(uint64_t srs_handle, size_t n, size_t num_inputs, co
   if ((rc = key_init(*K, n, num_inputs, srs_handle))) return rc;
   const size_t ps = K->ps;
   // stage the evaluation columns, then interpolate
-  fe* stage = nullptr;
-  CAP_HIP(hipMalloc(&stage, sizeof(fe) * 18 * n));
+  DevTmp<fe> stage;
+  DevTmp<g1_jac> d_comms;
+  CAP_HIP(stage.alloc(18 * n));
   CAP_HIP(hipMemcpyAsync(stage, selectors, sizeof(fe) * NS * n, hipMemcpyHostToDevice, s));
-  CAP_HIP(hipMemcpyAsync(stage + (size_t)NS * n, sigma_evals, sizeof(fe) * NW * n, hipMemcpyHostToDevice, s));
-  CAP_HIP(hipMemcpyAsync(K->sig_eval, stage + (size_t)NS * n, sizeof(fe) * NW * n, hipMemcpyDeviceToDevice, s));
-  pad_copy(s, K->coef, ps, 0, stage, n, 0, 1, 18, n, ps);
+  CAP_HIP(hipMemcpyAsync(stage.p + (size_t)NS * n, sigma_evals, sizeof(fe) * NW * n, hipMemcpyHostToDevice, s));
+  CAP_HIP(hipMemcpyAsync(K->sig_eval, stage.p + (size_t)NS * n, sizeof(fe) * NW * n, hipMemcpyDeviceToDevice, s));
+  pad_copy(s, K->coef, ps, 0, stage.p, n, 0, 1, 18, n, ps);
   if ((rc = run_ntt(s, K->log_n, K->coef, ps, 18, 1, 0))) return rc;
   if ((rc = key_finish_tables(s, *K))) return rc;
   // verifying key: commitments of the 18 polynomials
-  g1_jac* d_comms = nullptr;
-  CAP_HIP(hipMalloc(&d_comms, sizeof(g1_jac) * 18));
+  CAP_HIP(d_comms.alloc(18));
   if ((rc = run_msm(s, *B, K->coef, ps, 1, 0, n, 18, d_comms))) return rc;
   std::vector<g1_jac> hj(18);
   std::vector<g1_affine> ha;
   CAP_HIP(hipMemcpyAsync(hj.data(), d_comms, sizeof(g1_jac) * 18, hipMemcpyDeviceToHost, s));
   CAP_HIP(hipStreamSynchronize(s));
-  hipFree(d_comms);
-  hipFree(stage);
   batch_to_affine(hj, ha);
   key_set_vk(*K, ha);
   if (vk_out) *vk_out = K->vk;
   uint64_t h = c.next_handle++;
   c.keys[h] = K;
   *pk_handle_out = h;
-  return CAPGPU_OK;
+  return take_launch_error();
 }
 
 // ---- ProvingKey blob (layout in include/capgpu.h) ---------------------------------------------
@@ -756,7 +754,8 @@ int capgpu_plonk_key_serialize(uint64_t pk_handle, const uint64_t gamma_g[8], co
   if ((rc = find_srs(K->srs_handle, &B))) return rc;
   const size_t n = K->n, ps = K->ps, n_ck = n + 3;
   // upper bound: every polynomial at full length
-  const size_t bound = 2 * 8 + 18 * (8 + 32 * n) + 8 + 32 * n_ck + 8 + 1024;
+  const SrsEntry* E0 = find_srs_entry(K->srs_handle);
+  const size_t bound = 2 * 8 + 18 * (8 + 32 * n) + 8 + 32 * n_ck + 8 + (E0 ? E0->gamma_pts.size() : 0) + 1024;
   if (!out) {
     *len_out = bound;
     return CAPGPU_OK;
@@ -784,7 +783,13 @@ int capgpu_plonk_key_serialize(uint64_t pk_handle, const uint64_t gamma_g[8], co
   for (int i = 0; i < NS; i++) poly(i);
   w.u64(n_ck);
   w.put(ck.data(), ck.size());
-  w.u64(0);  // powers_of_gamma_g: none
+  {
+    // CommitKey::powers_of_gamma_g (Vec<G1>): what the blob this key was loaded from held; none for a key made here
+    const SrsEntry* E = find_srs_entry(K->srs_handle);
+    const size_t n_gamma = E ? E->gamma_pts.size() / 32 : 0;
+    w.u64(n_gamma);
+    if (n_gamma) w.put(E->gamma_pts.data(), 32 * n_gamma);
+  }
   params::OpenKey ok;
   {
     g1_affine g0;
@@ -865,14 +870,16 @@ int capgpu_plonk_key_deserialize(const uint8_t* bytes, size_t len, uint64_t* srs
   hipStream_t s = c.stream;
   int rc;
   // commit key -> device -> window table
-  g1_affine* d_ck = nullptr;
-  CAP_HIP(hipMalloc(&d_ck, sizeof(g1_affine) * std::max<uint64_t>(n_ck, n_gamma)));
-  rc = n_gamma ? params::decompress_g1(gamma, n_gamma, d_ck, s) : CAPGPU_OK;  // validated, then dropped
-  if (rc == CAPGPU_OK) rc = params::decompress_g1(ck, n_ck, d_ck, s);
   uint64_t srs_handle = 0;
-  if (rc == CAPGPU_OK) rc = register_srs(d_ck, n_ck, &srs_handle);
-  hipFree(d_ck);
-  if (rc) return rc;
+  {
+    DevTmp<g1_affine> d_ck;
+    CAP_HIP(d_ck.alloc(std::max<uint64_t>(n_ck, n_gamma)));
+    rc = n_gamma ? params::decompress_g1(gamma, n_gamma, d_ck, s) : CAPGPU_OK;  // validated; bytes kept below
+    if (rc == CAPGPU_OK) rc = params::decompress_g1(ck, n_ck, d_ck, s);
+    if (rc == CAPGPU_OK) rc = register_srs(d_ck, n_ck, &srs_handle);
+    if (rc) return rc;
+    if (SrsEntry* E = find_srs_entry(srs_handle)) E->gamma_pts.assign(gamma, gamma + 32 * n_gamma);
+  }
   auto K = std::make_shared<ProvingKey>();
   auto bail = [&](int code) {
     capgpu_srs_free(srs_handle);
@@ -903,6 +910,20 @@ int capgpu_plonk_key_deserialize(const uint8_t* bytes, size_t len, uint64_t* srs
   c.keys[h] = K;
   *pk_handle_out = h;
   *srs_handle_out = srs_handle;
+  return CAPGPU_OK;
+}
+
+int capgpu_plonk_key_info(uint64_t pk_handle, size_t* domain_size_out, size_t* num_inputs_out,
+                          uint64_t* srs_handle_out) {
+  CAP_CHECK_INIT();
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  std::shared_ptr<ProvingKey> K;
+  int rc = lookup_key(pk_handle, &K);
+  if (rc) return rc;
+  if (domain_size_out) *domain_size_out = K->n;
+  if (num_inputs_out) *num_inputs_out = K->num_inputs;
+  if (srs_handle_out) *srs_handle_out = K->srs_handle;
   return CAPGPU_OK;
 }
 

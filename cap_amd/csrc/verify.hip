@@ -58,7 +58,13 @@ void g2_to_words(const g2_affine& q, uint64_t w[16]) {
   fe_to_words(q.y.c0, w + 8);
   fe_to_words(q.y.c1, w + 12);
 }
+// arkworks' Fp256 values are canonical by construction (deserialisation rejects anything >= the modulus), so v and
+// v + r can never both be a valid public input or evaluation there.  The raw Montgomery words of this ABI could carry
+// such a second encoding - Fq::mul / Fr::mul reduce silently - which would make proofs malleable: every field word is
+// range-checked before any arithmetic touches it.
+bool g1_canonical(const g1_affine& p) { return !Fq::geq_mod(p.x) && !Fq::geq_mod(p.y); }
 bool g1_on_curve(const g1_affine& p) {
+  if (!g1_canonical(p)) return false;
   if (G1::is_inf(p)) return true;
   fe b3 = Fq::add(Fq::add(Fq::one(), Fq::one()), Fq::one());
   return Fq::eq(Fq::sqr(p.y), Fq::add(Fq::mul(Fq::sqr(p.x), p.x), b3));
@@ -130,8 +136,11 @@ static int verifier_prepare(const capgpu_verifying_key* vk, const uint64_t* pub_
   g1_affine zc = g1_from_words(proof->prod_perm_poly_comm);
   g1_affine w_zeta = g1_from_words(proof->opening_proof), w_zeta_w = g1_from_words(proof->shifted_opening_proof);
   {
+    // proof points: on the curve and canonical (x, y < p); key points likewise (a key is trusted input, but a
+    // non-canonical coordinate in it would hash differently from the same key written canonically)
     bool on = g1_on_curve(zc) && g1_on_curve(w_zeta) && g1_on_curve(w_zeta_w);
-    for (int i = 0; i < kNumWires; i++) on = on && g1_on_curve(wc[i]) && g1_on_curve(tq[i]);
+    for (int i = 0; i < kNumWires; i++) on = on && g1_on_curve(wc[i]) && g1_on_curve(tq[i]) && g1_on_curve(sig[i]);
+    for (int i = 0; i < kNumSelectors; i++) on = on && g1_on_curve(sel[i]);
     if (!on) return CAPGPU_OK;
   }
   fe we[kNumWires], se[kNumWires - 1];
@@ -140,6 +149,15 @@ static int verifier_prepare(const capgpu_verifying_key* vk, const uint64_t* pub_
   const fe znext = fe_from_words(proof->perm_next_eval);
   fe kk[kNumWires];
   for (int i = 0; i < kNumWires; i++) kk[i] = fe_from_words(vk->k[i]);
+  {
+    // every Fr word canonical: the 10 evaluations, the public inputs (nullifiers, Merkle root, ... - a ledger that
+    // de-duplicates on raw words must not see two accepted encodings of one value) and the key's coset constants
+    bool canon = !Fr::geq_mod(znext);
+    for (int i = 0; i < kNumWires; i++) canon = canon && !Fr::geq_mod(we[i]) && !Fr::geq_mod(kk[i]);
+    for (int i = 0; i < kNumWires - 1; i++) canon = canon && !Fr::geq_mod(se[i]);
+    for (size_t i = 0; i < num_inputs; i++) canon = canon && !Fr::geq_mod(fe_from_words(pub_inputs + 4 * i));
+    if (!canon) return CAPGPU_OK;
+  }
 
   // ---- challenges (same transcript as the prover) ------------------------------------------------------------
   SolidityTranscript t;

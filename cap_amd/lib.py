@@ -264,6 +264,30 @@ def plonk_preprocess(srs_handle: int, n: int, num_inputs: int, selectors: np.nda
     return h.value, vk
 
 
+def plonk_key_info(pk_handle: int):
+    """-> (domain size n, number of public inputs, SRS handle) of a resident proving key."""
+    n, ni, srs = ctypes.c_size_t(0), ctypes.c_size_t(0), ctypes.c_uint64(0)
+    check(load().capgpu_plonk_key_info(ctypes.c_uint64(pk_handle), ctypes.byref(n), ctypes.byref(ni), ctypes.byref(srs)))
+    return n.value, ni.value, srs.value
+
+
+def _check_prove_shapes(pk_handle: int, count: int, wires_elems, pub_inputs: np.ndarray, blinders: np.ndarray) -> int:
+    """The C ABI takes bare pointers: a mis-shaped array would be read out of bounds.  Every size is checked against
+    the key here (wires: count * 5 * n elements, pub_inputs: count * num_inputs, blinders: count * 13)."""
+    n, num_inputs, _ = plonk_key_info(pk_handle)
+    if count < 1:
+        raise CapGpuError(-1, f"count must be >= 1, got {count}")
+    if wires_elems != count * NUM_WIRE_TYPES * n:
+        raise CapGpuError(-1, f"wires hold {wires_elems} field elements, key (n = {n}) needs count * 5 * n = "
+                              f"{count * NUM_WIRE_TYPES * n}")
+    if blinders.size != count * 13 * 4:
+        raise CapGpuError(-1, f"blinders hold {blinders.size // 4} field elements, need count * 13 = {count * 13}")
+    if pub_inputs.size % 4 or pub_inputs.size != count * num_inputs * 4:
+        raise CapGpuError(-1, f"pub_inputs hold {pub_inputs.size / 4:g} field elements, key expects count * "
+                              f"{num_inputs} = {count * num_inputs}")
+    return num_inputs
+
+
 def plonk_free_key(pk_handle: int):
     check(load().capgpu_plonk_free_key(ctypes.c_uint64(pk_handle)))
 
@@ -281,7 +305,8 @@ def plonk_prove_batch(pk_handle: int, wires: np.ndarray, pub_inputs: np.ndarray,
     wires = np.ascontiguousarray(wires, dtype=np.uint64)
     pub_inputs = np.ascontiguousarray(pub_inputs, dtype=np.uint64).reshape(-1)
     blinders = np.ascontiguousarray(blinders, dtype=np.uint64).reshape(-1)
-    num_inputs = pub_inputs.size // 4 // count
+    num_inputs = _check_prove_shapes(pk_handle, count, wires.size // 4 if wires.size % 4 == 0 else -1, pub_inputs,
+                                     blinders)
     proofs = (Proof * count)()
     mbuf, mlen = _bytes_arg(ext_msg)
     pub_ptr = _p(pub_inputs) if pub_inputs.size else None
@@ -295,7 +320,8 @@ def plonk_prove_batch_dev(pk_handle: int, d_wires: DevBuf, pub_inputs: np.ndarra
                           ext_msg: bytes | None = None, count: int = 1):
     pub_inputs = np.ascontiguousarray(pub_inputs, dtype=np.uint64).reshape(-1)
     blinders = np.ascontiguousarray(blinders, dtype=np.uint64).reshape(-1)
-    num_inputs = pub_inputs.size // 4 // count
+    num_inputs = _check_prove_shapes(pk_handle, count, d_wires.nbytes // 32 if d_wires.nbytes % 32 == 0 else -1,
+                                     pub_inputs, blinders)
     proofs = (Proof * count)()
     mbuf, mlen = _bytes_arg(ext_msg)
     pub_ptr = _p(pub_inputs) if pub_inputs.size else None

@@ -150,6 +150,11 @@ typedef struct capgpu_verifying_key {
 int capgpu_plonk_preprocess(uint64_t srs_handle, size_t n, size_t num_inputs, const uint64_t* selectors,
                             const uint64_t* sigma_evals, uint64_t* pk_handle_out, capgpu_verifying_key* vk_out);
 int capgpu_plonk_free_key(uint64_t pk_handle);
+/* Shape of a resident proving key: the sizes every prove call's arrays must have (wires: count * 5 * domain_size
+ * field elements, pub_inputs: count * num_inputs, blinders: count * 13) and the SRS it commits with.  Any out
+ * pointer may be NULL. */
+int capgpu_plonk_key_info(uint64_t pk_handle, size_t* domain_size_out, size_t* num_inputs_out,
+                          uint64_t* srs_handle_out);
 
 /* wires: 5 columns of n Fr (Montgomery), column-major (the finalised circuit's wire assignment);
  * pub_inputs: num_inputs Fr (Montgomery); ext_msg: the caller's transcript init message

@@ -1,0 +1,148 @@
+"""BASELINE.json's configurations at their full sizes, under `-m gpu` (round-1 VERDICT "untested configs"):
+
+* config 5 and the whole single-MSM path above 2^18 points (windows c = 15 / 17): 2^19, 2^20, 2^22 and 2^24 points,
+  checked exactly with the known-scalar identity  sum k_i [a + i b]G = [a sum k_i + b sum i k_i] G  (SURVEY 8c.3);
+* the same MSM cut into 8 point ranges on one device (what 8 ranks do) against the unsharded result;
+* n = 2^16 proofs: the reference's own bench depth (TREE_DEPTH = 26, src/bench_utils/mod.rs:42, benches/transfer.rs:54-73)
+  and Freeze(5, 26) (src/utils/mod.rs:182-187), bit-exact against the C restatement;
+* config 4: the 64-proof mixed batch of TxnsParams::generate_txns (src/utils/params_builder.rs:64-241, ratio of
+  src/lib.rs:734-736) at full size - transfer 2-in/3-out, mint, freeze 3-in; three keys on one SRS - every proof accepted
+  by the product verifier singly and by the batch verifier (src/lib.rs:455-529), one proof per kind bit-exact.
+"""
+import numpy as np
+import pytest
+
+from cap_amd import bench_utils as bu
+from cap_amd import parallel as par
+from oracle import bn254 as bn
+from oracle import capref as cr
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+A_SEQ, B_SEQ = 0x1234567890ABCDEF1234567890ABCDEF % bn.R, 0xFEDCBA0987654321FEDCBA % bn.R
+
+
+def expected_affine_seq(sc, lo=0):
+    s0, s1 = bu.weighted_scalar_sums(sc, lo)
+    return bn.g1_mul(bn.G1_GEN, (A_SEQ * s0 + B_SEQ * s1) % bn.R)
+
+
+@pytest.mark.parametrize("log_n", [19, 20, 22, 24])
+def test_single_msm_above_2p18_known_scalar_identity(cg, log_n):
+    """msm_choose_window gives c = 15 up to 2^22 points and c = 17 beyond; 2^24 is BASELINE config 5."""
+    n = 1 << log_n
+    h = cg.srs_generate_affine_seq(A_SEQ, B_SEQ, n)
+    sc = bu.random_canonical_scalars(5 + log_n, n)
+    sc[0] = 0                                            # zero, one and r - 1 among the scalars
+    sc[1] = cr.int_to_limbs(1)
+    sc[2] = cr.int_to_limbs(bn.R - 1)
+    got = cr.affine_to_ints(cr.g1_to_affine(cg.msm_g1(h, sc)))
+    assert got == expected_affine_seq(sc)
+    if log_n <= 20:
+        # ragged size + base offset on the same table: the tail tile is partly empty
+        m, off = n - 12345, 777
+        got = cr.affine_to_ints(cr.g1_to_affine(cg.msm_g1(h, sc[:m], offset=off)))
+        s0, s1 = bu.weighted_scalar_sums(sc[:m], off)
+        assert got == bn.g1_mul(bn.G1_GEN, (A_SEQ * s0 + B_SEQ * s1) % bn.R)
+    cg.srs_free(h)
+
+
+def test_single_msm_2p20_skewed_scalars(cg):
+    """All scalars equal: every window sends its 2^20 entries into one bucket (the worst case for the sort and for the
+    work-item split) - on the large-MSM path."""
+    n = 1 << 20
+    h = cg.srs_generate_affine_seq(A_SEQ, B_SEQ, n)
+    k = 0x1F2E3D4C5B6A79880123456789ABCDEF0FEDCBA9876543210011223344556677 % bn.R
+    sc = np.tile(cr.int_to_limbs(k), (n, 1))
+    got = cr.affine_to_ints(cr.g1_to_affine(cg.msm_g1(h, sc)))
+    s = (A_SEQ * n + B_SEQ * (n * (n - 1) // 2)) % bn.R
+    assert got == bn.g1_mul(bn.G1_GEN, k * s % bn.R)
+    cg.srs_free(h)
+
+
+def test_msm_2p20_in_8_point_ranges_on_one_device(cg):
+    """SURVEY 8e on one GPU: the 8 ranges an 8-rank job would own (cap_amd.parallel.shard_range), each reduced by the
+    local Pippenger on the resident table, partials summed on the device (capgpu_g1_sum) - against the unsharded MSM and
+    the known answer."""
+    n, world = (1 << 20) + 5, 8
+    h = cg.srs_generate_affine_seq(A_SEQ, B_SEQ, n)
+    sc = bu.random_canonical_scalars(77, n)
+    parts = []
+    for rank in range(world):
+        lo, hi = par.shard_range(n, rank, world)
+        parts.append(cg.msm_g1(h, sc[lo:hi], offset=lo))
+    total = cr.affine_to_ints(cr.g1_to_affine(cg.g1_sum(np.stack(parts))))
+    whole = cr.affine_to_ints(cr.g1_to_affine(cg.msm_g1(h, sc)))
+    assert total == whole == expected_affine_seq(sc)
+    cg.srs_free(h)
+
+
+def _prove_and_compare(cg, tau, kind, seed, msg):
+    sc = bu.note_circuit(kind, seed=seed)
+    h = cg.srs_generate(tau, sc.n + 3)
+    pkh, vk = cg.plonk_preprocess(h, sc.n, sc.num_inputs, sc.selectors_mont(), sc.sigma_mont())
+    key = cr.PlonkKey(cg.srs_download(h, 0, sc.n + 3), sc.n, sc.num_inputs, sc.selectors_mont(), sc.sigma_mont())
+    vk_g = [cr.affine_to_ints(np.ctypeslib.as_array(vk.selector_comms[i])) for i in range(13)] + \
+           [cr.affine_to_ints(np.ctypeslib.as_array(vk.sigma_comms[i])) for i in range(5)]
+    assert vk_g == [cr.affine_to_ints(c) for c in key.vk_comms]
+    w, pubs = sc.witness(seed + 1)
+    wm, pm, bm = sc.wires_mont(w), bu.to_mont_array(pubs), bu.to_mont_array(bu.blinders(seed + 2))
+    pr = cg.plonk_prove_batch(pkh, wm[None], pm[None], bm[None], msg, 1)[0]
+    rc, comms, evals = key.prove(wm, pm, bm, msg)
+    assert rc == 0
+    assert H.proof_points(pr) == H.cref_proof_points(comms, evals)
+    g2h = cg.g2_generator()
+    bh = cg.g2_mul(g2h, tau)
+    assert cg.plonk_verify(vk, g2h, bh, pm, pr, msg)
+    bad = pm.copy(); bad[0, 0] ^= 1
+    assert not cg.plonk_verify(vk, g2h, bh, bad, pr, msg)
+    cg.plonk_free_key(pkh)
+    cg.srs_free(h)
+
+
+@pytest.mark.parametrize("kind", ["transfer_2x2_d26", "freeze_5_d26"])
+def test_note_shapes_at_n_2p16(cg, tau, kind):
+    assert bu.NOTE_SHAPES[kind][0] == 16
+    _prove_and_compare(cg, tau, kind, seed=26, msg=b"memo-d26" if kind.startswith("transfer") else None)
+
+
+def test_mixed_batch_of_64_full_size(cg, tau):
+    mix = [("transfer_2x3", 32), ("mint", 13), ("freeze_3", 19)]
+    n_max = 1 << max(bu.NOTE_SHAPES[k][0] for k, _ in mix)
+    h = cg.srs_generate(tau, n_max + 3)           # one SRS sized for the largest circuit (params_builder.rs:78-85)
+    srs_host = cg.srs_download(h, 0, n_max + 3)
+    g2h = cg.g2_generator()
+    bh = cg.g2_mul(g2h, tau)
+    all_vks, all_pubs, all_proofs, all_msgs = [], [], [], []
+    keys = []
+    for gi, (kind, count) in enumerate(mix):
+        sc = bu.note_circuit(kind, seed=40 + gi)
+        pkh, vk = cg.plonk_preprocess(h, sc.n, sc.num_inputs, sc.selectors_mont(), sc.sigma_mont())
+        keys.append(pkh)
+        wit = [sc.witness(500 + 10 * gi + i) for i in range(3)]      # three distinct witnesses per kind, cycled
+        wires = np.stack([sc.wires_mont(wit[i % 3][0]) for i in range(count)])
+        pubs = np.stack([bu.to_mont_array(wit[i % 3][1]) for i in range(count)])
+        blind = np.stack([bu.to_mont_array(bu.blinders(900 + 100 * gi + i)) for i in range(count)])
+        msg = None if kind == "mint" else b"txn-memo-ver-key"        # mint binds no extra data (src/proof/mint.rs:113)
+        proofs = cg.plonk_prove_batch(pkh, wires, pubs, blind, msg, count)
+        assert len({bytes(cg.proof_serialize(p)) for p in proofs}) == count     # distinct blinders: distinct proofs
+        for i in range(count):
+            assert cg.plonk_verify(vk, g2h, bh, pubs[i], proofs[i], msg), (kind, i)
+        assert not cg.plonk_verify(vk, g2h, bh, pubs[1], proofs[0], msg)
+        # one proof per kind bit-exact against the CPU restatement on the shared SRS
+        ck = cr.PlonkKey(srs_host[:sc.n + 3], sc.n, sc.num_inputs, sc.selectors_mont(), sc.sigma_mont())
+        rc, comms, evals = ck.prove(wires[0], pubs[0], blind[0], msg)
+        assert rc == 0 and H.proof_points(proofs[0]) == H.cref_proof_points(comms, evals), kind
+        all_vks += [vk] * count
+        all_pubs += [pubs[i] for i in range(count)]
+        all_proofs += proofs
+        all_msgs += [msg] * count
+    # txn_batch_verify (src/lib.rs:455-529): one pairing product for all 64 proofs under three keys
+    assert cg.plonk_batch_verify(all_vks, g2h, bh, all_pubs, all_proofs, all_msgs)
+    swapped = list(all_proofs)
+    swapped[0], swapped[1] = swapped[1], swapped[0]
+    assert not cg.plonk_batch_verify(all_vks, g2h, bh, all_pubs, swapped, all_msgs)
+    for k in keys:
+        cg.plonk_free_key(k)
+    cg.srs_free(h)

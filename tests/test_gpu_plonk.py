@@ -198,6 +198,24 @@ def test_unsatisfied_witness_and_bad_arguments(cg, tau):
     with pytest.raises(cg.CapGpuError) as e:             # unknown key
         cg.plonk_prove_batch(424242, wm[None], pubs_arr(pubs)[None], bl[None], None, 1)
     assert e.value.code == -4
+    # the C ABI takes bare pointers; the binding checks every array against the key's shape before the call
+    assert cg.plonk_key_info(pkh) == (sc.n, 2, h)
+    for bad_args in ((wm[None, :, :sc.n // 2], pubs_arr(pubs)[None], bl[None], 1),     # wires of another domain
+                     (wm[None], pubs_arr(pubs)[None], bl[None], 2),                    # count > arrays
+                     (wm[None], pubs_arr(pubs)[None], bl[None, :12], 1)):              # 12 blinders
+        with pytest.raises(cg.CapGpuError) as e:
+            cg.plonk_prove_batch(pkh, bad_args[0], bad_args[1], bad_args[2], None, bad_args[3])
+        assert e.value.code == -1
+    with pytest.raises(cg.CapGpuError) as e:
+        cg.plonk_prove_batch_dev(pkh, cg.DevBuf(32 * 5 * sc.n - 32), pubs_arr(pubs)[None], bl[None], None, 1)
+    assert e.value.code == -1
+    # and the library itself refuses a public-input count that differs from the key's
+    pr_raw = (cg.Proof * 1)()
+    import ctypes
+    rc = cg.load().capgpu_plonk_prove_batch(ctypes.c_uint64(pkh), 1, cg._p(wm.reshape(-1)),
+                                            cg._p(pubs_arr(pubs).reshape(-1)), ctypes.c_size_t(1), None,
+                                            ctypes.c_size_t(0), cg._p(bl.reshape(-1)), pr_raw)
+    assert rc == -1
     small = cg.srs_generate(tau, 10)                      # SRS too small for the circuit
     with pytest.raises(cg.CapGpuError) as e:
         cg.plonk_preprocess(small, sc.n, 2, sc.selectors_mont(), sc.sigma_mont())

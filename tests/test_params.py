@@ -252,8 +252,11 @@ def test_srs_blob_vs_oracle(cg, tau):
     o = pm.deserialize_universal_params(blob)
     rich = pm.serialize_universal_params(o["powers_of_g"], {0: o["powers_of_g"][3], 7: o["powers_of_g"][1]}, o["h"],
                                          o["beta_h"], {1: pr2.g2_neg(o["beta_h"])})
-    h4, _, _, used = cg.srs_deserialize(rich)
+    h4, hh4, bh4, used = cg.srs_deserialize(rich)
     assert used == len(rich) and np.array_equal(cg.srs_download(h4, 0, n), cg.srs_download(h, 0, n))
+    # ... and kept with the handle: load -> store gives the file back byte for byte (jf-plonk's `trim` reads
+    # powers_of_gamma_g, so a re-stored file must still hold them - round-1 ADVICE)
+    assert cg.srs_serialize(h4, hh4, bh4) == rich
     for hd in (h, h2, h3, h4):
         cg.srs_free(hd)
     # malformed blobs
@@ -292,6 +295,14 @@ def test_proving_key_blob_vs_oracle(cg, tau):
     vk2, _ = prm.deserialize_verifying_key(bytes.fromhex(G["vk"]))
     capproof.verify(vk2, pa, p2, g["ext_msg"].encode())          # the loaded verifying key accepts it
     assert prm.serialize_proving_key(pk2) == blob                # and the loaded key serialises to the same bytes
+    # a key whose commit key carries hiding powers (CommitKey::powers_of_gamma_g): kept and written back verbatim
+    o = pm.deserialize_proving_key(blob)
+    rich = pm.serialize_proving_key(o["sigmas"], o["selectors"], o["powers_of_g"], bytes.fromhex(G["vk"]),
+                                    gamma_powers=[o["powers_of_g"][2], o["powers_of_g"][5]])
+    pk3, used3 = prm.deserialize_proving_key(rich)
+    assert used3 == len(rich) and prm.serialize_proving_key(pk3) == rich
+    p3 = capproof.prove(pk3, sc.wires_mont(w), pa, bl, g["ext_msg"].encode())
+    assert H.proof_points(p3) == H.proof_points(p1)
     # malformed key blobs
     nine = bytearray(blob); nine[0] = 4
     longpoly = bytearray(blob); longpoly[8:16] = (sc.n + 1).to_bytes(8, "little")

@@ -137,6 +137,81 @@ def test_product_verifier_on_golden_proof(tau):
     assert e.value.code == -1
 
 
+def _add_to_words(words, modulus):
+    """raw 256-bit integer held in 4 ctypes u64 words += modulus (must stay below 2^256)"""
+    v = sum(int(words[i]) << (64 * i) for i in range(4)) + modulus
+    assert v < 1 << 256
+    for i in range(4):
+        words[i] = (v >> (64 * i)) & 0xFFFFFFFFFFFFFFFF
+
+
+def test_verifier_rejects_non_canonical_encodings(tau):
+    """arkworks field elements are canonical by construction, so v and v + r (or x and x + p) can never both be valid
+    in the reference.  The raw Montgomery words of the C ABI could carry the second encoding (2r, 2p < 2^256):
+    every field of the proof, every public input and every key point must be rejected in that form - otherwise a
+    nullifier or Merkle root would have two accepted encodings (round-1 ADVICE, proof malleability)."""
+    g = H.load_golden("proof_log5.json")
+    n, nin = 1 << g["log_n"], g["num_inputs"]
+    sc = bu.synthetic_circuit(g["log_n"], nin, seed=g["circuit_seed"])
+    _, pubs = sc.witness(g["witness_seed"])
+    sel = [H.unhex_pt(p) for p in g["selector_comms"]]
+    sig = [H.unhex_pt(p) for p in g["sigma_comms"]]
+    pts = [H.unhex_pt(p) for p in g["wires_poly_comms"]] + [H.unhex_pt(g["prod_perm_poly_comm"])] + \
+        [H.unhex_pt(p) for p in g["split_quot_poly_comms"]] + [H.unhex_pt(g["opening_proof"]),
+                                                              H.unhex_pt(g["shifted_opening_proof"])]
+    evals = [int(h, 16) for h in g["wires_evals"] + g["wire_sigma_evals"] + [g["perm_next_eval"]]]
+    h2 = cg.g2_generator()
+    bh = cg.g2_mul(h2, tau)
+    msg = g["ext_msg"].encode()
+    pub_arr = bu.to_mont_array(pubs)
+    vk0, proof0 = make_vk(n, nin, sel, sig), make_proof(pts, evals)
+    assert cg.plonk_verify(vk0, h2, bh, pub_arr, proof0, msg)
+    # public inputs: + r on each one in turn
+    for i in range(nin):
+        bad = pub_arr.copy()
+        v = cr.array_to_ints(bad[i])[0] + bn.R
+        bad[i] = cr.int_to_limbs(v)
+        assert not cg.plonk_verify(vk0, h2, bh, bad, proof0, msg), f"public input {i} + r accepted"
+        assert not cg.plonk_batch_verify([vk0], h2, bh, [bad], [proof0], [msg])
+    # the 10 evaluations: + r
+    ev_fields = [("wires_evals", i) for i in range(5)] + [("wire_sigma_evals", i) for i in range(4)] + \
+        [("perm_next_eval", None)]
+    for name, i in ev_fields:
+        pr_ = make_proof(pts, evals)
+        tgt = getattr(pr_, name) if i is None else getattr(pr_, name)[i]
+        _add_to_words(tgt, bn.R)
+        assert not cg.plonk_verify(vk0, h2, bh, pub_arr, pr_, msg), f"{name}[{i}] + r accepted"
+    # the 13 proof points: + p on x, then on y
+    pt_fields = [("wires_poly_comms", i) for i in range(5)] + [("prod_perm_poly_comm", None)] + \
+        [("split_quot_poly_comms", i) for i in range(5)] + [("opening_proof", None), ("shifted_opening_proof", None)]
+    for name, i in pt_fields:
+        for off in (0, 4):
+            pr_ = make_proof(pts, evals)
+            tgt = getattr(pr_, name) if i is None else getattr(pr_, name)[i]
+            view = (ctypes.c_uint64 * 4).from_buffer(tgt, 8 * off)
+            _add_to_words(view, bn.P)
+            assert not cg.plonk_verify(vk0, h2, bh, pub_arr, pr_, msg), f"{name}[{i}] coordinate {off // 4} + p accepted"
+    # verifying-key points and coset constants
+    for name, cnt in (("selector_comms", 13), ("sigma_comms", 5)):
+        for i in range(cnt):
+            vk = make_vk(n, nin, sel, sig)
+            _add_to_words((ctypes.c_uint64 * 4).from_buffer(getattr(vk, name)[i], 0), bn.P)
+            assert not cg.plonk_verify(vk, h2, bh, pub_arr, proof0, msg), f"vk.{name}[{i}].x + p accepted"
+    vk = make_vk(n, nin, sel, sig)
+    _add_to_words(vk.k[1], bn.R)
+    assert not cg.plonk_verify(vk, h2, bh, pub_arr, proof0, msg)
+    # G2 open key with a non-canonical coordinate is a malformed argument
+    bad_h = np.asarray(h2, dtype=np.uint64).copy()
+    bad_h[0:4] = cr.int_to_limbs(cr.array_to_ints(bad_h[0:4])[0] + bn.P)
+    with pytest.raises(cg.CapGpuError):
+        cg.plonk_verify(vk0, bad_h, bh, pub_arr, proof0, msg)
+    # pairing_check refuses non-canonical G1 input
+    g1 = cr.points_to_array([bn.G1_GEN])
+    g1[0, 0:4] = cr.int_to_limbs(cr.array_to_ints(g1[0, 0:4])[0] + bn.P)
+    with pytest.raises(cg.CapGpuError):
+        cg.pairing_check(g1, np.asarray(h2)[None])
+
+
 def test_batch_verify_and_proof_serialization(tau):
     """txn_batch_verify counterpart (src/lib.rs:455-529): proofs of two different circuits under one SRS."""
     h2 = cg.g2_generator()
