@@ -237,6 +237,73 @@ struct Fl {
     r.v[8] = (uint32_t)c[17];
     return r;
   }
+  // Two schedules of the same arithmetic (identical results, identical column sums, so identical bounds):
+  //  * row-wise (operand scanning): 18 independent 64-bit column accumulators, every product lands in its column,
+  //    then the carries walk up with a shift + 64-bit add per column;
+  //  * column-wise (product scanning, CAP_FL_COLWISE): one running accumulator per column that starts from the carry
+  //    of the column below, so the carry add is the addend of a v_mad_u64_u32 instead of its own instruction
+  //    (16 fewer instructions of ~220 per multiplication; measured in tools/ubench_mulcol.hip).
+#ifdef CAP_FL_COLWISE
+  // column sums of prod(i, j) over i + j = k; PROD: number of (a, b) operand pairs (1 or 2)
+  template <class ProdFn>
+  static CAP_HD fl montmul_cols(ProdFn prod_col) {
+    uint32_t m[9];
+    fl r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 17; k++) {
+      acc = prod_col(k, acc);
+      if (k < 9) {
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * PR::MOD[k - i];
+        m[k] = mul_lo32((uint32_t)acc, PR::NINV) & M29;
+        acc += (uint64_t)m[k] * PR::MOD[0];
+      } else {
+#pragma unroll
+        for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * PR::MOD[k - i];
+        r.v[k - 9] = (uint32_t)acc & M29;
+      }
+      acc >>= 29;
+    }
+    CAP_FL_ASSERT(acc < (1ull << 29));
+    r.v[8] = (uint32_t)acc;
+    return r;
+  }
+  static CAP_HD fl mul(const fl& a, const fl& b) {
+    return montmul_cols([&](int k, uint64_t acc) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        const int j = k - i;
+        if (j >= 0 && j < 9) acc += (uint64_t)a.v[i] * b.v[j];
+      }
+      return acc;
+    });
+  }
+  static CAP_HD fl sqr(const fl& a) {
+    uint32_t d[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;  // limbs < 2^30 -> < 2^31
+    return montmul_cols([&](int k, uint64_t acc) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        const int j = k - i;
+        if (j > i && j < 9) acc += (uint64_t)d[i] * a.v[j];
+        if (j == i) acc += (uint64_t)a.v[i] * a.v[i];
+      }
+      return acc;
+    });
+  }
+  static CAP_HD fl mul_add_mul(const fl& a, const fl& b, const fl& c2, const fl& d) {
+    return montmul_cols([&](int k, uint64_t acc) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        const int j = k - i;
+        if (j >= 0 && j < 9) acc += (uint64_t)a.v[i] * b.v[j] + (uint64_t)c2.v[i] * d.v[j];
+      }
+      return acc;
+    });
+  }
+#else
   static CAP_HD fl mul(const fl& a, const fl& b) {
     uint64_t c[18];
 #pragma unroll
@@ -273,6 +340,8 @@ struct Fl {
       for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)a.v[i] * b.v[j] + (uint64_t)c2.v[i] * d.v[j];
     return reduce_cols(c);
   }
+
+#endif
 
   // ---- forms ---------------------------------------------------------------------------------------------
   static CAP_HD fl konst(const uint32_t (&k)[9]) {

@@ -22,14 +22,17 @@ def _cxx():
     pytest.skip("no host C++ compiler")
 
 
-@pytest.fixture(scope="module")
-def binaries(tmp_path_factory):
-    out = tmp_path_factory.mktemp("f29")
+@pytest.fixture(scope="module", params=["rowwise", "colwise"])
+def binaries(tmp_path_factory, request):
+    """Both schedules of the Montgomery multiplication (field29.hpp: row-wise column accumulators / column-wise with
+    the carry as the multiply-add's addend) are built and must give the same results within the same bounds."""
+    out = tmp_path_factory.mktemp("f29" + request.param)
     cxx = _cxx()
     bins = {}
     for name in ("field29_check", "curve29_check"):
         exe = str(out / name)
-        subprocess.check_call([cxx, "-O1", "-std=c++17", os.path.join(CPP, name + ".cpp"), "-o", exe])
+        flags = ["-DCAP_FL_COLWISE"] if request.param == "colwise" else ["-DCAP_FL_ROWWISE"]
+        subprocess.check_call([cxx, "-O1", "-std=c++17"] + flags + [os.path.join(CPP, name + ".cpp"), "-o", exe])
         bins[name] = exe
     return bins
 
