@@ -474,6 +474,18 @@ int capgpu_msm_g1_dev(uint64_t srs_handle, size_t offset, const void* d_scalars,
   return take_launch_error();
 }
 
+int capgpu_msm_plan(uint64_t srs_handle, size_t n, int count, char* buf, size_t cap) {
+  CAP_CHECK_INIT();
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  const MsmBases* B = nullptr;
+  int rc = find_srs(srs_handle, &B);
+  if (rc) return rc;
+  if (!buf || cap == 0 || count < 1 || n > B->n) return CAPGPU_ERR_INVALID_ARG;
+  msm_plan_describe(*B, n, (uint32_t)count, buf, cap);
+  return CAPGPU_OK;
+}
+
 int capgpu_msm_g1_batch(uint64_t srs_handle, const size_t* offsets, const uint64_t* const* scalars, const size_t* ns,
                         int count, uint64_t* out_xyz) {
   CAP_CHECK_INIT();

@@ -82,7 +82,34 @@ static CAP_HD uint32_t mul_lo32(uint32_t a, uint32_t b) {
 #endif
 }
 
-template <class PR>
+// SCHED selects the schedule of the Montgomery multiplication (same arithmetic, same results, same bounds):
+//   0  row-wise (operand scanning): 18 independent 64-bit column accumulators, every product lands in its column,
+//      then the carries walk up with a 64-bit shift + add per column.  Best where a kernel keeps many independent
+//      multiplications in flight (NTT butterflies, the quotient kernel).
+//   1  column-wise (product scanning): one running accumulator per column that starts from the carry of the column
+//      below, so the carry add is the addend of a v_mad_u64_u32 instead of its own instruction: 204 instead of 220
+//      instructions per multiplication.  On gfx950 every one of these instructions issues at the same rate
+//      (tools/ubench_mulcol.hip: v_mad_u64_u32 36 T lane-ops/s = one wave instruction per 4 cycles per SIMD), so the
+//      count is the cost: 172 instead of 139-158 G multiplications/s in isolation.  Used by the MSM kernels.
+// A translation unit picks its default with CAP_FL_SCHED (the two instantiations are distinct types).
+#ifndef CAP_FL_SCHED
+#ifdef CAP_FL_COLWISE
+#define CAP_FL_SCHED 1
+#else
+#define CAP_FL_SCHED 0
+#endif
+#endif
+// LLVM's reassociation pass would sort the addends of a column by rank and add the carry (the youngest value) last,
+// as a separate 64-bit add - the row-wise code again.  A second, empty use of every partial sum stops it from
+// merging the additions into one expression tree (it only walks through single-use values), so each
+// "acc += x * y" stays a multiply-add whose addend is the running sum.  No instruction is emitted for it.
+#if defined(__HIP_DEVICE_COMPILE__)
+#define CAP_FL_KEEP(x) asm volatile("" ::"v"(x))
+#else
+#define CAP_FL_KEEP(x) ((void)0)
+#endif
+
+template <class PR, int SCHED = CAP_FL_SCHED>
 struct Fl {
   static constexpr uint32_t M29 = 0x1fffffffu;
 
@@ -237,14 +264,7 @@ struct Fl {
     r.v[8] = (uint32_t)c[17];
     return r;
   }
-  // Two schedules of the same arithmetic (identical results, identical column sums, so identical bounds):
-  //  * row-wise (operand scanning): 18 independent 64-bit column accumulators, every product lands in its column,
-  //    then the carries walk up with a shift + 64-bit add per column;
-  //  * column-wise (product scanning, CAP_FL_COLWISE): one running accumulator per column that starts from the carry
-  //    of the column below, so the carry add is the addend of a v_mad_u64_u32 instead of its own instruction
-  //    (16 fewer instructions of ~220 per multiplication; measured in tools/ubench_mulcol.hip).
-#ifdef CAP_FL_COLWISE
-  // column sums of prod(i, j) over i + j = k; PROD: number of (a, b) operand pairs (1 or 2)
+  // ---- column-wise schedule ---------------------------------------------------------------------------
   template <class ProdFn>
   static CAP_HD fl montmul_cols(ProdFn prod_col) {
     uint32_t m[9];
@@ -255,12 +275,18 @@ struct Fl {
       acc = prod_col(k, acc);
       if (k < 9) {
 #pragma unroll
-        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * PR::MOD[k - i];
+        for (int i = 0; i < k; i++) {
+          acc += (uint64_t)m[i] * PR::MOD[k - i];
+          CAP_FL_KEEP(acc);
+        }
         m[k] = mul_lo32((uint32_t)acc, PR::NINV) & M29;
         acc += (uint64_t)m[k] * PR::MOD[0];
       } else {
 #pragma unroll
-        for (int i = k - 8; i < 9; i++) acc += (uint64_t)m[i] * PR::MOD[k - i];
+        for (int i = k - 8; i < 9; i++) {
+          acc += (uint64_t)m[i] * PR::MOD[k - i];
+          CAP_FL_KEEP(acc);
+        }
         r.v[k - 9] = (uint32_t)acc & M29;
       }
       acc >>= 29;
@@ -269,17 +295,20 @@ struct Fl {
     r.v[8] = (uint32_t)acc;
     return r;
   }
-  static CAP_HD fl mul(const fl& a, const fl& b) {
+  static CAP_HD fl mul_col(const fl& a, const fl& b) {
     return montmul_cols([&](int k, uint64_t acc) {
 #pragma unroll
       for (int i = 0; i < 9; i++) {
         const int j = k - i;
-        if (j >= 0 && j < 9) acc += (uint64_t)a.v[i] * b.v[j];
+        if (j >= 0 && j < 9) {
+          acc += (uint64_t)a.v[i] * b.v[j];
+          CAP_FL_KEEP(acc);
+        }
       }
       return acc;
     });
   }
-  static CAP_HD fl sqr(const fl& a) {
+  static CAP_HD fl sqr_col(const fl& a) {
     uint32_t d[9];
 #pragma unroll
     for (int i = 0; i < 9; i++) d[i] = a.v[i] << 1;  // limbs < 2^30 -> < 2^31
@@ -287,24 +316,36 @@ struct Fl {
 #pragma unroll
       for (int i = 0; i < 9; i++) {
         const int j = k - i;
-        if (j > i && j < 9) acc += (uint64_t)d[i] * a.v[j];
-        if (j == i) acc += (uint64_t)a.v[i] * a.v[i];
+        if (j > i && j < 9) {
+          acc += (uint64_t)d[i] * a.v[j];
+          CAP_FL_KEEP(acc);
+        }
+        if (j == i) {
+          acc += (uint64_t)a.v[i] * a.v[i];
+          CAP_FL_KEEP(acc);
+        }
       }
       return acc;
     });
   }
-  static CAP_HD fl mul_add_mul(const fl& a, const fl& b, const fl& c2, const fl& d) {
+  static CAP_HD fl mul_add_mul_col(const fl& a, const fl& b, const fl& c2, const fl& d) {
     return montmul_cols([&](int k, uint64_t acc) {
 #pragma unroll
       for (int i = 0; i < 9; i++) {
         const int j = k - i;
-        if (j >= 0 && j < 9) acc += (uint64_t)a.v[i] * b.v[j] + (uint64_t)c2.v[i] * d.v[j];
+        if (j >= 0 && j < 9) {
+          acc += (uint64_t)a.v[i] * b.v[j];
+          CAP_FL_KEEP(acc);
+          acc += (uint64_t)c2.v[i] * d.v[j];
+          CAP_FL_KEEP(acc);
+        }
       }
       return acc;
     });
   }
-#else
+  // ---- row-wise schedule ------------------------------------------------------------------------------
   static CAP_HD fl mul(const fl& a, const fl& b) {
+    if constexpr (SCHED == 1) return mul_col(a, b);
     uint64_t c[18];
 #pragma unroll
     for (int k = 0; k < 18; k++) c[k] = 0;
@@ -315,6 +356,7 @@ struct Fl {
     return reduce_cols(c);
   }
   static CAP_HD fl sqr(const fl& a) {
+    if constexpr (SCHED == 1) return sqr_col(a);
     uint64_t c[18];
 #pragma unroll
     for (int k = 0; k < 18; k++) c[k] = 0;
@@ -331,6 +373,7 @@ struct Fl {
   }
   // a*b + c*d with one reduction (all four operands normalized: 18 products of < 2^58 per column)
   static CAP_HD fl mul_add_mul(const fl& a, const fl& b, const fl& c2, const fl& d) {
+    if constexpr (SCHED == 1) return mul_add_mul_col(a, b, c2, d);
     uint64_t c[18];
 #pragma unroll
     for (int k = 0; k < 18; k++) c[k] = 0;
@@ -340,8 +383,6 @@ struct Fl {
       for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)a.v[i] * b.v[j] + (uint64_t)c2.v[i] * d.v[j];
     return reduce_cols(c);
   }
-
-#endif
 
   // ---- forms ---------------------------------------------------------------------------------------------
   static CAP_HD fl konst(const uint32_t (&k)[9]) {

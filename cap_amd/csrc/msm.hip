@@ -1,12 +1,15 @@
 // K3-K6: Pippenger MSM over BN254 G1 with fixed-base window precomputation.
-// Design notes in msm.hpp.  Kernel sequence for one (batched) MSM:
-//   msm_digits_hist   K3  scalar -> signed base-2^c digits, histogram rank per (digit, bucket)
-//   msm_scan          K4  exclusive scan of bucket counts
-//   msm_scatter       K4  counting-sort scatter of table indices into bucket lists
-//   msm_accumulate    K5  one thread per work item (<= 32 list entries): mixed adds of gathered 64 B points
+// Design notes in msm.hpp.  Kernel sequence for one launch (a batch of MSMs; a long MSM is itself cut into a batch of
+// sub-MSMs over consecutive point ranges, see "parts" below):
+//   msm_digits_local  K3  tile of 1024 scalars -> signed base-2^c digits, counting-sorted by bucket (or bin) in LDS
+//   msm_scan*         K4  exclusive scan of the [key][tile] count table
+//   msm_scatter_runs  K4  one-level sort (c = 13): run copies;  msm_sort_level2: per-bin LDS sort (c = 15)
+//   msm_accumulate    K5  one thread per work item: mixed adds of gathered 64 B points
 //   msm_combine       K5  bucket = sum of its work items
-//   msm_reduce_bits   K6  T_b = sum of buckets whose weight has bit b set (log-depth trees)
-//   msm_reduce_final  K6  sum_b 2^b T_b  ->  one Jacobian point per MSM
+//   msm_reduce_*      K6  running sums over segments (large batches) or bit planes (log depth) -> one point per sub-MSM
+//   msm_sum_parts     K6  sum of the sub-MSM results of one MSM
+// the MSM kernels run long dependent chains of field multiplications per thread: column-wise schedule (field29.hpp)
+#define CAP_FL_SCHED 1
 #include "msm.hpp"
 #include "curve29.hpp"
 #include "launch.hpp"
@@ -18,7 +21,6 @@ namespace cap {
 
 namespace {
 
-constexpr uint32_t kSkip = 0xFFFFFFFFu;
 constexpr int kThreads = 256;
 constexpr uint32_t kDigitTile = 1024;    // scalars per msm_digits_local workgroup (its entries are sorted in LDS)
 constexpr int kDigitThreads = 1024;       // one scalar per thread: 16 waves hide the LDS-atomic latency
@@ -67,54 +69,9 @@ __global__ __launch_bounds__(kThreads) void msm_precompute_kernel(g1_affine* __r
   }
 }
 
-// ---- K3: digits + histogram ----------------------------------------------------------------
-// one thread per (batch, i).  keys[(b*W + w)*n + i] = (bucket | sign << 31) or kSkip.
-__global__ __launch_bounds__(kThreads) void msm_digits_hist(const fe* __restrict__ scalars, size_t outer_stride,
-                                                            uint32_t inner, size_t inner_stride,
-                                                            size_t n, uint32_t batch, int montgomery, uint32_t c,
-                                                            uint32_t windows, uint32_t* __restrict__ counts,
-                                                            uint32_t* __restrict__ keys,
-                                                            uint32_t* __restrict__ ranks) {
-  size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (t >= n * batch) return;
-  uint32_t b = (uint32_t)(t / n);
-  size_t i = t - (size_t)b * n;
-  fe k = scalars[(size_t)(b / inner) * outer_stride + (size_t)(b % inner) * inner_stride + i];
-  if (montgomery) k = Fr::from_mont(k);
-  const uint32_t half = 1u << (c - 1);
-  const uint32_t mask = (1u << c) - 1;
-  uint32_t carry = 0;
-  for (uint32_t w = 0; w < windows; w++) {
-    uint32_t bit = w * c;
-    uint32_t limb = bit >> 5, off = bit & 31;
-    uint32_t v = 0;
-    if (limb < 8) {
-      uint64_t two = (uint64_t)k.v[limb] | (limb + 1 < 8 ? ((uint64_t)k.v[limb + 1] << 32) : 0);
-      v = (uint32_t)(two >> off) & mask;
-    }
-    v += carry;
-    uint32_t neg = 0;
-    if (v > half) {
-      v = (1u << c) - v;
-      neg = 1;
-      carry = 1;
-    } else {
-      carry = 0;
-    }
-    size_t e = ((size_t)b * windows + w) * n + i;
-    if (v == 0) {
-      keys[e] = kSkip;
-    } else {
-      uint32_t bucket = v - 1;
-      uint32_t r = atomicAdd(&counts[(size_t)b * half + bucket], 1u);
-      keys[e] = bucket | (neg << 31);
-      ranks[e] = r;
-    }
-  }
-}
-
-// K3, LDS form (used whenever the bucket set fits LDS): a workgroup owns a tile of kDigitTile scalars of one batch
-// entry and sorts that tile's (window, scalar) entries by bucket entirely in LDS: pass A histograms the digits,
+// ---- K3: digits, sorted per tile in LDS --------------------------------------------------------------------------
+// A workgroup owns a tile of kDigitTile scalars of one (sub-)MSM and sorts that tile's (window, scalar) entries by
+// bucket entirely in LDS: pass A histograms the digits,
 // a workgroup scan turns counts into tile-local offsets, pass B recomputes the digits and drops each table index
 // at its slot.  The tile-sorted chunk goes to HBM with coalesced stores together with one row of the
 // [bucket][tile] count table and of the tile-local offset table.  A scan of the count table (bucket-major) then
@@ -165,12 +122,22 @@ __device__ __forceinline__ void all_digits(const fe& k, uint32_t& carry, uint32_
   }
 }
 
+// A tile's entries do not carry table indices but (window, scalar-within-tile): 15 bits.  The consumer of a run knows
+// which tile it reads and rebuilds the index  w * srs_n + base + tile * 1024 + t  (tile_entry_index), so the table may
+// hold up to 2^31 points whatever the tile format.  Layout of a tile entry:
+//   bits 0-9 t, 10-14 w, 15-21 tile (filled in by msm_sort_level2), 24-30 low bucket bits (two-level sort), 31 sign.
+__device__ __forceinline__ uint32_t tile_entry_index(uint32_t v, uint32_t tile, size_t srs_n, size_t base) {
+  return (uint32_t)((size_t)((v >> 10) & 31u) * srs_n + base + (size_t)tile * kDigitTile + (v & 1023u));
+}
+
+// Sub-MSM `sb` of a launch = (MSM b = sb / parts, part = sb % parts): scalars [part * n_sub, part * n_sub + len) of MSM
+// b, where len = min(n_sub, n - part * n_sub).
 template <uint32_t CT>  // CT = 13 / 15: window size known at compile time; 0: taken from the argument c
 __global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __restrict__ scalars, size_t outer_stride,
-                                                             uint32_t inner, size_t inner_stride, size_t n,
+                                                             uint32_t inner, size_t inner_stride, size_t n_total,
+                                                             size_t n_sub, uint32_t parts,
                                                              int montgomery, uint32_t c, uint32_t windows,
-                                                             uint32_t nblk, uint32_t batch, size_t srs_n,
-                                                             size_t base_offset, uint32_t sub_bits,
+                                                             uint32_t nblk, uint32_t batch, uint32_t sub_bits,
                                                              uint32_t* __restrict__ table,
                                                              uint32_t* __restrict__ tloc,
                                                              uint32_t* __restrict__ chunks) {
@@ -191,7 +158,10 @@ __global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __re
   if (b >= batch) return;
   for (uint32_t j = threadIdx.x; j < half; j += kDigitThreads) hist[j] = 0;
   __syncthreads();
-  const fe* sc = scalars + (size_t)(b / inner) * outer_stride + (size_t)(b % inner) * inner_stride;
+  const uint32_t msm = b / parts, part = b % parts;
+  const size_t n = n_total - (size_t)part * n_sub < n_sub ? n_total - (size_t)part * n_sub : n_sub;
+  const fe* sc = scalars + (size_t)(msm / inner) * outer_stride + (size_t)(msm % inner) * inner_stride +
+                 (size_t)part * n_sub;
   static_assert(kDigitTile == kDigitThreads, "one scalar per thread: it stays in registers between the passes");
   const size_t i = (size_t)blk * kDigitTile + threadIdx.x;
   // CT != 0: the digits are extracted once, with compile-time limb indices, and live in registers across both passes
@@ -255,8 +225,7 @@ __global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __re
       const uint32_t mag = d & 0x7FFFFFFFu;
       if (mag) {
         uint32_t pos = atomicAdd(&hist[(mag - 1) >> sub_bits], 1u);
-        buf[pos] = (uint32_t)((size_t)w * srs_n + base_offset + i) | (((mag - 1) & sub_mask) << 24) |
-                   (d & 0x80000000u);
+        buf[pos] = (w << 10) | threadIdx.x | (((mag - 1) & sub_mask) << 24) | (d & 0x80000000u);
       }
     };
     if constexpr (CT != 0) {
@@ -296,7 +265,9 @@ __global__ __launch_bounds__(kThreads) void msm_scatter_runs(const uint32_t* __r
                                                              const uint32_t* __restrict__ tloc,
                                                              const uint32_t* __restrict__ off2, size_t per,
                                                              uint32_t half, uint32_t nblk, uint32_t windows,
-                                                             size_t total_rows, uint32_t* __restrict__ sorted) {
+                                                             size_t total_rows, size_t srs_n, size_t offset,
+                                                             size_t n_sub, uint32_t parts,
+                                                             uint32_t* __restrict__ sorted) {
   size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b * half + bucket) * nblk + blk
   if (row >= total_rows) return;
   uint32_t cnt = table[row];
@@ -305,7 +276,11 @@ __global__ __launch_bounds__(kThreads) void msm_scatter_runs(const uint32_t* __r
   uint32_t b = (uint32_t)(row / ((size_t)half * nblk));
   const uint32_t* src = chunks + ((size_t)b * nblk + blk) * ((size_t)kDigitTile * windows) + tloc[row];
   uint32_t* dst = sorted + (size_t)b * per + off2[row];
-  for (uint32_t e = 0; e < cnt; e++) dst[e] = src[e];
+  const size_t base = offset + (size_t)(b % parts) * n_sub;
+  for (uint32_t e = 0; e < cnt; e++) {
+    const uint32_t v = src[e];
+    dst[e] = tile_entry_index(v, blk, srs_n, base) | (v & 0x80000000u);  // tile entry -> table index | sign
+  }
 }
 
 // ---- K4, second level of the two-level sort ---------------------------------------------------------------------
@@ -317,14 +292,17 @@ __global__ __launch_bounds__(kThreads) void msm_scatter_runs(const uint32_t* __r
 // 4-byte stores stay in L2).  Up to kL2Stage entries are staged in LDS between the passes; the rest of an oversized
 // bin (skewed scalars) is simply fetched again, so any bin size works.
 constexpr uint32_t kL2Stage = 6144;  // entries of a bin staged in LDS between the two passes (24 KiB)
-constexpr uint32_t kL2MaxTiles = 72;  // tiles per batch entry the run table in LDS holds (covers n = 2^16 + 3)
+constexpr uint32_t kL2MaxTiles = 72;  // tiles per sub-MSM the run table in LDS holds (7-bit tile field; n = 2^16 + 3 fits)
+constexpr size_t kMaxSubPoints = (size_t)kL2MaxTiles * kDigitTile;  // longer MSMs are cut into parts (choose_plan)
 
 __global__ __launch_bounds__(kThreads) void msm_sort_level2(const uint32_t* __restrict__ chunks,
                                                             const uint32_t* __restrict__ table,
                                                             const uint32_t* __restrict__ tloc,
                                                             const uint32_t* __restrict__ off2, size_t per,
                                                             uint32_t bins, uint32_t nblk, uint32_t windows,
-                                                            uint32_t sub_bits, uint32_t* __restrict__ counts,
+                                                            uint32_t sub_bits, size_t srs_n, size_t offset,
+                                                            size_t n_sub, uint32_t parts,
+                                                            uint32_t* __restrict__ counts,
                                                             uint32_t* __restrict__ offsets,
                                                             uint32_t* __restrict__ sorted) {
   // The bin's entries are read straight from the tile-sorted chunks (one run per tile, ~140 entries each): the
@@ -363,7 +341,11 @@ __global__ __launch_bounds__(kThreads) void msm_sort_level2(const uint32_t* __re
       uint32_t mid = (lo + hi) >> 1;
       if (run_pre[mid] <= p) lo = mid; else hi = mid;
     }
-    return cbase[run_src[lo] + (p - run_pre[lo])];
+    return cbase[run_src[lo] + (p - run_pre[lo])] | (lo << 15);  // the entry remembers the tile it came from
+  };
+  const size_t base = offset + (size_t)(b % parts) * n_sub;
+  auto final_entry = [&](uint32_t v) {  // tile entry -> table index | sign
+    return tile_entry_index(v, (v >> 15) & 127u, srs_n, base) | (v & 0x80000000u);
   };
   // pass A: the first kL2Stage entries stay in registers (24 per thread), the tail of an oversized bin is re-fetched
   constexpr int kPerThread = kL2Stage / kThreads;
@@ -405,8 +387,8 @@ __global__ __launch_bounds__(kThreads) void msm_sort_level2(const uint32_t* __re
   uint32_t* dst = sorted + (size_t)b * per + off;
   auto place = [&](uint32_t v) {
     const uint32_t pos = atomicAdd(&start[(v >> 24) & (nsub - 1)], 1u);
-    if (pos < kL2Stage) stage[pos] = v & 0x80FFFFFFu;
-    else dst[pos] = v & 0x80FFFFFFu;
+    if (pos < kL2Stage) stage[pos] = final_entry(v);
+    else dst[pos] = final_entry(v);
   };
 #pragma unroll
   for (int i = 0; i < kPerThread; i++)
@@ -551,15 +533,33 @@ __global__ __launch_bounds__(kThreads) void msm_combine_wave(const g1_xyzz* __re
   if (lane == 0 && items != 1) buckets[gb] = G1L::store(acc);
 }
 
-// item_base[b] = sum of totals[0..b), item_base[batch] = number of work items of the whole launch
-__global__ void msm_item_bases(const uint32_t* __restrict__ totals, uint32_t batch, uint32_t* __restrict__ item_base) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
-  uint32_t acc = 0;
-  for (uint32_t b = 0; b < batch; b++) {
-    item_base[b] = acc;
-    acc += totals[b];
+// item_base[b] = sum of totals[0..b), item_base[batch] = number of work items of the whole launch.
+// One workgroup of 1024 threads: block scans over slabs of 1024 entries (a long MSM run as thousands of sub-MSMs made
+// the former single-thread loop a visible serial step).
+__global__ __launch_bounds__(1024) void msm_item_bases(const uint32_t* __restrict__ totals, uint32_t batch,
+                                                       uint32_t* __restrict__ item_base) {
+  __shared__ uint32_t sh[1024];
+  __shared__ uint32_t carry_s;
+  if (threadIdx.x == 0) carry_s = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < batch; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t x = i < batch ? totals[i] : 0;
+    sh[threadIdx.x] = x;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+      uint32_t add = threadIdx.x >= d ? sh[threadIdx.x - d] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += add;
+      __syncthreads();
+    }
+    const uint32_t carry = carry_s;
+    if (i < batch) item_base[i] = carry + sh[threadIdx.x] - x;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry_s = carry + sh[1023];
+    __syncthreads();
   }
-  item_base[batch] = acc;
+  if (threadIdx.x == 0) item_base[batch] = carry_s;
 }
 
 // Work items of one batch entry, ordered by length (longest first): slot -> (bucket, sub-item).  Bucket sizes are
@@ -620,28 +620,6 @@ __global__ __launch_bounds__(1024) void msm_sort_items(const uint32_t* __restric
       item_sub[pos + k - r] = k;
     }
   }
-}
-
-__global__ __launch_bounds__(kThreads) void msm_scatter(const uint32_t* __restrict__ keys,
-                                                        const uint32_t* __restrict__ ranks,
-                                                        const uint32_t* __restrict__ offsets, size_t n,
-                                                        uint32_t batch, uint32_t c, uint32_t windows,
-                                                        size_t srs_n, size_t base_offset,
-                                                        uint32_t* __restrict__ sorted) {
-  size_t per = (size_t)windows * n;
-  size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e >= per * batch) return;
-  uint32_t key = keys[e];
-  if (key == kSkip) return;
-  uint32_t b = (uint32_t)(e / per);
-  size_t rem = e - (size_t)b * per;
-  uint32_t w = (uint32_t)(rem / n);
-  size_t i = rem - (size_t)w * n;
-  const uint32_t half = 1u << (c - 1);
-  uint32_t bucket = key & 0x7FFFFFFFu;
-  uint32_t pos = offsets[(size_t)b * half + bucket] + ranks[e];
-  uint32_t tidx = (uint32_t)((size_t)w * srs_n + base_offset + i);
-  sorted[(size_t)b * per + pos] = tidx | (key & 0x80000000u);
 }
 
 // ---- K5: bucket accumulation --------------------------------------------------------------------
@@ -726,8 +704,11 @@ __device__ g1x mul_small(const g1x& p, uint32_t k) {
 // repeats the running-sum walk one level up; the lane weights come from a suffix scan across the wave:
 // sum_l l S_l = sum_{m >= 1} (S_m + S_{m+1} + ... + S_63).  The whole kernel is one dependent chain of ~30 point
 // operations per launch, so it is written for depth, not for work.
+// out (one Jacobian point per MSM) or, when the MSMs of the launch are parts of longer ones, out_part (XYZZ, summed by
+// msm_sum_parts)
 __global__ __launch_bounds__(64) void msm_reduce_final(const g1_xyzz* __restrict__ seg_pts, uint32_t seg_len,
-                                                       uint32_t nseg, g1_jac* __restrict__ out) {
+                                                       uint32_t nseg, g1_jac* __restrict__ out,
+                                                       g1_xyzz* __restrict__ out_part) {
   const uint32_t b = blockIdx.x, lane = threadIdx.x;
   const uint32_t q = (nseg + 63) / 64;
   const uint32_t s_lo = lane * q;
@@ -752,7 +733,10 @@ __global__ __launch_bounds__(64) void msm_reduce_final(const g1_xyzz* __restrict
   g1x r = G1L::add(T, mul_small(suf, q));
   r = G1L::add(mul_small(r, seg_len), A);
   r = wave_sum(r);
-  if (lane == 0) out[b] = G1L::to_jac_ext(r);
+  if (lane == 0) {
+    if (out_part) out_part[b] = G1L::store(r);
+    else out[b] = G1L::to_jac_ext(r);
+  }
 }
 
 // ---- K6 for small batches --------------------------------------------------------------------------------------
@@ -818,7 +802,8 @@ __global__ __launch_bounds__(kThreads) void msm_reduce_bits(const g1_xyzz* __res
 // ---- K6b: sum_b 2^b T_b ------------------------------------------------------------------------------
 // one wavefront per batch entry; lane = bit.
 __global__ __launch_bounds__(64) void msm_reduce_bits_final(const g1_xyzz* __restrict__ partial, uint32_t c,
-                                                       uint32_t chunks, g1_jac* __restrict__ out) {
+                                                       uint32_t chunks, g1_jac* __restrict__ out,
+                                                       g1_xyzz* __restrict__ out_part) {
   const uint32_t b = blockIdx.x, lane = threadIdx.x;
   g1x acc = G1L::inf();
   if (lane < c) {
@@ -833,14 +818,32 @@ __global__ __launch_bounds__(64) void msm_reduce_bits_final(const g1_xyzz* __res
     g1x o = shfl_down_pt(acc, d);
     acc = G1L::add(acc, o);
   }
+  if (lane == 0) {
+    if (out_part) out_part[b] = G1L::store(acc);
+    else out[b] = G1L::to_jac_ext(acc);
+  }
+}
+
+// out[b] = sum of the `parts` sub-MSM results of MSM b (one wavefront per MSM)
+__global__ __launch_bounds__(64) void msm_sum_parts(const g1_xyzz* __restrict__ part_pts, uint32_t parts,
+                                                    g1_jac* __restrict__ out) {
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  g1x acc = G1L::inf();
+  for (uint32_t k = lane; k < parts; k += 64) acc = G1L::add(acc, G1L::load(part_pts[(size_t)b * parts + k]));
+  acc = wave_sum(acc);
   if (lane == 0) out[b] = G1L::to_jac_ext(acc);
+}
+// an MSM over no points
+__global__ void msm_fill_inf(g1_jac* __restrict__ out, uint32_t batch) {
+  const uint32_t b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < batch) out[b] = G1L::to_jac_ext(G1L::inf());
 }
 
 size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 struct WsLayout {
-  size_t counts, offsets, keys, ranks, sorted, buckets, partial, item_off, item_base, totals, item_bucket, item_sub, item_pts,
-      max_items, table, off2, tloc, chunks, nblk, seg_tot, total;
+  size_t counts, offsets, sorted, buckets, partial, item_off, item_base, totals, item_bucket, item_sub, item_pts, max_items,
+      table, off2, tloc, chunks, nblk, seg_tot, part_pts, total;
 };
 
 // which table / sort a launch uses
@@ -854,16 +857,51 @@ uint32_t wide_c() {
   return v;
 }
 constexpr uint32_t kSubBits = 7;  // buckets per level-1 bin = 128
+// A launch = `batch` MSMs of n points, each cut into `parts` sub-MSMs over consecutive ranges of n_sub points (the last
+// one shorter).  Every kernel below sees batch * parts independent MSMs of at most n_sub points; msm_sum_parts adds
+// the parts.  This is how one long MSM (2^19 .. 2^24 points) gets the chip-filling batched path: 2^24 points are 256
+// sub-MSMs of 2^16, whose bucket reductions cost 4 % of the bucket accumulation.
 struct Plan {
   uint32_t c, windows, sub_bits;
   const g1_affine* ext;
+  uint32_t parts;
+  size_t n_sub;
 };
+size_t split_target() {  // sub-MSMs a long MSM is cut into at least (when it has the points for it)
+  static const size_t v = [] {
+    const char* e = getenv("CAPGPU_MSM_SPLIT");
+    int x = e ? atoi(e) : 64;
+    return (size_t)(x >= 1 && x <= 4096 ? x : 64);
+  }();
+  return v;
+}
 Plan choose_plan(const MsmBases& bases, size_t n, uint32_t batch) {
+  Plan pl{bases.c, bases.windows, 0, bases.ext, 1, n};
+  const bool primary_wide = bases.c >= 14;  // tables of more than 2^18 points hold the wide windows only
+  if (primary_wide) {
+    pl.sub_bits = kSubBits;
+    // enough sub-MSMs to fill the chip (the running-sum reduction wants >= 64), none shorter than 8192 points (below
+    // that the 16384-bucket reduction of a part costs more than a third of its accumulation) nor longer than the
+    // level-2 sort's run table
+    size_t want = (n * batch + split_target() - 1) / split_target();
+    want = std::max<size_t>(want, 8192);
+    want = std::min<size_t>(align_up(want, kDigitTile), (size_t)64 * kDigitTile);
+    if (n > want) {
+      pl.n_sub = want;
+      pl.parts = (uint32_t)((n + want - 1) / want);
+    }
+    return pl;
+  }
   // wide windows pay off once (a) the batch alone gives every CU work, so that the 4x larger bucket set costs two
   // running-sum additions per bucket instead of a log-depth tree, and (b) buckets still hold several entries
-  if (bases.ext2 && batch >= 32 && n >= 4096 && n <= (size_t)kL2MaxTiles * kDigitTile)
-    return {bases.c2, bases.windows2, kSubBits, bases.ext2};
-  return {bases.c, bases.windows, 0, bases.ext};
+  if (bases.ext2 && n >= 4096) {
+    uint32_t parts = n > kMaxSubPoints ? (uint32_t)((n + 65535) / 65536) : 1;
+    if ((size_t)batch * parts >= 32) {
+      pl = Plan{bases.c2, bases.windows2, kSubBits, bases.ext2, parts, parts > 1 ? (size_t)65536 : n};
+      return pl;
+    }
+  }
+  return pl;  // one-level sort on the narrow table: n <= 2^18 here, whole MSMs
 }
 // buckets per msm_reduce_segments thread
 uint32_t reduce_seg_len(uint32_t half) {
@@ -882,16 +920,16 @@ uint32_t choose_item_len(size_t entries) {
     int x = e ? atoi(e) : (int)kMaxItemLen;
     return (size_t)(x >= 8 && x <= (int)kMaxItemLen ? x : (int)kMaxItemLen);
   }();
+  static const size_t floor_len = [] {
+    const char* e = getenv("CAPGPU_MSM_ITEM_MIN");
+    int x = e ? atoi(e) : (int)kMinItemLen;
+    return (size_t)(x >= 4 && x <= (int)kMaxItemLen ? x : (int)kMinItemLen);
+  }();
   size_t l = entries / ((size_t)1 << 19);
-  return (uint32_t)std::min<size_t>(std::max<size_t>(l, std::min<size_t>(kMinItemLen, cap)), cap);
+  return (uint32_t)std::min<size_t>(std::max<size_t>(l, std::min<size_t>(floor_len, cap)), cap);
 }
-bool use_local_digits(uint32_t c, size_t n, uint32_t batch, uint32_t sub_bits = 0) {
-  size_t half = ((size_t)1 << (c - 1)) >> sub_bits;
-  size_t nblk = (n + kDigitTile - 1) / kDigitTile;
-  // LDS: 2 * half counters + kDigitTile * W entries (<= 160 KiB with c <= 14)
-  return half <= 8192 && n > 0 && half * nblk * batch <= ((size_t)1 << 28);
-}
-WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t batch, uint32_t sub_bits = 0) {
+// sb = sub-MSMs of the launch (batch * parts), n = points per sub-MSM
+WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t sb, uint32_t sub_bits, bool has_parts) {
   WsLayout L{};
   const size_t bins = ((size_t)1 << (c - 1)) >> sub_bits;  // sort keys of the tile-local level
   size_t half = (size_t)1 << (c - 1);
@@ -899,36 +937,45 @@ WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t batch, uint3
   size_t seg_len = reduce_seg_len((uint32_t)half);
   size_t nseg = (half + seg_len - 1) / seg_len;
   size_t o = 0;
-  L.counts = o;  o = align_up(o + sizeof(uint32_t) * half * batch, 256);
-  L.offsets = o; o = align_up(o + sizeof(uint32_t) * half * batch, 256);
-  L.keys = o;    o = align_up(o + sizeof(uint32_t) * per * batch, 256);
-  L.ranks = o;   o = align_up(o + sizeof(uint32_t) * per * batch, 256);
-  L.sorted = o;  o = align_up(o + sizeof(uint32_t) * per * batch, 256);
+  L.counts = o;  o = align_up(o + sizeof(uint32_t) * half * sb, 256);
+  L.offsets = o; o = align_up(o + sizeof(uint32_t) * half * sb, 256);
+  L.sorted = o;  o = align_up(o + sizeof(uint32_t) * per * sb, 256);
   {
     size_t chunks = (half + kReduceChunk - 1) / kReduceChunk;
-    size_t npart = use_segment_reduce((uint32_t)half, batch) ? 2 * nseg : c * chunks;
-    L.buckets = o; o = align_up(o + sizeof(g1_xyzz) * half * batch, 256);
-    L.partial = o; o = align_up(o + sizeof(g1_xyzz) * npart * batch, 256);
+    size_t npart = use_segment_reduce((uint32_t)half, sb) ? 2 * nseg : c * chunks;
+    L.buckets = o; o = align_up(o + sizeof(g1_xyzz) * half * sb, 256);
+    L.partial = o; o = align_up(o + sizeof(g1_xyzz) * npart * sb, 256);
   }
-  L.max_items = per * batch / choose_item_len(per * batch) + half * batch;  // sum ceil(cnt/L) <= entries/L + buckets
-  L.item_off = o;    o = align_up(o + sizeof(uint32_t) * half * batch, 256);
-  L.item_base = o;   o = align_up(o + sizeof(uint32_t) * (batch + 1), 256);
-  L.totals = o;      o = align_up(o + sizeof(uint32_t) * batch, 256);
+  L.max_items = per * sb / choose_item_len(per * sb) + half * sb;  // sum ceil(cnt/L) <= entries/L + buckets
+  L.item_off = o;    o = align_up(o + sizeof(uint32_t) * half * sb, 256);
+  L.item_base = o;   o = align_up(o + sizeof(uint32_t) * ((size_t)sb + 1), 256);
+  L.totals = o;      o = align_up(o + sizeof(uint32_t) * sb, 256);
   L.item_bucket = o; o = align_up(o + sizeof(uint32_t) * L.max_items, 256);
   L.item_sub = o;    o = align_up(o + sizeof(uint32_t) * L.max_items, 256);
   L.item_pts = o;    o = align_up(o + sizeof(g1_xyzz) * L.max_items, 256);
-  L.nblk = use_local_digits(c, n, batch, sub_bits) ? (n + kDigitTile - 1) / kDigitTile : 0;
-  L.table = o;       o = align_up(o + sizeof(uint32_t) * bins * L.nblk * batch, 256);
-  L.off2 = o;        o = align_up(o + sizeof(uint32_t) * bins * L.nblk * batch, 256);
-  L.tloc = o;        o = align_up(o + sizeof(uint32_t) * bins * L.nblk * batch, 256);
-  L.chunks = o;      o = align_up(o + sizeof(uint32_t) * (size_t)kDigitTile * windows * L.nblk * batch, 256);
+  L.nblk = (n + kDigitTile - 1) / kDigitTile;
+  L.table = o;       o = align_up(o + sizeof(uint32_t) * bins * L.nblk * sb, 256);
+  L.off2 = o;        o = align_up(o + sizeof(uint32_t) * bins * L.nblk * sb, 256);
+  L.tloc = o;        o = align_up(o + sizeof(uint32_t) * bins * L.nblk * sb, 256);
+  L.chunks = o;      o = align_up(o + sizeof(uint32_t) * (size_t)kDigitTile * windows * L.nblk * sb, 256);
   {
     size_t rows = std::max<size_t>(bins * L.nblk, half);
-    L.seg_tot = o;   o = align_up(o + sizeof(uint32_t) * ((rows + kScanSeg - 1) / kScanSeg) * batch, 256);
+    L.seg_tot = o;   o = align_up(o + sizeof(uint32_t) * ((rows + kScanSeg - 1) / kScanSeg) * sb, 256);
   }
-
+  L.part_pts = o;    o = align_up(o + sizeof(g1_xyzz) * (has_parts ? sb : 0), 256);
   L.total = o;
   return L;
+}
+// MSMs of a launch that go through the kernels together: the [key][tile] tables must stay below 2^28 rows and every
+// per-launch counter within 32 bits; larger batches are run in slices
+uint32_t batch_slice(const Plan& pl, uint32_t batch) {
+  const size_t bins = ((size_t)1 << (pl.c - 1)) >> pl.sub_bits;
+  const size_t nblk = (pl.n_sub + kDigitTile - 1) / kDigitTile;
+  const size_t per_msm_rows = bins * std::max<size_t>(nblk, 1) * pl.parts;
+  const size_t per_msm_entries = (size_t)pl.windows * pl.n_sub * pl.parts + ((size_t)1 << (pl.c - 1)) * pl.parts;
+  size_t lim = std::min<size_t>(((size_t)1 << 28) / per_msm_rows, ((size_t)3 << 30) / per_msm_entries);
+  lim = std::min<size_t>(lim, 65535 / pl.parts);  // grid y of msm_sort_level2
+  return (uint32_t)std::max<size_t>(1, std::min<size_t>(lim, batch));
 }
 
 }  // namespace
@@ -937,12 +984,11 @@ uint32_t msm_choose_window(size_t n) {
   const char* env = getenv("CAPGPU_MSM_C");
   if (env) {
     int v = atoi(env);
-    if (v >= 2 && v <= 24) return (uint32_t)v;
+    if (v >= 2 && v <= 16) return (uint32_t)v;
   }
   if (n <= ((size_t)1 << 10)) return 9;
   if (n <= ((size_t)1 << 18)) return 13;
-  if (n <= ((size_t)1 << 22)) return 15;
-  return 17;
+  return wide_c();  // long MSMs are run as batches of sub-MSMs on the wide windows (choose_plan)
 }
 
 uint32_t msm_num_windows(uint32_t c) {
@@ -951,24 +997,22 @@ uint32_t msm_num_windows(uint32_t c) {
   return w;
 }
 
-void msm_free_bases(MsmBases* b);
 int msm_precompute(MsmBases* out, const g1_affine* d_bases, size_t n, uint32_t c, hipStream_t stream) {
   out->n = n;
   out->c = c;
   out->windows = msm_num_windows(c);
-  if ((size_t)out->windows * n >= ((size_t)1 << 31)) return (int)hipErrorInvalidValue;
-  hipError_t e = hipMalloc(&out->ext, sizeof(g1_affine) * n * out->windows);
+  if ((size_t)out->windows * n >= ((size_t)1 << 31) || out->windows > 31) return (int)hipErrorInvalidValue;
+  hipError_t e = hipMalloc(&out->ext, sizeof(g1_affine) * (n ? n : 1) * out->windows);
   if (e != hipSuccess) return (int)e;
   if (n == 0) return 0;
   size_t blocks = (n + kThreads - 1) / kThreads;
   launch("msm_precompute_kernel", msm_precompute_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, out->ext, d_bases, n, c,
                      out->windows);
-  // the wide-window table for large batches (prover-sized commit keys; entries carry 24-bit table indices)
+  // the wide-window table for large batches
   const char* env = getenv("CAPGPU_MSM_WIDE");
   const uint32_t kWideC = wide_c();
   const uint32_t w2 = msm_num_windows(kWideC);
-  if (!getenv("CAPGPU_MSM_C") && !(env && atoi(env) == 0) && c < kWideC && n >= 4096 &&
-      (size_t)w2 * n < ((size_t)1 << 24)) {
+  if (!getenv("CAPGPU_MSM_C") && !(env && atoi(env) == 0) && c < kWideC && n >= 4096) {
     e = hipMalloc(&out->ext2, sizeof(g1_affine) * n * w2);
     if (e != hipSuccess) {
       (void)hipStreamSynchronize(stream);
@@ -991,53 +1035,63 @@ void msm_free_bases(MsmBases* b) {
 }
 
 size_t msm_workspace_bytes(const MsmBases& bases, size_t n, uint32_t batch) {
+  if (n == 0 || batch == 0) return 256;
   Plan pl = choose_plan(bases, n, batch);
-  return ws_layout(pl.c, pl.windows, n, batch, pl.sub_bits).total;
+  const uint32_t slice = batch_slice(pl, batch);
+  return ws_layout(pl.c, pl.windows, pl.n_sub, slice * pl.parts, pl.sub_bits, pl.parts > 1).total;
 }
 
-int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t outer_stride, uint32_t inner,
-            size_t inner_stride, size_t n, uint32_t batch, int montgomery, g1_jac* d_out, void* ws, size_t ws_bytes,
-            hipStream_t stream) {
-  if (inner == 0) inner = 1;
-  if (batch == 0) return 0;
-  if (offset + n > bases.n) return (int)hipErrorInvalidValue;
-  const Plan pl = choose_plan(bases, n, batch);
-  const uint32_t c = pl.c, W = pl.windows;
+const char* msm_plan_describe(const MsmBases& bases, size_t n, uint32_t batch, char* buf, size_t cap) {
+  Plan pl = choose_plan(bases, n, batch);
+  snprintf(buf, cap, "c=%u windows=%u sort=%s parts=%u n_sub=%zu slice=%u", pl.c, pl.windows,
+           pl.sub_bits ? "two-level" : "one-level", pl.parts, pl.n_sub, batch_slice(pl, batch));
+  return buf;
+}
+
+namespace {
+// one slice of a launch: `batch` MSMs, all kernels
+int msm_run_slice(const MsmBases& bases, const Plan& pl, size_t offset, const fe* d_scalars, size_t outer_stride,
+                  uint32_t inner, size_t inner_stride, size_t n, uint32_t first, uint32_t batch, int montgomery,
+                  g1_jac* d_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  const uint32_t c = pl.c, W = pl.windows, parts = pl.parts;
+  const size_t n_sub = pl.n_sub;
   const uint32_t half = 1u << (c - 1);
-  WsLayout L = ws_layout(c, W, n, batch, pl.sub_bits);
+  const uint32_t sb = batch * parts;  // sub-MSMs of this slice
+  WsLayout L = ws_layout(c, W, n_sub, sb, pl.sub_bits, parts > 1);
   if (ws_bytes < L.total) return (int)hipErrorInvalidValue;
   char* base = reinterpret_cast<char*>(ws);
   uint32_t* counts = reinterpret_cast<uint32_t*>(base + L.counts);
   uint32_t* offsets = reinterpret_cast<uint32_t*>(base + L.offsets);
-  uint32_t* keys = reinterpret_cast<uint32_t*>(base + L.keys);
-  uint32_t* ranks = reinterpret_cast<uint32_t*>(base + L.ranks);
   uint32_t* sorted = reinterpret_cast<uint32_t*>(base + L.sorted);
   g1_xyzz* partial = reinterpret_cast<g1_xyzz*>(base + L.partial);
-  const size_t per = (size_t)W * n;
+  g1_xyzz* part_pts = parts > 1 ? reinterpret_cast<g1_xyzz*>(base + L.part_pts) : nullptr;
+  const size_t per = (size_t)W * n_sub;
   const uint32_t seg_len = reduce_seg_len(half), nseg = (half + seg_len - 1) / seg_len;
-  const uint32_t total_buckets = half * batch;
-  // exclusive scan of `nb` counters per batch entry: one workgroup per entry, or - for the long table of a single
-  // large MSM - segments in parallel
+  const uint32_t total_buckets = half * sb;
+  // the scalars of MSM `first + b`: the addressing of msm_run with the slice's first MSM folded into the pointer
+  // (slices start at multiples of `inner` or the launch has inner == 1 / a single slice)
+  const fe* sc0 = d_scalars + (size_t)(first / inner) * outer_stride + (size_t)(first % inner) * inner_stride;
+  // exclusive scan of `nb` counters per sub-MSM: one workgroup per entry, or - for a long table - segments in parallel
   uint32_t* seg_tot = reinterpret_cast<uint32_t*>(base + L.seg_tot);
   auto scan_counts = [&](const uint32_t* in, uint32_t* out, uint32_t nb) {
     if (nb <= 4 * kScanSeg) {
-      launch("msm_scan", msm_scan<0>, dim3(batch), dim3(1024), 0, stream, in, out, nb, (uint32_t*)nullptr, 0u);
+      launch("msm_scan", msm_scan<0>, dim3(sb), dim3(1024), 0, stream, in, out, nb, (uint32_t*)nullptr, 0u);
       return;
     }
     const uint32_t ns = (nb + kScanSeg - 1) / kScanSeg;
-    launch("msm_scan_seg", msm_scan_seg, dim3(ns, batch), dim3(1024), 0, stream, in, out, nb, ns, seg_tot);
-    launch("msm_scan_tot", msm_scan_tot, dim3(batch), dim3(1024), 0, stream, seg_tot, ns);
-    launch("msm_scan_add", msm_scan_add, dim3(ns, batch), dim3(1024), 0, stream, out, nb, ns, (const uint32_t*)seg_tot);
+    launch("msm_scan_seg", msm_scan_seg, dim3(ns, sb), dim3(1024), 0, stream, in, out, nb, ns, seg_tot);
+    launch("msm_scan_tot", msm_scan_tot, dim3(sb), dim3(1024), 0, stream, seg_tot, ns);
+    launch("msm_scan_add", msm_scan_add, dim3(ns, sb), dim3(1024), 0, stream, out, nb, ns, (const uint32_t*)seg_tot);
   };
 
-  if (L.nblk) {
+  {
     const uint32_t nblk = (uint32_t)L.nblk;
     uint32_t* table = reinterpret_cast<uint32_t*>(base + L.table);
     uint32_t* off2 = reinterpret_cast<uint32_t*>(base + L.off2);
     uint32_t* tloc = reinterpret_cast<uint32_t*>(base + L.tloc);
     uint32_t* chunk_buf = reinterpret_cast<uint32_t*>(base + L.chunks);
     const uint32_t bins = half >> pl.sub_bits;  // sort keys of the tile-local level (= buckets without a 2nd level)
-    const uint32_t total_bins = bins * batch;
+    const uint32_t total_bins = bins * sb;
     size_t lds_bytes = sizeof(uint32_t) * (2 * (size_t)bins + (size_t)kDigitTile * W);
     static bool attr_set = false;
     if (!attr_set) {
@@ -1048,36 +1102,22 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
       attr_set = true;
     }
     auto digits_kernel = c == 13 ? msm_digits_local<13> : (c == 15 ? msm_digits_local<15> : msm_digits_local<0>);
-    launch("msm_digits_local", digits_kernel, dim3(nblk * ((batch + 7) / 8) * 8), dim3(kDigitThreads), lds_bytes,
-           stream, d_scalars, outer_stride, inner, inner_stride, n, montgomery, c, W, nblk, batch, bases.n, offset,
-           pl.sub_bits, table, tloc, chunk_buf);
+    launch("msm_digits_local", digits_kernel, dim3(nblk * ((sb + 7) / 8) * 8), dim3(kDigitThreads), lds_bytes, stream,
+           sc0, outer_stride, inner, inner_stride, n, n_sub, parts, montgomery, c, W, nblk, sb, pl.sub_bits, table, tloc,
+           chunk_buf);
     scan_counts(table, off2, bins * nblk);
     if (pl.sub_bits) {
       // two-level sort: bins are finished per workgroup straight from the tile chunks
-      launch("msm_sort_level2", msm_sort_level2, dim3(bins, batch), dim3(kThreads), 0, stream,
-             (const uint32_t*)chunk_buf, (const uint32_t*)table, (const uint32_t*)tloc, (const uint32_t*)off2, per, bins,
-             nblk, W, pl.sub_bits, counts, offsets, sorted);
+      launch("msm_sort_level2", msm_sort_level2, dim3(bins, sb), dim3(kThreads), 0, stream, (const uint32_t*)chunk_buf,
+             (const uint32_t*)table, (const uint32_t*)tloc, (const uint32_t*)off2, per, bins, nblk, W, pl.sub_bits,
+             bases.n, offset, n_sub, parts, counts, offsets, sorted);
     } else {
       launch("msm_bucket_ranges", msm_bucket_ranges, dim3((total_bins + kThreads - 1) / kThreads), dim3(kThreads), 0,
              stream, (const uint32_t*)table, (const uint32_t*)off2, bins, nblk, total_bins, counts, offsets);
       size_t rows = (size_t)total_bins * nblk;
       launch("msm_scatter", msm_scatter_runs, dim3((unsigned)((rows + kThreads - 1) / kThreads)), dim3(kThreads), 0,
              stream, (const uint32_t*)chunk_buf, (const uint32_t*)table, (const uint32_t*)tloc, (const uint32_t*)off2,
-             per, bins, nblk, W, rows, sorted);
-    }
-  } else {
-    hipError_t e = hipMemsetAsync(counts, 0, sizeof(uint32_t) * (size_t)half * batch, stream);
-    if (e != hipSuccess) return (int)e;
-    if (n > 0) {
-      size_t nt = n * batch;
-      launch("msm_digits_hist", msm_digits_hist, dim3((unsigned)((nt + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-             stream, d_scalars, outer_stride, inner, inner_stride, n, batch, montgomery, c, W, counts, keys, ranks);
-    }
-    scan_counts(counts, offsets, half);
-    if (n > 0) {
-      size_t ne = per * batch;
-      launch("msm_scatter", msm_scatter, dim3((unsigned)((ne + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
-             keys, ranks, offsets, n, batch, c, W, bases.n, offset, sorted);
+             per, bins, nblk, W, rows, bases.n, offset, n_sub, parts, sorted);
     }
   }
   uint32_t* item_off = reinterpret_cast<uint32_t*>(base + L.item_off);
@@ -1086,21 +1126,22 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
   uint32_t* item_bucket = reinterpret_cast<uint32_t*>(base + L.item_bucket);
   g1_xyzz* item_pts = reinterpret_cast<g1_xyzz*>(base + L.item_pts);
   uint32_t* item_sub = reinterpret_cast<uint32_t*>(base + L.item_sub);
-  const uint32_t item_len = choose_item_len(per * batch);
-  launch("msm_scan_items", msm_scan<1>, dim3(batch), dim3(1024), 0, stream, (const uint32_t*)counts, item_off, half,
+  const uint32_t item_len = choose_item_len(per * sb);
+  launch("msm_scan_items", msm_scan<1>, dim3(sb), dim3(1024), 0, stream, (const uint32_t*)counts, item_off, half,
          totals, item_len);
-  launch("msm_item_bases", msm_item_bases, dim3(1), dim3(64), 0, stream, (const uint32_t*)totals, batch, item_base);
-  launch("msm_sort_items", msm_sort_items, dim3(batch), dim3(1024), 0, stream, (const uint32_t*)counts,
+  launch("msm_item_bases", msm_item_bases, dim3(1), dim3(1024), 0, stream, (const uint32_t*)totals, sb, item_base);
+  launch("msm_sort_items", msm_sort_items, dim3(sb), dim3(1024), 0, stream, (const uint32_t*)counts,
          (const uint32_t*)item_base, half, item_len, item_bucket, item_sub);
   if (L.max_items > 0) {
     launch("msm_accumulate", msm_accumulate, dim3((unsigned)((L.max_items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
            stream, pl.ext, (const uint32_t*)sorted, (const uint32_t*)counts, (const uint32_t*)offsets,
            (const uint32_t*)item_off, (const uint32_t*)item_base, (const uint32_t*)item_bucket,
-           (const uint32_t*)item_sub, per, half, batch, item_len, item_pts,
+           (const uint32_t*)item_sub, per, half, sb, item_len, item_pts,
            reinterpret_cast<g1_xyzz*>(base + L.buckets));
   }
   g1_xyzz* buckets = reinterpret_cast<g1_xyzz*>(base + L.buckets);
-  if (use_segment_reduce(half, batch))
+  g1_jac* out = d_out + first;
+  if (use_segment_reduce(half, sb))
     launch("msm_combine", msm_combine, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0, stream,
            (const g1_xyzz*)item_pts, (const uint32_t*)counts, (const uint32_t*)item_off, (const uint32_t*)item_base, half,
            total_buckets, item_len, buckets);
@@ -1112,19 +1153,44 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
     launch("msm_combine", msm_combine_wave<16>, dim3((unsigned)(((size_t)total_buckets * 16 + kThreads - 1) / kThreads)),
            dim3(kThreads), 0, stream, (const g1_xyzz*)item_pts, (const uint32_t*)counts, (const uint32_t*)item_off,
            (const uint32_t*)item_base, half, total_buckets, item_len, buckets);
-  if (use_segment_reduce(half, batch)) {
-    launch("msm_reduce_segments", msm_reduce_segments, dim3((nseg * batch + kThreads - 1) / kThreads), dim3(kThreads),
-           0, stream, (const g1_xyzz*)buckets, half, seg_len, nseg, batch, partial);
-    launch("msm_reduce_final", msm_reduce_final, dim3(batch), dim3(64), 0, stream, (const g1_xyzz*)partial, seg_len,
-           nseg, d_out);
+  if (use_segment_reduce(half, sb)) {
+    launch("msm_reduce_segments", msm_reduce_segments, dim3((nseg * sb + kThreads - 1) / kThreads), dim3(kThreads), 0,
+           stream, (const g1_xyzz*)buckets, half, seg_len, nseg, sb, partial);
+    launch("msm_reduce_final", msm_reduce_final, dim3(sb), dim3(64), 0, stream, (const g1_xyzz*)partial, seg_len, nseg,
+           out, part_pts);
   } else {
     const uint32_t chunks = (half + kReduceChunk - 1) / kReduceChunk;
-    launch("msm_reduce_bits", msm_reduce_bits, dim3(chunks, c, batch), dim3(kThreads), 0, stream,
-           (const g1_xyzz*)buckets, half, c, chunks, partial);
-    launch("msm_reduce_bits_final", msm_reduce_bits_final, dim3(batch), dim3(64), 0, stream, (const g1_xyzz*)partial, c,
-           chunks, d_out);
+    launch("msm_reduce_bits", msm_reduce_bits, dim3(chunks, c, sb), dim3(kThreads), 0, stream, (const g1_xyzz*)buckets,
+           half, c, chunks, partial);
+    launch("msm_reduce_bits_final", msm_reduce_bits_final, dim3(sb), dim3(64), 0, stream, (const g1_xyzz*)partial, c,
+           chunks, out, part_pts);
   }
+  if (parts > 1)
+    launch("msm_sum_parts", msm_sum_parts, dim3(batch), dim3(64), 0, stream, (const g1_xyzz*)part_pts, parts, out);
   return (int)hipGetLastError();
+}
+}  // namespace
+
+int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t outer_stride, uint32_t inner,
+            size_t inner_stride, size_t n, uint32_t batch, int montgomery, g1_jac* d_out, void* ws, size_t ws_bytes,
+            hipStream_t stream) {
+  if (inner == 0) inner = 1;
+  if (batch == 0) return 0;
+  if (offset + n > bases.n) return (int)hipErrorInvalidValue;
+  if (n == 0) {
+    launch("msm_fill_inf", msm_fill_inf, dim3((batch + 255) / 256), dim3(256), 0, stream, d_out, batch);
+    return (int)hipGetLastError();
+  }
+  const Plan pl = choose_plan(bases, n, batch);
+  uint32_t slice = batch_slice(pl, batch);
+  if (slice < batch && inner > 1) slice = slice >= inner ? slice / inner * inner : 0;  // slices start on an `inner` boundary
+  if (slice == 0) return (int)hipErrorInvalidValue;
+  for (uint32_t first = 0; first < batch; first += slice) {
+    int rc = msm_run_slice(bases, pl, offset, d_scalars, outer_stride, inner, inner_stride, n, first,
+                           std::min(slice, batch - first), montgomery, d_out, ws, ws_bytes, stream);
+    if (rc) return rc;
+  }
+  return 0;
 }
 
 }  // namespace cap

@@ -56,6 +56,8 @@ int msm_precompute(MsmBases* out, const g1_affine* d_bases, size_t n, uint32_t c
 void msm_free_bases(MsmBases* b);
 
 size_t msm_workspace_bytes(const MsmBases& bases, size_t n, uint32_t batch);
+// "c=15 windows=18 sort=two-level parts=256 n_sub=65536 slice=1": which table, sort and split a launch would use
+const char* msm_plan_describe(const MsmBases& bases, size_t n, uint32_t batch, char* buf, size_t cap);
 
 // out[b] = sum_{i<n} scalars_b[i] * bases[offset + i]   for b < batch, where
 // scalars_b = d_scalars + (b / inner) * outer_stride + (b % inner) * inner_stride   (elements).

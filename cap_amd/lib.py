@@ -202,6 +202,18 @@ def msm_g1_dev(handle: int, d_scalars: DevBuf, n: int, count: int = 1, stride: i
     return d_out
 
 
+def msm_plan(handle: int, n: int, count: int = 1) -> dict:
+    """Which table / sort / split `count` MSMs of n points would take: {'c': 15, 'windows': 18, 'sort': 'two-level',
+    'parts': 256, 'n_sub': 65536, 'slice': 1}."""
+    buf = ctypes.create_string_buffer(256)
+    check(load().capgpu_msm_plan(ctypes.c_uint64(handle), ctypes.c_size_t(n), count, buf, ctypes.c_size_t(256)))
+    out = {}
+    for kv in buf.value.decode().split():
+        k, v = kv.split("=")
+        out[k] = int(v) if v.isdigit() else v
+    return out
+
+
 def g1_sum(points: np.ndarray) -> np.ndarray:
     """(k, 12) Jacobian points -> their group sum (12,)."""
     points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 12)

@@ -112,6 +112,11 @@ int capgpu_msm_g1_batch(uint64_t srs_handle, const size_t* offsets, const uint64
 int capgpu_msm_g1_dev(uint64_t srs_handle, size_t offset, const void* d_scalars, size_t scalar_stride, size_t n,
                       int count, int scalars_montgomery, void* d_out_xyz);
 
+/* Diagnostic: which window table, sort and split `count` MSMs of n points on this SRS would take, as text
+ * ("c=15 windows=18 sort=two-level parts=256 n_sub=65536 slice=1").  Tests pin the plan of the BASELINE sizes with
+ * it, so that a size limit can never silently move a configuration to a slower path. */
+int capgpu_msm_plan(uint64_t srs_handle, size_t n, int count, char* buf, size_t cap);
+
 /* out = sum of n Jacobian points (96 B each, host memory): the combine step after the all-gather of a
  * point-range-sharded MSM (replaces the G-1 `GroupProjective::add_assign` a multi-GPU caller would do). */
 int capgpu_g1_sum(const uint64_t* points_xyz, size_t n, uint64_t out_xyz[12]);
