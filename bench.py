@@ -11,7 +11,10 @@ witnesses, the proving key and the SRS are resident in HBM when the timed region
 proves its own batch (proofs are independent: replicas, no data-path collective) -> weak scaling;
 value = all proofs of all ranks / max-over-ranks time.
 
-Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the definition of every field.
+Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the definition of every field.  Secondary legs (each
+bounded, all outside the timed region of `value`): reference_schedule, n2p16, latency_ms_batch1, pcie_inclusive,
+cpu_baseline (+ all cores), msm (single 2^17, sharded 2^22 / 2^24 through the library's RCCL exchange), and - with
+--workload mixed64 - BASELINE config 4 in both of its modes.
 """
 from __future__ import annotations
 
@@ -27,79 +30,77 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-TRAFFIC_BATCH = 256      # batch size of the committed PMC pass (profiles/traffic_r01.json)
+MADS_PER_MUL = 171       # lazy 9 x 29-bit Montgomery multiplication: 81 product + 81 reduction + 9 digit multiply-adds
+TRAFFIC_FILE = "profiles/traffic_r02.json"   # PMC pass (FETCH_SIZE / WRITE_SIZE) of this same command, batch 256
 
 
 def algorithmic_bytes_per_proof(n: int) -> dict:
     """reference schedule, primitives only."""
-    msm_pairs = 4 * 0 + 5 * (n + 2) + (n + 3) + 5 * (n + 2) + 2 * (n + 2)
+    msm_pairs = 5 * (n + 2) + (n + 3) + 5 * (n + 2) + 2 * (n + 2)
     ntt_elems = 7 * n + 26 * 8 * n
     return {"msm_pairs": msm_pairs, "msm_bytes": 96 * msm_pairs, "ntt_elems": ntt_elems, "ntt_bytes": 64 * ntt_elems,
             "total_bytes": 96 * msm_pairs + 64 * ntt_elems}
 
 
 P_FQ = 0x30644E72E131A029B85045B68181585D97816A916871CA8D3C208C16D87CFD47
+A_SEQ, B_SEQ = 0x1234567890ABCDEF1234567890ABCDEF, 0xFEDCBA0987654321FEDCBA
 
 
-def _weighted_sums(sc: np.ndarray, lo: int):
-    """sum k_i and sum (lo + i) k_i for canonical scalars (n, 4) uint64, exactly, with numpy on 16-bit pieces."""
-    n = sc.shape[0]
-    pieces = sc.view(np.uint16).reshape(n, 16).astype(np.uint64)
-    idx = (np.arange(n, dtype=np.uint64) + np.uint64(lo))
-    s0 = s1 = 0
-    for start in range(0, n, 1 << 18):
-        blk = pieces[start:start + (1 << 18)]
-        col = blk.sum(axis=0)
-        wcol = (blk * idx[start:start + (1 << 18), None]).sum(axis=0)
-        s0 += sum(int(col[j]) << (16 * j) for j in range(16))
-        s1 += sum(int(wcol[j]) << (16 * j) for j in range(16))
-    return s0, s1
+def _words_to_ints(words):
+    w = np.asarray(words, dtype=np.uint64).reshape(-1, 4)
+    return [int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192 for r in w]
 
 
-def msm_leg(cg, bu, torch, dist, rank, world, log_n, iters=5, coll_dev="cuda"):
+def msm_leg(cg, bu, torch, dist, rank, world, log_n, iters=5, coll_dev="cuda", use_lib_comm=False):
     """Point-range-sharded MSM: bases P_i = [a + i b]G generated on each rank's GPU for its range,
     scalars resident, local Pippenger, ONE exchange step (all-gather of a 96-byte Jacobian point per rank) and
-    G-1 group additions.  Checked against [sum k_i (a + i b)] G."""
+    G-1 group additions.  With use_lib_comm the exchange is the library's own (RCCL all-gather on its stream from
+    device memory + sum on the device: capgpu_msm_g1_sharded_dev); otherwise (gloo test runs) it hops through
+    torch.distributed.  Checked against [sum k_i (a + i b)] G."""
     from cap_amd import parallel as par
     n_total = 1 << log_n
     lo, hi = par.shard_range(n_total, rank, world)
     n = hi - lo
-    a, b = 0x1234567890ABCDEF1234567890ABCDEF % bu.R, 0xFEDCBA0987654321FEDCBA % bu.R
+    a, b = A_SEQ % bu.R, B_SEQ % bu.R
     srs = cg.srs_generate_affine_seq((a + lo * b) % bu.R, b, n)
-    rng = np.random.default_rng(5)
-    sc = rng.integers(0, 1 << 63, size=(n_total, 4), dtype=np.uint64)
-    sc[:, 3] &= np.uint64((1 << 61) - 1)          # < 2^253 < r : canonical
-    mine = np.ascontiguousarray(sc[lo:hi])
-    d_sc = cg.DevBuf.from_numpy(mine)
+    plan = cg.msm_plan(srs, n, 1)
+    sc = bu.random_canonical_scalars(5, n_total)
+    d_sc = cg.DevBuf.from_numpy(np.ascontiguousarray(sc[lo:hi]))
     d_out = cg.DevBuf(96)
-    cg.msm_g1_dev(srs, d_sc, n, d_out=d_out)       # warm-up
+
+    def one():
+        if dist is None:
+            cg.msm_g1_dev(srs, d_sc, n, d_out=d_out)
+            return None
+        if use_lib_comm:
+            cg.msm_g1_sharded_dev(srs, d_sc, n, d_out=d_out)       # local MSM + all-gather + sum: all enqueued
+            return None
+        cg.msm_g1_dev(srs, d_sc, n, d_out=d_out)
+        return cg.g1_sum(par.all_gather_points(d_out.to_numpy(), device=coll_dev))
+
+    one()                                                           # warm-up
     cg.sync()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
-    # the timed region is the whole sharded MSM: local Pippenger, the one exchange step (all-gather of a 96-byte
-    # partial per rank) and the G - 1 additions of the partials
+    # the timed region is the whole sharded MSM: local Pippenger, the exchange step and the additions of the partials
     t0 = time.perf_counter()
+    total = None
     for _ in range(iters):
-        cg.msm_g1_dev(srs, d_sc, n, d_out=d_out)
-        part = d_out.to_numpy()                    # synchronises: the partial sum leaves the device here
-        if dist is not None:
-            parts = par.all_gather_points(part, device=coll_dev)
-            total = cg.g1_sum(parts)
-        else:
-            total = part
+        total = one()
     cg.sync()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / iters
+    if total is None:
+        total = d_out.to_numpy()
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     ok = None
     if rank == 0:
-        s0, s1 = _weighted_sums(sc, 0)
-        expect_scalar = (a * s0 + b * s1) % bu.R
-        h1 = cg.srs_generate_affine_seq(expect_scalar, 0, 1)
+        s0, s1 = bu.weighted_scalar_sums(sc, 0)
+        h1 = cg.srs_generate_affine_seq((a * s0 + b * s1) % bu.R, 0, 1)
         rinv = pow(1 << 256, -1, P_FQ)
         ex, ey = [v * rinv % P_FQ for v in _words_to_ints(cg.srs_download(h1, 0, 1))]
         cg.srs_free(h1)
@@ -111,14 +112,14 @@ def msm_leg(cg, bu, torch, dist, rank, world, log_n, iters=5, coll_dev="cuda"):
             ok = bool((X * zi * zi % P_FQ, Y * zi * zi * zi % P_FQ) == (ex, ey))
     cg.srs_free(srs)
     gbps = 96.0 * n_total / dt / 1e9
+    if world == 1:
+        how = "single GPU"
+    elif use_lib_comm:
+        how = f"point range x{world}: local Pippenger + ncclAllGather(96 B) on the library stream + on-device sum (capgpu_msm_g1_sharded_dev)"
+    else:
+        how = f"point range x{world} + torch.distributed all_gather(96 B) + capgpu_g1_sum (gloo test path)"
     return {"log_n": log_n, "points": n_total, "ms": dt * 1e3, "GBps_algorithmic": gbps, "frac_of_hbm_peak": gbps / HBM_PEAK_GBPS,
-            "sharding": f"point range x{world} + all_gather(96 B) + g1_sum" if world > 1 else "single GPU",
-            "identity_check": ok}
-
-
-def _words_to_ints(words):
-    w = np.asarray(words, dtype=np.uint64).reshape(-1, 4)
-    return [int(r[0]) | int(r[1]) << 64 | int(r[2]) << 128 | int(r[3]) << 192 for r in w]
+            "sharding": how, "plan_per_rank": plan, "identity_check": ok}
 
 
 def main():
@@ -130,15 +131,18 @@ def main():
     ap.add_argument("--log-n", type=int, default=15, help="evaluation domain (15: pinned for depth 10; 16: upper bound)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-reference-schedule", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the n2p16 / batch-1 latency / PCIe-inclusive legs")
     ap.add_argument("--workload", default="transfer", choices=["transfer", "mixed64"],
                     help="transfer: P identical-shape 2-in/2-out transfer proofs per GPU (weak scaling, the headline); "
                          "mixed64: BASELINE config 4 - 32 transfer(2x3) + 13 mint + 19 freeze(3) proofs in total, "
-                         "proof i on rank i mod N (strong scaling)")
+                         "mode B: proof i on rank i mod N (replicas); mode A (N > 1): every rank proves all 64 with each "
+                         "commitment MSM sharded by point range over the ranks")
     ap.add_argument("--dist-backend", default="nccl", choices=["nccl", "gloo"],
                     help="nccl (= RCCL, the real multi-GPU path); gloo only to exercise the N>1 logic on a 1-GPU box "
                          "together with CAPGPU_BENCH_DEVICE=0")
     ap.add_argument("--no-msm", action="store_true")
-    ap.add_argument("--msm-log-n", type=int, default=22, help="size of the sharded MSM leg (24 = BASELINE config 5)")
+    ap.add_argument("--msm-log-n", type=int, default=None,
+                    help="size of the sharded MSM leg (default: 22 on one GPU, 24 = BASELINE config 5 with N > 1)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -162,6 +166,15 @@ def main():
 
     cg.init(local_rank)                       # raises (no fallback) when the HIP library / a gfx950 device is missing
     torch.cuda.set_device(local_rank)
+    # the library's own RCCL communicator (the sharded-MSM exchange step lives inside the C ABI)
+    lib_comm, lib_comm_error = False, None
+    if world > 1 and args.dist_backend == "nccl":
+        from cap_amd import parallel as par
+        try:
+            par.init_library_comm(cg, device=coll_dev)
+            lib_comm = True
+        except Exception as e:                # reported in the JSON line; the replica headline does not need it
+            lib_comm_error = str(e)
     P, log_n = args.batch, args.log_n
     n = 1 << log_n
     num_inputs = 27
@@ -173,33 +186,32 @@ def main():
     if args.workload == "transfer":
         plan = [("transfer_2x2", log_n, num_inputs, P)]
     else:
-        from cap_amd import parallel as par
         mix = [("transfer_2x3", 32), ("mint", 13), ("freeze_3", 19)]       # src/lib.rs:734-736 ratio 5:2:3
         plan, gi = [], 0
         for kind, cnt in mix:
             mine = [i for i in range(gi, gi + cnt) if i % world == rank]
             gi += cnt
             ln, ni = bu.NOTE_SHAPES[kind]
-            plan.append((kind, ln, ni, len(mine)))
-        log_n = max(ln for _, ln, _, _ in plan)
+            plan.append((kind, ln, ni, len(mine), cnt))
+        log_n = max(p[1] for p in plan)
         n = 1 << log_n
     srs = cg.srs_generate(tau, n + 3)
-    groups = []
-    for kind, ln, ni, cnt in plan:
+
+    def make_group(kind, ln, ni, cnt, seed_rank, n_wit=4):
         sc = bu.synthetic_circuit(ln, ni, seed=2 + ln + ni)
         sel, sig = sc.selectors_mont(), sc.sigma_mont()
-        pk, _vk = cg.plonk_preprocess(srs, 1 << ln, ni, sel, sig)
-        if not groups:
-            _vk0 = _vk
-        n_wit = max(1, min(cnt, 4))
-        wit = [sc.witness(1000 * rank + 3 + i) for i in range(n_wit)]
-        g = {"kind": kind, "n": 1 << ln, "num_inputs": ni, "count": cnt, "pk": pk, "sel": sel, "sig": sig}
+        pk, vk = cg.plonk_preprocess(srs, 1 << ln, ni, sel, sig)
+        n_wit = max(1, min(cnt, n_wit))
+        wit = [sc.witness(1000 * seed_rank + 3 + i) for i in range(n_wit)]
+        g = {"kind": kind, "n": 1 << ln, "num_inputs": ni, "count": cnt, "pk": pk, "vk": vk, "sel": sel, "sig": sig}
         if cnt:
             g["wires"] = np.stack([sc.wires_mont(wit[i % n_wit][0]) for i in range(cnt)])
             g["pubs"] = np.stack([bu.to_mont_array(wit[i % n_wit][1]) for i in range(cnt)])
-            g["blind"] = np.stack([bu.to_mont_array(bu.blinders(7000 + 100 * rank + i)) for i in range(cnt)])
+            g["blind"] = np.stack([bu.to_mont_array(bu.blinders(7000 + 100 * seed_rank + i)) for i in range(cnt)])
             g["d_wires"] = cg.DevBuf.from_numpy(g["wires"])
-        groups.append(g)
+        return g
+
+    groups = [make_group(p[0], p[1], p[2], p[3], rank) for p in plan]
     g0 = groups[0]
     pk, sel, sig = g0["pk"], g0["sel"], g0["sig"]
     wires, pubs, blind = g0.get("wires"), g0.get("pubs"), g0.get("blind")
@@ -211,24 +223,28 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    def step(key):
+    def step(key, grps):
         out_proofs = []
-        for g in groups:
+        for g in grps:
             if g["count"]:
                 k = key if (key is not None and g is g0) else g["pk"]
                 out_proofs += cg.plonk_prove_batch_dev(k, g["d_wires"], g["pubs"], g["blind"], ext_msg, g["count"])
         return out_proofs
 
-    def timed(key, steps, warmup, profile):
+    def timed(key, steps, warmup, profile, grps=None):
+        grps = groups if grps is None else grps
         for _ in range(warmup):
-            step(key)
+            step(key, grps)
         if profile:
             cg.profile_reset()
             cg.profile_enable(True)
         sync_all()
+        per_step = []
         t0 = time.perf_counter()
         for _ in range(steps):
-            proofs = step(key)
+            ts = time.perf_counter()
+            proofs = step(key, grps)          # returns with the proofs on the host: the step is complete here
+            per_step.append(time.perf_counter() - ts)
         sync_all()
         dt = time.perf_counter() - t0
         stats = cg.profile_stats() if profile else {}
@@ -237,9 +253,9 @@ def main():
             t = torch.tensor([dt], dtype=torch.float64, device=coll_dev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt = float(t.item())
-        return dt, stats, proofs
+        return dt, stats, proofs, per_step
 
-    dt, stats, proofs = timed(pk, args.steps, args.warmup, profile=True)
+    dt, stats, proofs, per_step = timed(pk, args.steps, args.warmup, profile=True)
     per_step_all_ranks = P * world if args.workload == "transfer" else 64
     total_proofs = per_step_all_ranks * args.steps
     value = total_proofs / dt
@@ -257,10 +273,13 @@ def main():
         # K8: 26 arrays of 6n elements (25 in, 1 out) x 32 B (jf-plonk's 8n domain would be a third more)
         "k_quotient": 26 * 6 * n * 32 * P,
     }
-    traffic_tab = {}
+    traffic_tab, traffic_src = {}, None
     try:
-        with open(os.path.join(ROOT, "profiles", "traffic_r01.json")) as f:
-            traffic_tab = json.load(f).get("per_launch_bytes", {})
+        with open(os.path.join(ROOT, TRAFFIC_FILE)) as f:
+            tj = json.load(f)
+        traffic_tab = tj.get("per_launch_bytes", {})
+        traffic_src = f"{TRAFFIC_FILE} (static: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command at batch " \
+                      f"{tj.get('batch', '?')}, committed; not re-measured by this run)"
     except OSError:
         pass
     roofline = None
@@ -272,25 +291,35 @@ def main():
             achieved = bytes_per_launch / (avg_ms * 1e-3) / 1e9
         else:
             bytes_per_launch, achieved = None, None
+        same_cfg = (P == 256 and log_n == 15 and args.workload == "transfer")
         roofline = {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": (achieved / HBM_PEAK_GBPS) if achieved else None,
-                    # HBM bytes per launch from the committed PMC pass (profiles/traffic_r01.json, batch 16) or null
-                    "traffic": traffic_tab.get(dom) if (P == TRAFFIC_BATCH and log_n == 15 and args.workload == "transfer") else None,
+                    "traffic": traffic_tab.get(dom) if same_cfg else None,
+                    "traffic_source": traffic_src if (same_cfg and dom in traffic_tab) else None,
                     "avg_launch_ms": avg_ms, "launches": launches, "algorithmic_bytes_per_launch": bytes_per_launch,
                     "share_of_kernel_time": kern_ms[dom] / sum(kern_ms.values())}
-    # SURVEY 8d asks for an integer-ALU fraction beside the HBM one: the path is multiplication-bound.  Mixed additions of
-    # a step = non-zero digits minus one per non-empty bucket (the first entry of a bucket is a copy); one mixed
-    # addition = 8 products + 2 squarings + 9 reductions ~ 10.5 Montgomery multiplications of the lazy 29-bit field,
-    # whose measured ceiling in isolation is 158 G/s (tools/ubench_mlo.hip, profiles/ubench_mlo_r01.txt).
+    # SURVEY 8d asks for an integer-ALU fraction beside the HBM one: the path is instruction-issue-bound.  Mixed additions
+    # of a step = non-zero digits minus one per non-empty bucket (the first entry of a bucket is a copy); one mixed
+    # addition = 8 products + 2 squarings + 9 reductions ~ 10.5 Montgomery multiplications of 171 v_mad_u64_u32 each.
+    # peak = the chip's measured v_mad_u64_u32 issue rate / 171: a machine ceiling (multiply-adds only, nothing else
+    # issued), not this library's own best loop.
     alu = None
-    if dom == "msm_accumulate" and args.workload == "transfer" and P >= 32 and n >= 4096:
+    if dom == "msm_accumulate" and args.workload == "transfer" and P >= 32 and n >= 4096 and rank == 0:
+        mad_rate = cg.ubench_mad_rate()
         digits, buckets = 17, 1 << 14                       # c = 15 table, 254-bit scalars
         adds_per_step = P * (13 * ((n + 2) * digits - buckets) + (n + 3 - (n + 2)) * digits)
         mul_eq = adds_per_step * args.steps * 10.5 / (kern_ms[dom] * 1e-3) / 1e9
-        alu = {"kernel": dom, "achieved": mul_eq, "peak": 158.0, "unit": "G field multiplications/s (equivalent)",
-               "frac": mul_eq / 158.0, "mixed_adds_per_step": adds_per_step}
+        peak = mad_rate / MADS_PER_MUL / 1e9
+        alu = {"kernel": dom, "achieved": mul_eq, "peak": peak, "unit": "G field multiplications/s (equivalent)",
+               "frac": mul_eq / peak, "mixed_adds_per_step": adds_per_step,
+               "peak_source": f"measured v_mad_u64_u32 issue rate {mad_rate / 1e12:.1f} T lane-ops/s (capgpu_ubench_mad_rate, "
+                              f"this run) / {MADS_PER_MUL} multiply-adds per multiplication"}
     top = sorted(kern_ms.items(), key=lambda kv: -kv[1])[:8]
     whole_gbps = ab["total_bytes"] * total_proofs / dt / 1e9
+    ps = sorted(per_step)
+
+    def pct(q):
+        return ps[min(len(ps) - 1, int(q * len(ps)))] * 1e3
 
     out = {
         "metric": "transfer-note proofs/sec (2-in/2-out)", "value": value, "unit": "proofs/s", "n_gpus": world,
@@ -303,6 +332,7 @@ def main():
                    "domain_size": n, "batch_per_gpu": P, "parallelism": f"replicas x{world} (independent proofs)",
                    "pk_coset_cache": "18 fixed selector/sigma coset NTTs cached in the proving key (see "
                                      "reference_schedule for the per-proof recompute number)"},
+        "step_ms_this_rank": {"p10": pct(0.10), "p50": pct(0.50), "p90": pct(0.90), "min": ps[0] * 1e3, "max": ps[-1] * 1e3},
         "roofline": roofline,
         "alu_roofline": alu,
         "proof_hbm_roofline": {"algorithmic_bytes_per_proof": ab["total_bytes"], "achieved_GBps": whole_gbps,
@@ -310,24 +340,110 @@ def main():
         "top_kernels_ms": {k: round(v, 3) for k, v in top},
         "setup_s": round(t_setup, 2),
     }
+    if lib_comm_error:
+        out["library_comm_error"] = lib_comm_error
 
     if world == 1 and not args.no_reference_schedule and args.workload == "transfer":
         os.environ["CAPGPU_RECOMPUTE_PK_COSET"] = "1"
         pk_ref, _ = cg.plonk_preprocess(srs, n, num_inputs, sel, sig)
         os.environ.pop("CAPGPU_RECOMPUTE_PK_COSET")
-    if not args.no_reference_schedule and args.workload == "transfer":
-        # every rank must take part (barriers); only rank 0 built the key when world == 1
-        if world == 1:
-            rs = max(2, args.steps // 2)
-            dt_ref, _, proofs_ref = timed(pk_ref, rs, 1, profile=False)
-            a, b = cg.proof_to_arrays(proofs_ref[0]), cg.proof_to_arrays(proofs[0])
-            same = all(np.array_equal(a[k], b[k]) for k in a)
-            out["reference_schedule"] = {"proofs_per_s": P * rs / dt_ref, "steps": rs,
-                                         "note": "all 25 coset NTTs re-run per proof as jf-plonk does",
-                                         "proof_identical_to_cached_mode": bool(same)}
-            cg.plonk_free_key(pk_ref)
+        rs = max(2, args.steps // 2)
+        dt_ref, _, proofs_ref, _ = timed(pk_ref, rs, 1, profile=False)
+        a, b = cg.proof_to_arrays(proofs_ref[0]), cg.proof_to_arrays(proofs[0])
+        same = all(np.array_equal(a[k], b[k]) for k in a)
+        out["reference_schedule"] = {"proofs_per_s": P * rs / dt_ref, "steps": rs,
+                                     "note": "like-for-like schedule: all 25 coset NTTs re-run per proof as jf-plonk does "
+                                             "(the headline keeps the 18 key columns' coset evaluations resident)",
+                                     "proof_identical_to_cached_mode": bool(same)}
+        cg.plonk_free_key(pk_ref)
 
-    # ---- CPU baseline: the C restatement of the arkworks/jf-plonk algorithm, 1 thread, rank 0, N = 1 ----------
+    # ---- bounded secondary measurements on one GPU -------------------------------------------------------
+    if world == 1 and args.workload == "transfer" and not args.no_extras:
+        # (1) one proof at a time: what the reference's criterion bench times (benches/transfer.rs:103-105)
+        d1 = cg.DevBuf.from_numpy(wires[:1])
+        for _ in range(2):
+            cg.plonk_prove_batch_dev(pk, d1, pubs[:1], blind[:1], ext_msg, 1)
+        lat = []
+        for _ in range(7):
+            t0 = time.perf_counter()
+            p1 = cg.plonk_prove_batch_dev(pk, d1, pubs[:1], blind[:1], ext_msg, 1)
+            lat.append((time.perf_counter() - t0) * 1e3)
+        a, b = cg.proof_to_arrays(p1[0]), cg.proof_to_arrays(proofs[0])
+        out["latency_ms_batch1"] = {"median": sorted(lat)[len(lat) // 2], "min": min(lat), "max": max(lat), "runs": len(lat),
+                                    "same_proof_as_in_the_batch": bool(all(np.array_equal(a[k], b[k]) for k in a)),
+                                    "note": "capgpu_plonk_prove_batch_dev with count = 1, witness resident; the GPU is mostly "
+                                            "idle at this size (latency-bound launches)"}
+        d1.free()
+        # (2) the boundary handing over HOST buffers: wires cross PCIe inside the timed region (never `value`)
+        for _ in range(1):
+            cg.plonk_prove_batch(pk, wires, pubs, blind, ext_msg, P)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        reps = 3
+        for _ in range(reps):
+            ph = cg.plonk_prove_batch(pk, wires, pubs, blind, ext_msg, P)
+        dt_h = (time.perf_counter() - t0) / reps
+        out["pcie_inclusive"] = {"proofs_per_s": P / dt_h, "ms_per_step": dt_h * 1e3,
+                                 "host_bytes_per_step": int(wires.nbytes),
+                                 "note": "capgpu_plonk_prove_batch: the 5 wire columns of every proof (5 n x 32 B) are copied "
+                                         "from pageable host memory inside the call"}
+        del ph
+        # (3) the reference's own bench depth: n = 2^16 (TREE_DEPTH = 26, src/bench_utils/mod.rs:42)
+        if log_n == 15:
+            t0 = time.time()
+            srs16 = cg.srs_generate(tau, (1 << 16) + 3)
+            sc16 = bu.synthetic_circuit(16, num_inputs, seed=2 + 16 + num_inputs)
+            pk16, _ = cg.plonk_preprocess(srs16, 1 << 16, num_inputs, sc16.selectors_mont(), sc16.sigma_mont())
+            w16 = [sc16.witness(3 + i) for i in range(2)]
+            P16 = min(P, 128)
+            wm16 = [sc16.wires_mont(w[0]) for w in w16]
+            d16 = cg.DevBuf.from_numpy(np.stack([wm16[i % 2] for i in range(P16)]))
+            pubs16 = np.stack([bu.to_mont_array(w16[i % 2][1]) for i in range(P16)])
+            bl16 = np.stack([bu.to_mont_array(bu.blinders(9000 + i)) for i in range(P16)])
+            cg.plonk_prove_batch_dev(pk16, d16, pubs16, bl16, ext_msg, P16)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                cg.plonk_prove_batch_dev(pk16, d16, pubs16, bl16, ext_msg, P16)
+            dt16 = (time.perf_counter() - t1) / 3
+            out["n2p16"] = {"proofs_per_s": P16 / dt16, "ms_per_step": dt16 * 1e3, "batch": P16, "domain_size": 1 << 16,
+                            "setup_s": round(time.time() - t0, 1),
+                            "note": "same prover at the transfer shape of Merkle depth 26 (n = 2^16), 3 steps"}
+            d16.free()
+            cg.plonk_free_key(pk16)
+            cg.srs_free(srs16)
+
+    # ---- BASELINE config 4 in its two modes (N > 1 only for mode A) ---------------------------------------------------
+    if args.workload == "mixed64":
+        out["mixed64_mode_B_replicas"] = {"proofs_per_s": value, "ms_per_step": dt / args.steps * 1e3,
+                                          "note": "proof i on rank i mod N; no data-path collective"}
+        if world > 1 and lib_comm:
+            # mode A: every rank proves all 64 proofs, each commitment MSM sharded by point range + RCCL exchange
+            full = [make_group(p[0], p[1], p[2], p[4], 0, n_wit=3) for p in plan]
+            cg.plonk_shard_msm(True)
+            try:
+                dt_a, _, proofs_a, _ = timed(None, max(2, args.steps // 2), 1, profile=False, grps=full)
+                steps_a = max(2, args.steps // 2)
+                ser = cg.proof_serialize(proofs_a[0])
+                t = torch.frombuffer(bytearray(ser), dtype=torch.uint8).clone().to(coll_dev)
+                ref = t.clone()
+                dist.broadcast(ref, src=0)
+                same = bool(torch.equal(ref, t))
+                agree = torch.tensor([1 if same else 0], device=coll_dev)
+                dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+                out["mixed64_mode_A_sharded_msm"] = {
+                    "proofs_per_s": 64 * steps_a / dt_a, "ms_per_step": dt_a / steps_a * 1e3,
+                    "all_ranks_hold_the_same_proofs": bool(agree.item() == 1),
+                    "note": "every rank runs all NTT / quotient work (NTT stays single-GPU) and 1/N of every commitment "
+                            "MSM; one ncclAllGather of 96 B x MSMs per round"}
+            finally:
+                cg.plonk_shard_msm(False)
+            for g in full:
+                cg.plonk_free_key(g["pk"])
+        elif world > 1:
+            out["mixed64_mode_A_sharded_msm"] = {"error": lib_comm_error or "needs the nccl backend"}
+
+    # ---- CPU baseline: the C restatement of the arkworks/jf-plonk algorithm, rank 0, N = 1 ---------------------------
     if rank == 0 and world == 1 and not args.no_cpu_baseline and args.workload == "transfer":
         from oracle import capref as cr        # cpu_baseline leg: the only place bench.py touches oracle/
         key = cr.PlonkKey(cg.srs_download(srs, 0, n + 3), n, num_inputs, sel, sig)
@@ -345,7 +461,7 @@ def main():
             parity = parity and bool(rc == 0 and np.array_equal(got_comms, comms) and np.array_equal(got_evals, evals))
         h2 = cg.g2_generator()
         t0 = time.perf_counter()
-        accepted = cg.plonk_verify(_vk0, h2, cg.g2_mul(h2, tau), pubs[0], proofs[0], ext_msg)
+        accepted = cg.plonk_verify(g0["vk"], h2, cg.g2_mul(h2, tau), pubs[0], proofs[0], ext_msg)
         out["verify"] = {"accepted_by_product_verifier": bool(accepted), "ms": (time.perf_counter() - t0) * 1e3,
                          "note": "host-side pairing check (capgpu_plonk_verify), outside the timed region"}
         out["cpu_baseline"] = {"value": 1.0 / t_cpu, "unit": "proofs/s", "cores": 1, "kind": "port",
@@ -353,15 +469,36 @@ def main():
                                          "restatement of the arkworks/jf-plonk algorithm (reference schedule, no asm)",
                                "gpu_proof_bit_exact_vs_cpu": parity}
         out["speedup_vs_cpu_1core"] = value / (1.0 / t_cpu)
-    # ---- MSM leg: BASELINE config 2 (2^17 points) on one GPU, and a point-range-sharded MSM over all ranks ------
+        # all host cores: one proof per thread, the way the reference parallelises over notes (rayon par_iter,
+        # src/utils/params_builder.rs:194-226); the C prover is re-entrant and ctypes releases the GIL
+        from concurrent.futures import ThreadPoolExecutor
+        cores = max(1, min(os.cpu_count() or 1, 64))
+        n_w = wires.shape[0]
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            res = list(ex.map(lambda i: key.prove(wires[i % n_w], pubs[i % n_w], blind[i % n_w], ext_msg)[0], range(cores)))
+        t_all = time.perf_counter() - t0
+        out["cpu_baseline_all_cores"] = {"value": cores / t_all, "unit": "proofs/s", "cores": cores, "kind": "port",
+                                         "all_ok": bool(all(r == 0 for r in res)),
+                                         "sample": f"{cores} proofs, one per thread on {os.cpu_count()} logical cores, {t_all:.1f} s "
+                                                   "(the same single-thread C prover run concurrently, as the reference's "
+                                                   "par_iter over notes does)"}
+        out["speedup_vs_cpu_all_cores"] = value / (cores / t_all)
+    # ---- MSM legs: BASELINE config 2 (2^17 points) on one GPU, and a point-range-sharded MSM over all ranks ------
     if not args.no_msm:
         legs = []
-        if world == 1:
-            legs.append(msm_leg(cg, bu, torch, dist, rank, world, 17, coll_dev=coll_dev))
-        legs.append(msm_leg(cg, bu, torch, dist, rank, world, args.msm_log_n, coll_dev=coll_dev))
+        try:
+            if world == 1:
+                legs.append(msm_leg(cg, bu, torch, dist, rank, world, 17, coll_dev=coll_dev))
+            big = args.msm_log_n if args.msm_log_n is not None else (22 if world == 1 else 24)
+            legs.append(msm_leg(cg, bu, torch, dist, rank, world, big, coll_dev=coll_dev, use_lib_comm=lib_comm))
+        except Exception as e:                # a failed secondary leg must not lose the headline line
+            legs.append({"error": str(e)})
         out["msm"] = legs
     if rank == 0:
         print(json.dumps(out), flush=True)
+    if lib_comm:
+        cg.comm_destroy()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -172,6 +172,30 @@ __global__ __launch_bounds__(64) void g1_sum_kernel(const g1_jac* __restrict__ i
   if (threadIdx.x == 0) *out = G1L::to_jac_ext(acc);
 }
 
+// Issue rate of v_mad_u64_u32, the instruction 84 % of a field multiplication consists of: 8 independent accumulate
+// chains per lane, 8 waves per SIMD.  Prices the multiplication ceiling of the chip (bench.py: alu_roofline.peak).
+__global__ __launch_bounds__(256) void ubench_mad_kernel(uint64_t* io, int iters) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t acc[8];
+  const uint32_t a = (uint32_t)io[i] | 1u, b = (uint32_t)(io[i] >> 32) | 1u;
+#pragma unroll
+  for (int c = 0; c < 8; c++) acc[c] = io[i] + c;
+  for (int k = 0; k < iters; k++) {
+#pragma unroll
+    for (int rep = 0; rep < 8; rep++)
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        uint64_t r, carry;
+        asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(a), "v"(b + c), "v"(acc[c]));
+        acc[c] = r;
+      }
+  }
+  uint64_t x = 0;
+#pragma unroll
+  for (int c = 0; c < 8; c++) x ^= acc[c];
+  io[i] = x;
+}
+
 fe fe_from_u64x4(const uint64_t v[4]) {
   fe r;
   for (int i = 0; i < 4; i++) {
@@ -585,6 +609,38 @@ int capgpu_ntt_fr(uint64_t* data, uint32_t log_n, int dir, int coset) {
 }
 
 // ---- instrumentation ------------------------------------------------------------------------------
+int capgpu_ubench_mad_rate(double* lane_ops_per_s_out) {
+  CAP_CHECK_INIT();
+  if (!lane_ops_per_s_out) return CAPGPU_ERR_INVALID_ARG;
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  hipDeviceProp_t prop;
+  CAP_HIP(hipGetDeviceProperties(&prop, c.device));
+  const int blocks = prop.multiProcessorCount * 8, iters = 2000;  // 8 workgroups of 4 waves per CU: 8 waves per SIMD
+  DevTmp<uint64_t> d;
+  CAP_HIP(d.alloc((size_t)blocks * 256));
+  CAP_HIP(hipMemsetAsync(d, 0x5a, sizeof(uint64_t) * blocks * 256, c.stream));
+  hipEvent_t e0, e1;
+  CAP_HIP(hipEventCreate(&e0));
+  CAP_HIP(hipEventCreate(&e1));
+  hipLaunchKernelGGL(ubench_mad_kernel, dim3(blocks), dim3(256), 0, c.stream, d.p, 10);  // warm-up
+  double best = 0;
+  for (int rep = 0; rep < 3; rep++) {
+    hipEventRecord(e0, c.stream);
+    hipLaunchKernelGGL(ubench_mad_kernel, dim3(blocks), dim3(256), 0, c.stream, d.p, iters);
+    hipEventRecord(e1, c.stream);
+    CAP_HIP(hipEventSynchronize(e1));
+    float ms = 0;
+    hipEventElapsedTime(&ms, e0, e1);
+    const double rate = (double)blocks * 256 * iters * 64 / (ms * 1e-3);
+    if (rate > best) best = rate;
+  }
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  *lane_ops_per_s_out = best;
+  return take_launch_error();
+}
+
 int capgpu_profile_enable(int on) {
   std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   profiler().on = on != 0;

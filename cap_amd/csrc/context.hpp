@@ -61,6 +61,15 @@ int register_srs(g1_affine* d_bases, size_t n, uint64_t* handle_out);
 int find_srs(uint64_t h, const MsmBases** out);
 SrsEntry* find_srs_entry(uint64_t h);  // nullptr when unknown
 
+// comm.hip: the RCCL communicator of a multi-process job (one process per GPU)
+bool comm_active();        // a communicator of more than one rank exists
+bool comm_shard_prover();  // the prover's commitment MSMs are sharded by point range over the ranks
+int comm_rank();
+int comm_world();
+struct g1_jac;
+// all-gather of `count` points per rank on stream s + their per-index sums, in place (same result on every rank)
+int comm_allgather_sum(g1_jac* d_points, uint32_t count, hipStream_t s);
+
 // Owning device pointer for temporaries of an entry point: freed on every return path (the OOM paths included).
 template <class T>
 struct DevTmp {

@@ -19,8 +19,9 @@ struct g1x {  // XYZZ, registers
   fl x, y, zz, zzz;
 };
 
-struct G1L {
-  using F = Fq29;
+template <int SCHED>
+struct G1LT {
+  using F = Fl<FqP29, SCHED>;
 
   static CAP_HD bool all_zero(const fl& a) {
     uint32_t o = 0;
@@ -216,5 +217,6 @@ struct G1L {
     return r;
   }
 };
+using G1L = G1LT<CAP_FL_SCHED>;  // the translation unit's default multiplication schedule (field29.hpp)
 
 }  // namespace cap

@@ -684,18 +684,23 @@ __global__ __launch_bounds__(kThreads) void msm_reduce_segments(const g1_xyzz* _
   seg_pts[2 * (size_t)t + 1] = G1L::store(T);
 }
 
+// The one-wavefront-per-MSM finishing kernels are single dependent chains of point operations: latency, not issue
+// slots, is their cost, and there the row-wise multiplication (18 independent accumulators) is the faster schedule.
+using G1S = G1LT<0>;
+template <class G = G1L>
 __device__ __forceinline__ g1x wave_sum(g1x v) {
   for (int d = 32; d >= 1; d >>= 1) {
     g1x o = shfl_down_pt(v, d);
-    v = G1L::add(v, o);
+    v = G::add(v, o);
   }
   return v;  // lane 0 holds the sum
 }
+template <class G = G1L>
 __device__ g1x mul_small(const g1x& p, uint32_t k) {
-  g1x r = G1L::inf();
+  g1x r = G::inf();
   for (int bit = 31; bit >= 0; bit--) {
-    if (!G1L::is_inf(r)) r = G1L::dbl(r);
-    if ((k >> bit) & 1) r = G1L::add(r, p);
+    if (!G::is_inf(r)) r = G::dbl(r);
+    if ((k >> bit) & 1) r = G::add(r, p);
   }
   return r;
 }
@@ -715,27 +720,27 @@ __global__ __launch_bounds__(64) void msm_reduce_final(const g1_xyzz* __restrict
   uint32_t s_hi = s_lo + q;
   if (s_hi > nseg) s_hi = nseg;
   const g1_xyzz* sp = seg_pts + 2 * (size_t)b * nseg;
-  g1x S = G1L::inf(), T = G1L::inf(), A = G1L::inf();
+  g1x S = G1S::inf(), T = G1S::inf(), A = G1S::inf();
   for (uint32_t s = s_hi; s > s_lo;) {
     s--;
-    T = G1L::add(T, S);                       // every segment above s gains one more unit of weight
-    S = G1L::add(S, G1L::load(sp[2 * s]));
-    A = G1L::add(A, G1L::load(sp[2 * s + 1]));
+    T = G1S::add(T, S);                       // every segment above s gains one more unit of weight
+    S = G1S::add(S, G1S::load(sp[2 * s]));
+    A = G1S::add(A, G1S::load(sp[2 * s + 1]));
   }
   // S = sum S_s, T = sum (s - s_lo) S_s, A = sum T_s over the lane's segments
   g1x suf = S;  // inclusive suffix sum over lanes
   for (int d = 1; d < 64; d <<= 1) {
     g1x o = shfl_down_pt(suf, d);
-    if (lane + d < 64) suf = G1L::add(suf, o);
+    if (lane + d < 64) suf = G1S::add(suf, o);
   }
-  if (lane == 0) suf = G1L::inf();
+  if (lane == 0) suf = G1S::inf();
   // per lane: A + seg_len * (T + q * suf); their sum over the wave is the result
-  g1x r = G1L::add(T, mul_small(suf, q));
-  r = G1L::add(mul_small(r, seg_len), A);
-  r = wave_sum(r);
+  g1x r = G1S::add(T, mul_small<G1S>(suf, q));
+  r = G1S::add(mul_small<G1S>(r, seg_len), A);
+  r = wave_sum<G1S>(r);
   if (lane == 0) {
-    if (out_part) out_part[b] = G1L::store(r);
-    else out[b] = G1L::to_jac_ext(r);
+    if (out_part) out_part[b] = G1S::store(r);
+    else out[b] = G1S::to_jac_ext(r);
   }
 }
 
@@ -805,22 +810,22 @@ __global__ __launch_bounds__(64) void msm_reduce_bits_final(const g1_xyzz* __res
                                                        uint32_t chunks, g1_jac* __restrict__ out,
                                                        g1_xyzz* __restrict__ out_part) {
   const uint32_t b = blockIdx.x, lane = threadIdx.x;
-  g1x acc = G1L::inf();
+  g1x acc = G1S::inf();
   if (lane < c) {
     const g1_xyzz* p = partial + ((size_t)b * c + lane) * chunks;
-    for (uint32_t k = 0; k < chunks; k++) acc = G1L::add(acc, G1L::load(p[k]));
+    for (uint32_t k = 0; k < chunks; k++) acc = G1S::add(acc, G1S::load(p[k]));
   }
   for (uint32_t k = 0; k + 1 < c; k++) {
-    g1x d = G1L::dbl(acc);
+    g1x d = G1S::dbl(acc);
     if (lane > k && lane < c) acc = d;
   }
   for (int d = 16; d >= 1; d >>= 1) {
     g1x o = shfl_down_pt(acc, d);
-    acc = G1L::add(acc, o);
+    acc = G1S::add(acc, o);
   }
   if (lane == 0) {
-    if (out_part) out_part[b] = G1L::store(acc);
-    else out[b] = G1L::to_jac_ext(acc);
+    if (out_part) out_part[b] = G1S::store(acc);
+    else out[b] = G1S::to_jac_ext(acc);
   }
 }
 
@@ -828,10 +833,10 @@ __global__ __launch_bounds__(64) void msm_reduce_bits_final(const g1_xyzz* __res
 __global__ __launch_bounds__(64) void msm_sum_parts(const g1_xyzz* __restrict__ part_pts, uint32_t parts,
                                                     g1_jac* __restrict__ out) {
   const uint32_t b = blockIdx.x, lane = threadIdx.x;
-  g1x acc = G1L::inf();
-  for (uint32_t k = lane; k < parts; k += 64) acc = G1L::add(acc, G1L::load(part_pts[(size_t)b * parts + k]));
-  acc = wave_sum(acc);
-  if (lane == 0) out[b] = G1L::to_jac_ext(acc);
+  g1x acc = G1S::inf();
+  for (uint32_t k = lane; k < parts; k += 64) acc = G1S::add(acc, G1S::load(part_pts[(size_t)b * parts + k]));
+  acc = wave_sum<G1S>(acc);
+  if (lane == 0) out[b] = G1S::to_jac_ext(acc);
 }
 // an MSM over no points
 __global__ void msm_fill_inf(g1_jac* __restrict__ out, uint32_t batch) {

@@ -217,10 +217,21 @@ int run_ntt3_inv(hipStream_t s, uint32_t log_mm, fe* data, uint32_t count) {
 int run_msm(hipStream_t s, const MsmBases& B, const fe* scalars, size_t outer_stride, uint32_t inner,
             size_t inner_stride, size_t n, uint32_t batch, g1_jac* d_out) {
   Context& c = ctx();
-  int rc = scratch_reserve(c.msm_ws, msm_workspace_bytes(B, n, batch));
+  // Mode A of BASELINE config 4 (capgpu_plonk_shard_msm): every rank proves the same batch, each commitment MSM is cut
+  // by point range over the ranks and finished by one all-gather of 96-byte partials + G - 1 additions.
+  // All ranks then hold the same commitments, derive the same challenges and stay in lock step.
+  size_t lo = 0, len = n;
+  if (comm_shard_prover()) {
+    const size_t world = (size_t)comm_world(), rank = (size_t)comm_rank();
+    const size_t base = n / world, rem = n % world;
+    lo = rank * base + std::min(rank, rem);
+    len = base + (rank < rem ? 1 : 0);
+  }
+  int rc = scratch_reserve(c.msm_ws, msm_workspace_bytes(B, len, batch));
   if (rc) return rc;
-  rc = msm_run(B, 0, scalars, outer_stride, inner, inner_stride, n, batch, 1, d_out, c.msm_ws.p, c.msm_ws.cap, s);
+  rc = msm_run(B, lo, scalars + lo, outer_stride, inner, inner_stride, len, batch, 1, d_out, c.msm_ws.p, c.msm_ws.cap, s);
   if (rc) return hip_fail((hipError_t)rc, "msm_run");
+  if (comm_shard_prover()) return comm_allgather_sum(d_out, batch, s);
   return CAPGPU_OK;
 }
 

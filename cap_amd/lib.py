@@ -214,6 +214,51 @@ def msm_plan(handle: int, n: int, count: int = 1) -> dict:
     return out
 
 
+# ---- multi-GPU (one process per GPU; RCCL inside the library) -----------------------------------------------------
+def comm_unique_id() -> bytes:
+    buf = (ctypes.c_uint8 * 128)()
+    check(load().capgpu_comm_unique_id(buf))
+    return bytes(buf)
+
+
+def comm_init(rank: int, world: int, unique_id: bytes):
+    assert len(unique_id) == 128
+    check(load().capgpu_comm_init(rank, world, (ctypes.c_uint8 * 128).from_buffer_copy(unique_id)))
+
+
+def comm_destroy():
+    check(load().capgpu_comm_destroy())
+
+
+def comm_info():
+    r, w = ctypes.c_int(0), ctypes.c_int(0)
+    check(load().capgpu_comm_info(ctypes.byref(r), ctypes.byref(w)))
+    return r.value, w.value
+
+
+def msm_g1_sharded_dev(handle: int, d_scalars: DevBuf, n_local: int, count: int = 1, stride: int | None = None,
+                       montgomery: bool = False, offset: int = 0, d_out: DevBuf | None = None) -> DevBuf:
+    if d_out is None:
+        d_out = DevBuf(96 * count)
+    check(load().capgpu_msm_g1_sharded_dev(ctypes.c_uint64(handle), ctypes.c_size_t(offset), d_scalars.ptr,
+                                           ctypes.c_size_t(n_local if stride is None else stride),
+                                           ctypes.c_size_t(n_local), count, int(montgomery), d_out.ptr))
+    return d_out
+
+
+def msm_g1_sharded(handle: int, scalars: np.ndarray, offset: int = 0) -> np.ndarray:
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros(12, dtype=np.uint64)
+    check(load().capgpu_msm_g1_sharded(ctypes.c_uint64(handle), ctypes.c_size_t(offset),
+                                       _p(scalars) if scalars.size else None, ctypes.c_size_t(scalars.shape[0]),
+                                       _p(out)))
+    return out
+
+
+def plonk_shard_msm(on: bool):
+    check(load().capgpu_plonk_shard_msm(int(on)))
+
+
 def g1_sum(points: np.ndarray) -> np.ndarray:
     """(k, 12) Jacobian points -> their group sum (12,)."""
     points = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 12)
@@ -244,6 +289,13 @@ def ntt_fr_dev(d_data: DevBuf, log_n: int, count: int = 1, stride: int | None = 
 
 
 # ---- instrumentation ---------------------------------------------------------------------------
+def ubench_mad_rate() -> float:
+    """measured v_mad_u64_u32 lane-operations per second of the bound device"""
+    out = ctypes.c_double(0)
+    check(load().capgpu_ubench_mad_rate(ctypes.byref(out)))
+    return out.value
+
+
 def profile_enable(on: bool):
     check(load().capgpu_profile_enable(int(on)))
 

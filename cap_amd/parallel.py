@@ -6,8 +6,11 @@
   exchange step is an all-gather of one 96-byte Jacobian point per rank (RCCL has no elliptic-curve
   reduction op, so no all-reduce), followed by G-1 group additions (`sharded_msm`).
 
-The local MSM engine and the point-combine are passed in, so the same code path runs on RCCL with the
-HIP kernels (bench.py) and on gloo in the CPU tests.
+On GPUs the exchange step lives inside libcapgpu.so (`capgpu_comm_init` + `capgpu_msm_g1_sharded*`,
+cap_amd/csrc/comm.hip): RCCL all-gather on the library stream from device memory, sum on the device.
+`init_library_comm` bootstraps that communicator from an existing torch.distributed job (rank 0's
+ncclUniqueId is broadcast to the others).  `sharded_msm` below is the same algorithm with the engine and
+the combine passed in - the form the CPU (gloo) tests drive with the oracle standing in for the HIP engine.
 """
 from __future__ import annotations
 
@@ -26,6 +29,33 @@ def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
 def shard_proofs(count: int, rank: int, world: int) -> list[int]:
     """proof i -> rank i mod world (the reference's par_iter over notes, params_builder.rs:194-226)."""
     return [i for i in range(count) if i % world == rank]
+
+
+def broadcast_bytes(payload: bytes | None, nbytes: int, src: int = 0, device=None) -> bytes:
+    """rank `src` passes `payload` (nbytes long), the others None; everyone gets the bytes back."""
+    import torch
+    import torch.distributed as dist
+
+    if dist.get_rank() == src:
+        assert payload is not None and len(payload) == nbytes
+        t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone()
+    else:
+        t = torch.zeros(nbytes, dtype=torch.uint8)
+    if device is not None:
+        t = t.to(device)
+    dist.broadcast(t, src=src)
+    return bytes(t.cpu().numpy().tobytes())
+
+
+def init_library_comm(lib, device=None) -> tuple[int, int]:
+    """Create libcapgpu's RCCL communicator over the ranks of the running torch.distributed job.
+    `lib` = cap_amd.lib (already initialised on this rank's GPU).  Returns (rank, world)."""
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    uid = broadcast_bytes(lib.comm_unique_id() if rank == 0 else None, 128, 0, device)
+    lib.comm_init(rank, world, uid)
+    return rank, world
 
 
 def all_gather_points(local_point: np.ndarray, device=None) -> np.ndarray:

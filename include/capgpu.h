@@ -65,8 +65,9 @@ extern "C" {
 #define CAPGPU_NUM_SELECTORS 13
 
 /* ---- lifecycle ------------------------------------------------------------------------- */
-/* Binds this process to one GPU (device_ids[0]; one process per GPU is the scaling model).
- * Idempotent.  device_ids == NULL selects HIP device 0. */
+/* Binds this process to ONE GPU: device_ids[0] (NULL selects HIP device 0).  Further ids are ignored - a process
+ * drives one device; N GPUs are N processes (see "multi-GPU" below), which is also what keeps the per-process lock
+ * from serialising work that could run on different devices.  Idempotent. */
 int capgpu_init(const int* device_ids, int n_devices);
 void capgpu_shutdown(void);
 const char* capgpu_last_error(void);
@@ -120,6 +121,36 @@ int capgpu_msm_plan(uint64_t srs_handle, size_t n, int count, char* buf, size_t 
 /* out = sum of n Jacobian points (96 B each, host memory): the combine step after the all-gather of a
  * point-range-sharded MSM (replaces the G-1 `GroupProjective::add_assign` a multi-GPU caller would do). */
 int capgpu_g1_sum(const uint64_t* points_xyz, size_t n, uint64_t out_xyz[12]);
+
+/* ---- multi-GPU: one process per GPU, MSM sharded by point range -------------------------------
+ * The reference parallelises inside one process (rayon, src/utils/params_builder.rs:194-226); a multi-GPU
+ * deployment starts one worker process per GPU.  Rank g uploads (or generates) the bases of ITS point range as its
+ * SRS and passes the matching scalar slice; every rank runs the whole Pippenger locally down to one point, then ONE
+ * exchange step - an RCCL all-gather of the 96-byte partial per MSM on the library stream, device to device over xGMI -
+ * and G - 1 group additions on the device give every rank the full result.  (RCCL has no elliptic-curve reduction
+ * operator, hence no all-reduce; bucket arrays are never exchanged.)
+ *
+ * capgpu_comm_unique_id: called by ONE rank; the 128 bytes (an ncclUniqueId) travel to the other ranks by whatever
+ * channel the job has (MPI, a socket, torch.distributed - bench.py broadcasts them).  capgpu_comm_init is collective:
+ * it returns once all `world` ranks have called it.  RCCL is loaded at that moment (dlopen of librccl.so.1; a copy
+ * already in the process is reused), so single-GPU users need no RCCL at all. */
+int capgpu_comm_unique_id(uint8_t id_out[128]);
+int capgpu_comm_init(int rank, int world, const uint8_t id[128]);
+int capgpu_comm_destroy(void);
+/* rank / world of the communicator; world == 0 when there is none */
+int capgpu_comm_info(int* rank_out, int* world_out);
+/* out (on every rank) = sum over ranks of sum_i scalars_r[i] * bases_r[offset + i]: `count` MSMs in one launch, their
+ * partials exchanged in ONE all-gather of count * 96 bytes per rank.  Arguments as capgpu_msm_g1_dev (n_local = this
+ * rank's points; may differ between ranks, count may not). */
+int capgpu_msm_g1_sharded_dev(uint64_t srs_handle, size_t offset, const void* d_scalars, size_t scalar_stride,
+                              size_t n_local, int count, int scalars_montgomery, void* d_out_xyz);
+int capgpu_msm_g1_sharded(uint64_t srs_handle, size_t offset, const uint64_t* scalars, size_t n_local,
+                          uint64_t out_xyz[12]);
+/* BASELINE config 4, mode A: with on != 0 every commitment MSM of capgpu_plonk_preprocess / capgpu_plonk_prove* is cut
+ * by point range over the ranks of the communicator (each rank holds the whole commit key, uses its range) and all
+ * ranks must then make the same calls with the same inputs; they all return the same proofs.  Mode B - the default,
+ * and the faster one for throughput - is replicas: independent proofs on independent ranks, no communicator needed. */
+int capgpu_plonk_shard_msm(int on);
 
 /* ---- NTT: replaces Radix2EvaluationDomain::{fft, ifft, coset_fft, coset_ifft}_in_place -------- */
 /* in place, natural order in/out, Montgomery Fr; dir: 0 forward, 1 inverse (includes n^-1);
@@ -252,6 +283,10 @@ int capgpu_plonk_key_deserialize(const uint8_t* bytes, size_t len, uint64_t* srs
                                  size_t* consumed_out);
 
 /* ---- instrumentation ------------------------------------------------------------------------------ */
+/* Measured issue rate of v_mad_u64_u32 on the bound device, in lane-operations per second (8 independent chains per
+ * lane, 8 waves per SIMD, ~50 ms).  A lazy Montgomery multiplication is 171 of them (81 + 81 + 9), so rate / 171 is the
+ * chip's multiplication ceiling - what bench.py prices the ALU-bound kernels against. */
+int capgpu_ubench_mad_rate(double* lane_ops_per_s_out);
 /* When enabled, every kernel launch is bracketed by HIP events on the launch stream and accumulated
  * per kernel name (costs a few microseconds per launch; leave off for throughput runs). */
 int capgpu_profile_enable(int on);

@@ -66,3 +66,19 @@ def test_param_sizes_pinned_by_the_reference():
     assert (1 << bu.NOTE_SHAPES["transfer_2x2_d26"][0]) + 2 == proof.compute_universal_param_size("transfer", 3, 5, 26)
     assert (1 << bu.NOTE_SHAPES["mint"][0]) + 2 == proof.compute_universal_param_size("mint", 0, 0, 26)
     assert (1 << bu.NOTE_SHAPES["freeze_2"][0]) + 2 == proof.compute_universal_param_size("freeze", 2, 0, 5)
+
+
+def test_weighted_scalar_sums_exact():
+    """the full-size MSM known answer (sum k_i, sum (lo + i) k_i) against Python integers, across a block boundary"""
+    sc = bu.random_canonical_scalars(3, (1 << 18) + 77)
+    ks = [int(w[0]) | int(w[1]) << 64 | int(w[2]) << 128 | int(w[3]) << 192 for w in sc]
+    assert all(k < bu.R for k in ks[:1000])
+    s0, s1 = bu.weighted_scalar_sums(sc, 12345)
+    assert s0 == sum(ks)
+    assert s1 == sum((12345 + i) * k for i, k in enumerate(ks))
+
+
+def test_transfer_public_input_counts():
+    """27 is pinned by the reference for 2-in/2-out (src/proof/transfer.rs:443-458 + the viewing memo layout)."""
+    assert bu.transfer_num_public_inputs(2, 2) == 27
+    assert bu.NOTE_SHAPES["transfer_2x2"] == (15, 27) and bu.NOTE_SHAPES["transfer_2x3"] == (15, 32)

@@ -33,6 +33,18 @@ def _worker(rank, world, port, n, q):
             acc = cr.g1_add(acc, p)
         return acc
 
+    # the bootstrap of the library's RCCL communicator: rank 0's unique id reaches every rank unchanged
+    class FakeLib:
+        seen = None
+
+        def comm_unique_id(self):
+            return bytes((7 * i + 3) % 256 for i in range(128))
+
+        def comm_init(self, r, w, uid):
+            FakeLib.seen = (r, w, uid)
+
+    assert par.init_library_comm(FakeLib()) == (rank, world)
+    assert FakeLib.seen == (rank, world, bytes((7 * i + 3) % 256 for i in range(128)))
     total = par.sharded_msm(local, combine)
     full = cr.msm_g1(bases, scalars)
     ok = np.array_equal(cr.g1_to_affine(total), cr.g1_to_affine(full))
