@@ -198,6 +198,18 @@ struct Fl {
     return normalize(r);
   }
 
+  // a - b + 2p WITHOUT carrying: limbs(a) + 2^30 at most.  For a value that is only ever added to / subtracted from
+  // before its next normalisation (the "u" side of the following butterfly), never a multiplicand.
+  static CAP_HD fl sub2p_lazy(const fl& a, const fl& b) {
+    fl r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      CAP_FL_ASSERT(i == 8 ? b.v[i] <= PR::SUB2P[i] : (b.v[i] < (1u << 29) && a.v[i] < (1u << 30)));
+      r.v[i] = a.v[i] + (PR::SUB2P[i] - b.v[i]);
+    }
+    return r;
+  }
+
   // ---- weak reduction: normalized x -> normalized value in [0, 2p) ------------------------------------
   static CAP_HD fl weak_reduce(const fl& x) {
     // q <= floor(x / p) <= q + 1 from the top limb: q = (x_8 * floor(2^272/p)) >> 40

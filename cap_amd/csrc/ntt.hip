@@ -117,11 +117,13 @@ __device__ __forceinline__ void lds_ntt(fl* sh, const fl* __restrict__ tw_small,
       const uint32_t i0 = (j << log_c) + c, i1 = i0 + step, i2 = i1 + step, i3 = i2 + step;
       fl a = sh[i0], b = sh[i1], cc = sh[i2], d = sh[i3];
       const fl w1 = tw_small[pos << (log_len - 1 - s)];  // omega^0 = 1 is multiplied like any other twiddle
+      // carries are propagated only where a value becomes a multiplicand (limbs < 2^30 needed) or goes back to LDS:
+      // a1, c1 = x + t have limbs < 2^30 as they are; b1 = a - t + 2p is only added to afterwards
       fl t = Fr29::mul(b, w1);
-      fl a1 = Fr29::normalize(Fr29::add(a, t));
-      fl b1 = Fr29::sub2p(a, t);
+      fl a1 = Fr29::add(a, t);
+      fl b1 = Fr29::sub2p_lazy(a, t);
       t = Fr29::mul(d, w1);
-      fl c1 = Fr29::normalize(Fr29::add(cc, t));
+      fl c1 = Fr29::add(cc, t);
       fl d1 = Fr29::sub2p(cc, t);
       t = Fr29::mul(c1, tw_small[pos << (log_len - 2 - s)]);
       sh[i0] = Fr29::normalize(Fr29::add(a1, t));

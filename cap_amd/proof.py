@@ -55,14 +55,29 @@ class VerifyingKey:
     beta_h: np.ndarray | None = None
 
 
-# Domain sizes the reference pins for BN254 (test_compute_srs_size, src/utils/mod.rs:136-193; gate count of
-# Transfer(2, 6, 10): src/proof/transfer.rs:602-603).  The real function builds the circuit and reads its evaluation
-# domain (src/utils/mod.rs:89-113); circuit construction is CPU-side and out of scope, so only the
-# pinned shapes are known here.
+def eval_domain_size(num_gates: int) -> int:
+    """Radix2EvaluationDomain size of a circuit with `num_gates` constraints: the smallest power of two that holds
+    them (jf-relation `Arithmetization::eval_domain_size`, called at src/utils/mod.rs:109-111)."""
+    if num_gates < 1:
+        raise TxnApiError.FailedSnark("a circuit has at least one gate")
+    return 1 << (num_gates - 1).bit_length()
+
+
+def universal_param_size_for_gates(num_gates: int) -> int:
+    """src/utils/mod.rs:108-112: evaluation-domain size + 2 ("+2 for handling zero-knowledge") - the `max_degree` to
+    pass to `universal_setup` for a circuit of that many constraints.  This is the whole arithmetic of
+    compute_universal_param_size; what remains of the reference's function is building the circuit to count its gates."""
+    return eval_domain_size(num_gates) + 2
+
+
+# Gate counts / domain sizes the reference itself states for BN254.  The real function builds the note's circuit
+# (src/circuit/*.rs - CPU-side, out of scope, SURVEY 8a A9) and reads its evaluation domain; only the shapes whose
+# result the reference pins are known here: test_compute_srs_size (src/utils/mod.rs:136-193) gives the sizes, and
+# src/proof/transfer.rs:602-603 the one explicit constraint count (2-in/6-out, depth 10: 30 740 gates).
+_PINNED_GATE_COUNTS = {("transfer", 2, 6, 10): 30740}
 _PINNED_PARAM_SIZES = {
     ("transfer", 3, 5, 26): 65538,
     ("transfer", 2, 2, 10): 32770,
-    ("transfer", 2, 6, 10): 32770,
     ("mint", 0, 0, 26): 16386,
     ("freeze", 2, 0, 5): 16386,
     ("freeze", 5, 0, 26): 65538,
@@ -70,15 +85,19 @@ _PINNED_PARAM_SIZES = {
 
 
 def compute_universal_param_size(note_type: str, num_inputs: int, num_outputs: int, tree_depth: int) -> int:
-    """src/utils/mod.rs:89-113: evaluation-domain size of the note's circuit + 2 (zero-knowledge blinding), i.e. the
-    `max_degree` to pass to `universal_setup`.  Known for the shapes the reference's tests pin; anything else needs the
-    circuit builder and raises like the reference does when the circuit cannot be built."""
+    """src/utils/mod.rs:89-113.  Known for the shapes the reference pins (a gate count -> computed; a pinned result ->
+    looked up); anything else needs the circuit builder and raises like the reference does when the circuit cannot be
+    built.  NOT a general implementation - see universal_param_size_for_gates for the part that is."""
+    key = (note_type.lower(), num_inputs, num_outputs, tree_depth)
+    if key in _PINNED_GATE_COUNTS:
+        return universal_param_size_for_gates(_PINNED_GATE_COUNTS[key])
     try:
-        return _PINNED_PARAM_SIZES[(note_type.lower(), num_inputs, num_outputs, tree_depth)]
+        return _PINNED_PARAM_SIZES[key]
     except KeyError:
         raise TxnApiError.FailedSnark(
             f"domain size of {note_type}({num_inputs}, {num_outputs}, depth {tree_depth}) is not pinned by the "
-            "reference's tests; it takes the circuit builder (out of scope) to compute it") from None
+            "reference's tests; it takes the circuit builder (out of scope) to count its gates - pass the count to "
+            "universal_param_size_for_gates instead") from None
 
 
 def universal_setup(max_degree: int, tau: int) -> UniversalSrs:

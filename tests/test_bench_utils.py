@@ -59,6 +59,10 @@ def test_param_sizes_pinned_by_the_reference():
     assert proof.compute_universal_param_size("Mint", 0, 0, 26) == 16386
     assert proof.compute_universal_param_size("Freeze", 2, 0, 5) == 16386
     assert proof.compute_universal_param_size("Freeze", 5, 0, 26) == 65538
+    # the arithmetic itself: domain = next power of two of the gate count, + 2 for the blinding
+    assert proof.compute_universal_param_size("Transfer", 2, 6, 10) == 32770          # 30 740 gates (transfer.rs:602)
+    assert proof.universal_param_size_for_gates(30740) == 32770 and proof.eval_domain_size(32768) == 32768
+    assert proof.eval_domain_size(32769) == 65536 and proof.eval_domain_size(1) == 1
     with pytest.raises(proof.TxnApiError):
         proof.compute_universal_param_size("Transfer", 7, 7, 3)
     # the synthetic circuits of the benchmark have exactly these domains: size - 2 = 2^log_n

@@ -69,7 +69,7 @@ def test_msm_plans_of_the_baseline_sizes(cg, tau):
     cg.srs_free(h)
     h = cg.srs_generate_affine_seq(A_SEQ, B_SEQ, 1 << 19)
     p = cg.msm_plan(h, 1 << 19, 1)
-    assert (p["c"], p["sort"], p["parts"], p["n_sub"]) == (15, "two-level", 64, 8192)
+    assert (p["c"], p["sort"], p["parts"], p["n_sub"]) == (15, "two-level", 64, 8192)    # no part below 8192 points
     assert cg.msm_plan(h, 100, 1)["parts"] == 1
     cg.srs_free(h)
 
