@@ -168,13 +168,30 @@ def main():
     torch.cuda.set_device(local_rank)
     # the library's own RCCL communicator (the sharded-MSM exchange step lives inside the C ABI)
     lib_comm, lib_comm_error = False, None
+    comm_thread_stuck = False
     if world > 1 and args.dist_backend == "nccl":
+        import threading
         from cap_amd import parallel as par
-        try:
-            par.init_library_comm(cg, device=coll_dev)
-            lib_comm = True
-        except Exception as e:                # reported in the JSON line; the replica headline does not need it
-            lib_comm_error = str(e)
+        box = {}
+
+        def _init():
+            try:
+                par.init_library_comm(cg, device=coll_dev)
+                box["ok"] = True
+            except Exception as e:            # reported in the JSON line; the replica headline does not need it
+                box["err"] = str(e)
+
+        th = threading.Thread(target=_init, daemon=True)
+        th.start()
+        th.join(timeout=180)                  # ncclCommInitRank is collective: never let it hang the headline
+        if th.is_alive():
+            comm_thread_stuck = True
+            box["err"] = "capgpu_comm_init did not return within 180 s"
+        mine = torch.tensor([1 if box.get("ok") else 0], device=coll_dev)
+        dist.all_reduce(mine, op=dist.ReduceOp.MIN)   # every rank takes the same path
+        lib_comm = bool(mine.item() == 1)
+        if not lib_comm:
+            lib_comm_error = box.get("err", "another rank failed to create the communicator")
     P, log_n = args.batch, args.log_n
     n = 1 << log_n
     num_inputs = 27
@@ -502,6 +519,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    if comm_thread_stuck:
+        sys.stdout.flush()
+        os._exit(0)                           # a thread is still blocked inside RCCL: do not wait for it at exit
 
 
 if __name__ == "__main__":

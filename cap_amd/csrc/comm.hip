@@ -173,21 +173,30 @@ int capgpu_comm_init(int rank, int world, const uint8_t id[128]) {
     set_error("capgpu_comm_init: bad argument (rank %d of %d)", rank, world);
     return CAPGPU_ERR_INVALID_ARG;
   }
-  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   Comm& c = comm();
-  if (c.comm) {
+  {
+    std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+    if (c.comm) {
+      set_error("capgpu_comm_init: a communicator already exists (capgpu_comm_destroy first)");
+      return CAPGPU_ERR_INVALID_ARG;
+    }
+    int rc = load_rccl(c.api);
+    if (rc) return rc;
+  }
+  // ncclCommInitRank is collective and blocks until every rank has arrived: the process lock is NOT held across it,
+  // so a rank that never shows up cannot freeze the single-GPU entry points of this process (bench.py relies on it)
+  ncclUniqueId uid;
+  memcpy(uid.internal, id, 128);
+  ncclComm_t nc = nullptr;
+  ncclResult_t e = c.api.CommInitRank(&nc, world, uid, rank);
+  if (e) return rccl_fail(e, "ncclCommInitRank");
+  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  if (c.comm) {  // a concurrent capgpu_comm_init won the race
+    c.api.CommDestroy(nc);
     set_error("capgpu_comm_init: a communicator already exists (capgpu_comm_destroy first)");
     return CAPGPU_ERR_INVALID_ARG;
   }
-  int rc = load_rccl(c.api);
-  if (rc) return rc;
-  ncclUniqueId uid;
-  memcpy(uid.internal, id, 128);
-  ncclResult_t e = c.api.CommInitRank(&c.comm, world, uid, rank);  // collective: blocks until all ranks arrive
-  if (e) {
-    c.comm = nullptr;
-    return rccl_fail(e, "ncclCommInitRank");
-  }
+  c.comm = nc;
   c.rank = rank;
   c.world = world;
   return CAPGPU_OK;
