@@ -176,7 +176,8 @@ def main():
 
         def _init():
             try:
-                par.init_library_comm(cg, device=coll_dev)
+                torch.cuda.set_device(local_rank)     # the current device is per thread
+                par.init_library_comm(cg, device=torch.device("cuda", local_rank))
                 box["ok"] = True
             except Exception as e:            # reported in the JSON line; the replica headline does not need it
                 box["err"] = str(e)
