@@ -169,7 +169,8 @@ def main():
     # the library's own RCCL communicator (the sharded-MSM exchange step lives inside the C ABI)
     lib_comm, lib_comm_error = False, None
     comm_thread_stuck = False
-    if world > 1 and args.dist_backend == "nccl":
+    force_comm = os.environ.get("CAPGPU_BENCH_FORCE_LIB_COMM") == "1"   # test hook: try the bootstrap under gloo too
+    if world > 1 and (args.dist_backend == "nccl" or force_comm):
         import threading
         from cap_amd import parallel as par
         box = {}
@@ -177,17 +178,17 @@ def main():
         def _init():
             try:
                 torch.cuda.set_device(local_rank)     # the current device is per thread
-                par.init_library_comm(cg, device=torch.device("cuda", local_rank))
+                par.init_library_comm(cg, device=torch.device("cuda", local_rank) if coll_dev == "cuda" else None)
                 box["ok"] = True
             except Exception as e:            # reported in the JSON line; the replica headline does not need it
                 box["err"] = str(e)
 
         th = threading.Thread(target=_init, daemon=True)
         th.start()
-        th.join(timeout=180)                  # ncclCommInitRank is collective: never let it hang the headline
+        th.join(timeout=float(os.environ.get("CAPGPU_BENCH_COMM_TIMEOUT", "180")))   # never let a collective init hang the headline
         if th.is_alive():
             comm_thread_stuck = True
-            box["err"] = "capgpu_comm_init did not return within 180 s"
+            box["err"] = "capgpu_comm_init did not return in time"
         mine = torch.tensor([1 if box.get("ok") else 0], device=coll_dev)
         dist.all_reduce(mine, op=dist.ReduceOp.MIN)   # every rank takes the same path
         lib_comm = bool(mine.item() == 1)
