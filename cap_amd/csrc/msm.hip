@@ -679,7 +679,9 @@ __global__ __launch_bounds__(kThreads) void msm_accumulate(const g1_affine* __re
     const fl qq = F::mul(acc.x, pp);
     g1x o;
     o.x = F::weak_reduce(F::sub(F::sub(F::sqr(r), ppp), F::add(qq, qq)));
-    o.y = F::weak_reduce(F::mul_add_mul(r, F::sub(qq, o.x), F::neg(acc.y), ppp));  // one reduction for both products
+    // one reduction for both products.  y is a product sum, < p (1 + (17.1^2 + 16 * 1.1) / 169) = 2.83 p: small enough
+    // for every later use (subtrahend < 15.9 p, 32-byte image < 2^256) without the weak reduction G1L::add_mixed applies
+    o.y = F::mul_add_mul(r, F::sub(qq, o.x), F::neg(acc.y), ppp);
     o.zz = F::mul(acc.zz, pp);
     o.zzz = F::mul(acc.zzz, ppp);
     acc = o;

@@ -65,48 +65,44 @@ struct PassParams {
 
 __device__ __forceinline__ uint32_t bitrev32(uint32_t x, uint32_t bits) { return __brev(x) >> (32 - bits); }
 
-// radix-2 DIT stages on sh[len][C] (rows were written bit-reversed): natural order out.
+// DIT stages on sh[len][C] (rows were written bit-reversed): natural order out.
 // Lazy 29-bit field: per butterfly  t = v * w (one Montgomery product, < 1.2p),  (u + t, u + 2p - t); values
 // grow by at most 2p per stage (<= 2p * 11 stages + input), far below the 169p capacity of 9 x 29-bit limbs.
 // Twiddles are stored in the internal Montgomery form (w * 2^261), so data keeps whatever form it came in.
+//
+// Stage plan: one radix-2 stage when the stage count is odd, then radix-4 rounds (stages s, s + 1 on four rows held in
+// registers: the same multiplications as two radix-2 stages at half the LDS traffic, index arithmetic and barriers -
+// 147 instead of 216 instructions per element and stage).  The first round of an even-length transform (s = 0) has
+// trivial twiddles - 1, 1 and omega_4 - and, for the prover's zero-padded inputs (a polynomial of n + 2 coefficients on a
+// 2n-point coset: rows len/2.. are zero), two zero operands: ONE multiplication for its four elements instead of four.
+__device__ __forceinline__ uint32_t fl_any(const fl& a) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int k = 0; k < 9; k++) o |= a.v[k];
+  return o;
+}
 __device__ __forceinline__ void lds_ntt(fl* sh, const fl* __restrict__ tw_small, uint32_t log_len, uint32_t log_c) {
   const uint32_t half_tile = 1u << (log_len + log_c - 1);
   const uint32_t cmask = (1u << log_c) - 1;
-  // the first three (or four) stages as single radix-2 stages: they carry the zero-padding shortcut; the remaining
-  // even number of stages goes two at a time below
-  uint32_t r2 = log_len < 3 ? log_len : (((log_len - 3) & 1) ? 4u : 3u);
-  if (r2 > log_len) r2 = log_len;
-  for (uint32_t s = 0; s < r2; s++) {
-    const uint32_t half = 1u << s;
+  const uint32_t s0 = log_len & 1;
+  if (s0) {
+    // stage 0 alone: every twiddle is omega^0 = 1
     for (uint32_t b = threadIdx.x; b < half_tile; b += kThreads) {
-      uint32_t c = b & cmask;
-      uint32_t bb = b >> log_c;
-      uint32_t pos = bb & (half - 1);
-      uint32_t j = ((bb >> s) << (s + 1)) + pos;
-      uint32_t i0 = (j << log_c) + c, i1 = ((j + half) << log_c) + c;
-      fl u = sh[i0], v = sh[i1];
-      if (s < 3) {
-        // zero-padded inputs (a degree-n polynomial evaluated on a much larger coset: most of the prover's transforms): the rows
-        // beyond len/8 are zero, so in the first three stages every odd operand is zero and the butterfly is a copy
-        uint32_t any = 0;
-#pragma unroll
-        for (int k = 0; k < 9; k++) any |= v.v[k];
-        if (any == 0) {
-          sh[i1] = u;
-          continue;
-        }
+      const uint32_t c = b & cmask, bb = b >> log_c;
+      const uint32_t i0 = ((bb << 1) << log_c) + c, i1 = i0 + (1u << log_c);
+      const fl u = sh[i0], v = sh[i1];
+      if (fl_any(v) == 0) {  // zero padding: the butterfly is a copy
+        sh[i1] = u;
+        continue;
       }
-      uint32_t e = pos << (log_len - 1 - s);
-      fl t = e ? Fr29::mul(v, tw_small[e]) : Fr29::weak_reduce(v);
+      const fl t = Fr29::weak_reduce(v);
       sh[i0] = Fr29::normalize(Fr29::add(u, t));
       sh[i1] = Fr29::sub2p(u, t);
     }
     __syncthreads();
   }
-  // radix-4: stages s and s + 1 on four rows j, j + h, j + 2h, j + 3h held in registers - the same four
-  // multiplications as two radix-2 stages, half the LDS traffic, index arithmetic and barriers
   const uint32_t quarter_tile = half_tile >> 1;
-  for (uint32_t s = r2; s + 1 < log_len; s += 2) {
+  for (uint32_t s = s0; s + 1 < log_len; s += 2) {
     const uint32_t h = 1u << s;
     const uint32_t step = h << log_c;
     for (uint32_t g = threadIdx.x; g < quarter_tile; g += kThreads) {
@@ -116,16 +112,38 @@ __device__ __forceinline__ void lds_ntt(fl* sh, const fl* __restrict__ tw_small,
       const uint32_t j = ((gg >> s) << (s + 2)) + pos;
       const uint32_t i0 = (j << log_c) + c, i1 = i0 + step, i2 = i1 + step, i3 = i2 + step;
       fl a = sh[i0], b = sh[i1], cc = sh[i2], d = sh[i3];
-      const fl w1 = tw_small[pos << (log_len - 1 - s)];  // omega^0 = 1 is multiplied like any other twiddle
       // carries are propagated only where a value becomes a multiplicand (limbs < 2^30 needed) or goes back to LDS:
       // a1, c1 = x + t have limbs < 2^30 as they are; b1 = a - t + 2p is only added to afterwards
-      fl t = Fr29::mul(b, w1);
-      fl a1 = Fr29::add(a, t);
-      fl b1 = Fr29::sub2p_lazy(a, t);
-      t = Fr29::mul(d, w1);
-      fl c1 = Fr29::add(cc, t);
-      fl d1 = Fr29::sub2p(cc, t);
-      t = Fr29::mul(c1, tw_small[pos << (log_len - 2 - s)]);
+      fl a1, b1, c1, d1, t;
+      if (s == 0) {
+        // w1 = 1: t = b, d themselves (weakly reduced for the subtraction); zero operands make the butterfly a copy
+        if (fl_any(b)) {
+          t = Fr29::weak_reduce(b);
+          a1 = Fr29::add(a, t);
+          b1 = Fr29::sub2p_lazy(a, t);
+        } else {
+          a1 = a;
+          b1 = a;
+        }
+        if (fl_any(d)) {
+          t = Fr29::weak_reduce(d);
+          c1 = Fr29::normalize(Fr29::add(cc, t));
+          d1 = Fr29::sub2p(cc, t);
+        } else {
+          c1 = cc;
+          d1 = cc;
+        }
+        t = Fr29::weak_reduce(c1);  // second-level twiddle of the (a1, c1) pair: omega^0 = 1
+      } else {
+        const fl w1 = tw_small[pos << (log_len - 1 - s)];
+        t = Fr29::mul(b, w1);
+        a1 = Fr29::add(a, t);
+        b1 = Fr29::sub2p_lazy(a, t);
+        t = Fr29::mul(d, w1);
+        c1 = Fr29::add(cc, t);
+        d1 = Fr29::sub2p(cc, t);
+        t = Fr29::mul(c1, tw_small[pos << (log_len - 2 - s)]);
+      }
       sh[i0] = Fr29::normalize(Fr29::add(a1, t));
       sh[i2] = Fr29::sub2p(a1, t);
       t = Fr29::mul(d1, tw_small[(pos + h) << (log_len - 2 - s)]);
