@@ -31,6 +31,9 @@ sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MADS_PER_MUL = 171       # lazy 9 x 29-bit Montgomery multiplication: 81 product + 81 reduction + 9 digit multiply-adds
+# VALU wave-instructions msm_accumulate executes per mixed addition: SQ_INSTS_VALU of the kernel / (additions / 64),
+# profiles/inst_counters_r02.json (static PMC pass; the loop body's ISA counts 2334, of which 1550 are multiply-adds)
+INSTR_PER_MIXED_ADD = 2302
 TRAFFIC_FILE = "profiles/traffic_r02.json"   # PMC pass (FETCH_SIZE / WRITE_SIZE) of this same command, batch 256
 
 
@@ -332,7 +335,12 @@ def main():
         alu = {"kernel": dom, "achieved": mul_eq, "peak": peak, "unit": "G field multiplications/s (equivalent)",
                "frac": mul_eq / peak, "mixed_adds_per_step": adds_per_step,
                "peak_source": f"measured v_mad_u64_u32 issue rate {mad_rate / 1e12:.1f} T lane-ops/s (capgpu_ubench_mad_rate, "
-                              f"this run) / {MADS_PER_MUL} multiply-adds per multiplication"}
+                              f"this run) / {MADS_PER_MUL} multiply-adds per multiplication",
+               # the kernel's real instruction stream against the same measured issue rate (every VALU instruction of
+               # the loop issues at the multiply-add's rate, tools/ubench_mulcol.hip)
+               "issue_frac": adds_per_step * args.steps * INSTR_PER_MIXED_ADD / (kern_ms[dom] * 1e-3) / mad_rate,
+               "issue_frac_source": f"{INSTR_PER_MIXED_ADD} VALU instructions per mixed addition (profiles/inst_counters_r02.json, "
+                                    "static PMC pass) x additions / kernel time / measured issue rate"}
     top = sorted(kern_ms.items(), key=lambda kv: -kv[1])[:8]
     whole_gbps = ab["total_bytes"] * total_proofs / dt / 1e9
     ps = sorted(per_step)

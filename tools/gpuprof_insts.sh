@@ -15,7 +15,7 @@ import csv, glob, collections
 agg = collections.defaultdict(lambda: collections.defaultdict(lambda: [0.0, 0]))
 for f in glob.glob("gpurun_out/insts_$tag/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "").replace("cap::(anonymous namespace)::", "").replace("cap::pk::", "")
+        k = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "").replace("cap::pk::", "").replace("cap::", "").split("(")[0]
         a = agg[k][r["Counter_Name"]]
         a[0] += float(r["Counter_Value"]); a[1] += 1
 for k in sorted(agg, key=lambda k: -agg[k].get("SQ_INSTS_VALU", [0])[0])[:10]:
