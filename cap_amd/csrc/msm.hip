@@ -335,13 +335,12 @@ __global__ __launch_bounds__(kThreads) void msm_sort_level2(const uint32_t* __re
   }
   __syncthreads();
   const uint32_t cnt = run_pre[nblk], off = off2[row0];
-  auto fetch = [&](uint32_t p) {  // p-th entry of the bin: binary search for its run
-    uint32_t lo = 0, hi = nblk;
-    while (hi - lo > 1) {
-      uint32_t mid = (lo + hi) >> 1;
-      if (run_pre[mid] <= p) lo = mid; else hi = mid;
-    }
-    return cbase[run_src[lo] + (p - run_pre[lo])] | (lo << 15);  // the entry remembers the tile it came from
+  // p-th entry of the bin.  A thread asks for increasing p (stride 256 against runs of ~130 entries), so the run is
+  // found by walking on from the previous one - about two steps - instead of a binary search over all runs per entry
+  uint32_t walk = 0;
+  auto fetch = [&](uint32_t p) {
+    while (walk + 1 < nblk && run_pre[walk + 1] <= p) walk++;
+    return cbase[run_src[walk] + (p - run_pre[walk])] | (walk << 15);  // the entry remembers the tile it came from
   };
   const size_t base = offset + (size_t)(b % parts) * n_sub;
   auto final_entry = [&](uint32_t v) {  // tile entry -> table index | sign
@@ -393,6 +392,7 @@ __global__ __launch_bounds__(kThreads) void msm_sort_level2(const uint32_t* __re
 #pragma unroll
   for (int i = 0; i < kPerThread; i++)
     if (threadIdx.x + i * kThreads < staged) place(ev[i]);
+  walk = 0;
   for (uint32_t p = kL2Stage + threadIdx.x; p < cnt; p += kThreads) place(fetch(p));
   __syncthreads();
   for (uint32_t p = threadIdx.x; p < staged; p += kThreads) dst[p] = stage[p];

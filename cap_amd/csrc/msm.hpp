@@ -20,7 +20,13 @@
 //  * bucket lists come from a counting sort done per 1024-scalar tile in LDS, a
 //    table scan and run copies (c = 13), or - when a tile holds only about one
 //    entry per bucket (c = 15) - a tile sort on 128-bucket bins followed by a
-//    per-bin LDS sort that reads the tile chunks directly;
+//    per-bin LDS sort that reads the tile chunks directly; tile entries are
+//    15-bit (window, scalar-in-tile) pairs, the table index is rebuilt by the
+//    consumer of a run, so a table may hold up to 2^31 points;
+//  * an MSM of more than 2^18 points (and every MSM of more than 73 728 points
+//    in a batch) is cut into sub-MSMs over consecutive point ranges that go
+//    through the batched path together; one more kernel adds their results -
+//    the same shape as sharding an MSM over several GPUs, one level down;
 //  * the unit of parallelism is a work item (a slice of one bucket's list), the
 //    items of a launch are ordered by length and alternate direction per MSM so
 //    that lanes of a wave, and the eight XCDs, finish together.
@@ -38,7 +44,8 @@ struct MsmBases {
   uint32_t windows = 0;      // W
   g1_affine* ext = nullptr;  // [W][n]: ext[w*n + i] = 2^(c*w) * P_i  (w = 0 is the input itself)
   // Second table with wider windows for large batches (see msm.hip, "two-level sort"): fewer, larger digits mean
-  // fewer mixed additions per scalar; only worth it when the batch alone fills the chip.  Null when not built.
+  // fewer mixed additions per scalar; only worth it when the batch alone fills the chip.  Null when not built
+  // (fewer than 4096 points, or c itself is already the wide window: tables of more than 2^18 points).
   uint32_t c2 = 0, windows2 = 0;
   g1_affine* ext2 = nullptr;
 };

@@ -233,6 +233,36 @@ def test_msm_wide_window_path_vs_single_path(cg, tau, n, batch, offset):
     cg.srs_free(h)
 
 
+@pytest.mark.parametrize("n,batch", [(9, 1), (2000, 1), (4096, 40)])
+def test_msm_special_cases_inside_one_bucket(cg, n, batch):
+    """The accumulation loop takes every special case - accumulator at infinity (first entry, or after P + (-P)), a base
+    at infinity, P + P - through one test on the x-difference.  Here nine bases P, -P, Q, Q, -Q, R, infinity, P, -P carry
+    the same small scalar d, so all of them meet in ONE bucket of window 0 (in whatever order the tile sort leaves them):
+    the result must be d (Q + R).  Run on the one-level path (c = 9 / 13) and, padded with zero scalars to 4096 points
+    in a batch of 40, on the two-level path (c = 15)."""
+    P_, Q_, R_ = (bn.g1_mul(bn.G1_GEN, k) for k in (1234567, 7654321, 1357911))
+    pts = [P_, bn.g1_neg(P_), Q_, Q_, bn.g1_neg(Q_), R_, None, P_, bn.g1_neg(P_)]
+    filler = bn.g1_mul(bn.G1_GEN, 99)
+    bases = cr.points_to_array(pts + [filler] * (n - len(pts)))
+    h = cg.srs_upload(bases)
+    for d in (1, 5, (1 << 12) + 1):
+        sc = np.zeros((n, 4), np.uint64)
+        sc[:len(pts), 0] = d
+        want = bn.g1_mul(bn.g1_add(Q_, R_), d)
+        if batch == 1:
+            got = [cg.msm_g1(h, sc)]
+        else:
+            got = cg.msm_g1_batch(h, [sc] * batch)
+        for g in (got[0], got[-1]):
+            assert cr.affine_to_ints(cr.g1_to_affine(g)) == want, d
+    # everything cancels: the accumulator ends at infinity
+    sc = np.zeros((n, 4), np.uint64)
+    sc[[0, 1, 7, 8], 0] = 3
+    out = cg.msm_g1(h, sc) if batch == 1 else cg.msm_g1_batch(h, [sc] * batch)[0]
+    assert cr.affine_to_ints(cr.g1_to_affine(out)) is None
+    cg.srs_free(h)
+
+
 def test_msm_affine_seq_bases(cg):
     """BASELINE config 5's synthetic bases P_i = [a + i b]G: sum k_i P_i = [sum k_i (a + i b)] G."""
     a, b, n = 12345678901234567890, 987654321987654321, 5000
