@@ -147,6 +147,33 @@ struct G1LT {
     o.zzz = F::mul(a.zzz, ppp);
     return o;
   }
+  // The mixed addition of the bucket-accumulation loop (msm_accumulate): acc += q (or -q), common case only.
+  // Returns false - acc untouched - when the x-difference vanishes, which is how EVERY special case shows up: the
+  // accumulator at infinity (zz = 0 and x = 0 make both sides 0), acc == q (doubling), acc == -q (cancellation); the
+  // caller then takes the general add_mixed.  q must not be the point at infinity (the caller tests that).
+  // Compared with add_mixed the carries are propagated only where the next operation needs them:
+  //   * -q.y is 16p - y with un-carried limbs (< 2^31): it is one operand of one multiplication;
+  //   * r^2 - ppp - 2qq is carried once, not twice;  qq - x3 (+ 2p, limbs < 1.5 * 2^30) feeds the fused product directly;
+  //   * y3 stays a product sum (< 1.5 p) without the weak reduction.
+  // Invariants of acc here: x < 2p, y < 3p, zz, zzz < 1.2p, all with normalized limbs.
+  static CAP_HD bool madd_acc(g1x& a, const g1a& q, bool negate) {
+    const fl qy = negate ? F::neg_lazy(q.y) : q.y;
+    const fl u2 = F::mul(q.x, a.zz);
+    const fl s2 = F::mul(qy, a.zzz);
+    const fl p = F::sub(u2, a.x);
+    if (F::is_zero(p)) return false;
+    const fl r = F::sub(s2, a.y);
+    const fl pp = F::sqr(p);
+    const fl ppp = F::mul(p, pp);
+    const fl qq = F::mul(a.x, pp);
+    g1x o;
+    o.x = F::weak_reduce(F::sub_from_lazy(F::sub2p_lazy(F::sqr(r), ppp), F::add(qq, qq)));
+    o.y = F::mul_add_mul(r, F::sub2p_lazy(qq, o.x), F::neg(a.y), ppp);  // one reduction for both products
+    o.zz = F::mul(a.zz, pp);
+    o.zzz = F::mul(a.zzz, ppp);
+    a = o;
+    return true;
+  }
   static CAP_HD g1x add(const g1x& a, const g1x& b) {
     if (is_inf(a)) return b;
     if (is_inf(b)) return a;

@@ -69,10 +69,19 @@ struct FrP29 {
 #define CAP_FL_ASSERT(x) ((void)0)
 #endif
 
+// Host builds of this header also run under clang's unsigned-integer-overflow sanitizer (tests/test_field29_host.py):
+// every 64-bit column sum and every 32-bit limb sum is then checked for wrap-around on the tested inputs.  The few
+// places that wrap on purpose carry this attribute.
+#if defined(__clang__) && !defined(__HIP_DEVICE_COMPILE__)
+#define CAP_WRAPS __attribute__((no_sanitize("unsigned-integer-overflow")))
+#else
+#define CAP_WRAPS
+#endif
+
 // Low 32 bits of a 32 x 32 product.  On gfx950 v_mul_lo_u32 issues at a quarter of the rate of v_mad_u64_u32
 // (tools/ubench_mlo.hip: 145 -> 158 G Montgomery multiplications/s when the nine digit multiplications of a
 // reduction go through the 64-bit multiply-add instead), so the device build asks for the latter explicitly.
-static CAP_HD uint32_t mul_lo32(uint32_t a, uint32_t b) {
+CAP_WRAPS static CAP_HD uint32_t mul_lo32(uint32_t a, uint32_t b) {
 #if defined(__HIP_DEVICE_COMPILE__) && !defined(CAP_NO_MADLO)
   uint64_t r, carry;
   asm("v_mad_u64_u32 %0, %1, %2, %3, 0" : "=v"(r), "=s"(carry) : "v"(a), "v"(b));
@@ -198,6 +207,27 @@ struct Fl {
     return normalize(r);
   }
 
+  // 16p - b WITHOUT carrying, for a normalized b < 15.9 p: limbs in (2^29, 2^31).  Only as ONE operand of a
+  // multiplication whose other operand is normalized (81 products of < 2^60 and the reduction stay below 2^64).
+  static CAP_HD fl neg_lazy(const fl& b) {
+    fl r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      CAP_FL_ASSERT(i == 8 ? b.v[i] <= PR::SUB16P[i] : b.v[i] < (1u << 29));
+      r.v[i] = PR::SUB16P[i] - b.v[i];
+    }
+    return r;
+  }
+  // a - b + 16p, normalized, for a LAZY a (limbs < 2^31, e.g. the result of sub2p_lazy) and limbs(b) < 2^30
+  static CAP_HD fl sub_from_lazy(const fl& a, const fl& b) {
+    fl r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      CAP_FL_ASSERT(i == 8 ? b.v[i] <= PR::SUB16P[i] : (b.v[i] < (1u << 30) && a.v[i] < (1u << 31)));
+      r.v[i] = a.v[i] + (PR::SUB16P[i] - b.v[i]);  // < 2^31 + 2^31
+    }
+    return normalize(r);
+  }
   // a - b + 2p WITHOUT carrying: limbs(a) + 2^30 at most.  For a value that is only ever added to / subtracted from
   // before its next normalisation (the "u" side of the following butterfly), never a multiplicand.
   static CAP_HD fl sub2p_lazy(const fl& a, const fl& b) {
@@ -245,7 +275,7 @@ struct Fl {
     return r;
   }
   // x == 0 (mod p)?  x normalized.  Fast path: one multiplication by p^-1 mod 2^29 decides almost always.
-  static CAP_HD bool is_zero(const fl& x) {
+  CAP_WRAPS static CAP_HD bool is_zero(const fl& x) {
     // x = k p  =>  k = x_0 * p^-1 mod 2^29 ; a multiple of p below 2^261 has k < 169
     uint32_t k = mul_lo32(x.v[0], 0u - PR::NINV) & M29;  // p^-1 = -NINV mod 2^29
     if (k >= 256) return false;

@@ -622,10 +622,6 @@ __global__ __launch_bounds__(1024) void msm_sort_items(const uint32_t* __restric
   }
 }
 
-// the general mixed addition, in its own branch: reached once per work item (its first entry) and on the rare special
-// cases.  (Inlined: as a real call it forced the accumulator through scratch memory.)
-__device__ __forceinline__ g1x add_mixed_rare(const g1x& a, const g1a& q, bool negate) { return G1L::add_mixed(a, q, negate); }
-
 // ---- K5: bucket accumulation --------------------------------------------------------------------
 // One thread per work item (a slice of one bucket's list).  The slices of a bucket are of (almost) equal length
 // and the items of a wavefront come from a length-sorted list (msm_sort_items), so every lane of a wavefront runs
@@ -653,38 +649,17 @@ __global__ __launch_bounds__(kThreads) void msm_accumulate(const g1_affine* __re
   const uint32_t q = cnt / items, r = cnt - q * items;
   const uint32_t lo = j * q + (j < r ? j : r), hi = lo + q + (j < r ? 1u : 0u);
   const uint32_t* lst = sorted + (size_t)b * per + offsets[gb];
-  using F = G1L::F;
   g1x acc = G1L::inf();
-  // Common path kept lean: the loop body is the XYZZ mixed addition and ONE test.  Everything else - the accumulator
-  // still at infinity (first entry of the item, or after P + (-P)), a table point at infinity, P + P - makes the
-  // x-difference p vanish (zz = 0 => u2 = 0 = acc.x) or is caught by the OR over the table point, and goes to the
-  // general G1L::add_mixed in a branch of its own, so that its selects and copies never sit in the hot block
-  // (2334 instead of 2650 instructions per addition on the common path).
+  // Common path kept lean: the loop body is G1L::madd_acc - the XYZZ mixed addition with ONE test.  Everything else -
+  // the accumulator still at infinity (first entry of the item, or after P + (-P)), P + P - makes the x-difference
+  // vanish, a table point at infinity is caught by the OR over its limbs, and both go to the general G1L::add_mixed
+  // in a branch of its own, so that its selects and copies never sit in the hot block (2650 -> 2260 instructions per
+  // addition on the common path).
   for (uint32_t e = lo; e < hi; e++) {
     const uint32_t v = lst[e];
-    const g1a q0 = G1L::load(ext[v & 0x7FFFFFFFu]);
+    const g1a q = G1L::load(ext[v & 0x7FFFFFFFu]);
     const bool negate = (v >> 31) != 0;
-    g1a q = q0;
-    if (negate) q.y = F::neg(q.y);
-    const fl u2 = F::mul(q.x, acc.zz);
-    const fl s2 = F::mul(q.y, acc.zzz);
-    const fl p = F::sub(u2, acc.x);
-    const fl r = F::sub(s2, acc.y);
-    if (__builtin_expect(F::is_zero(p) || G1L::is_inf(q0), 0)) {
-      acc = add_mixed_rare(acc, q0, negate);
-      continue;
-    }
-    const fl pp = F::sqr(p);
-    const fl ppp = F::mul(p, pp);
-    const fl qq = F::mul(acc.x, pp);
-    g1x o;
-    o.x = F::weak_reduce(F::sub(F::sub(F::sqr(r), ppp), F::add(qq, qq)));
-    // one reduction for both products.  y is a product sum, < p (1 + (17.1^2 + 16 * 1.1) / 169) = 2.83 p: small enough
-    // for every later use (subtrahend < 15.9 p, 32-byte image < 2^256) without the weak reduction G1L::add_mixed applies
-    o.y = F::mul_add_mul(r, F::sub(qq, o.x), F::neg(acc.y), ppp);
-    o.zz = F::mul(acc.zz, pp);
-    o.zzz = F::mul(acc.zzz, ppp);
-    acc = o;
+    if (__builtin_expect(G1L::is_inf(q) || !G1L::madd_acc(acc, q, negate), 0)) acc = G1L::add_mixed(acc, q, negate);
   }
   // a bucket made of a single item is final: it goes straight to the bucket array and msm_combine skips it
   if (items == 1) buckets[gb] = G1L::store(acc);

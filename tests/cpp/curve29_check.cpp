@@ -22,7 +22,7 @@ int main(){
   g1_affine g; g.x = Fq::one(); g.y = Fq::dbl(Fq::one());
   g1_xyzz acc = G1::from_affine(g);
   unsigned long long s = 12345;
-  for (int i=0;i<N;i++){ pts[i]=G1::to_affine(acc); int reps = 1 + (s>>60); s = s*6364136223846793005ULL+1442695040888963407ULL; for(int k=0;k<reps;k++) acc = G1::add_mixed(acc, g); acc = G1::dbl(acc); }
+  for (int i=0;i<N;i++){ pts[i]=G1::to_affine(acc); int reps = 1 + (int)(s % 15); s = (s * 1103515245ULL + 12345ULL) % 2147483648ULL; for(int k=0;k<reps;k++) acc = G1::add_mixed(acc, g); acc = G1::dbl(acc); }
   pts[17] = pts[16];                 // duplicate
   memset(&pts[33], 0, sizeof(g1_affine)); // infinity
   int bad=0;

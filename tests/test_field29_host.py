@@ -84,6 +84,45 @@ def test_field29_against_python_integers(binaries):
             assert v % m == e and v < (1 << 261), line
 
 
+CLANG = "/opt/rocm/lib/llvm/bin/clang++"
+
+
+@pytest.fixture(scope="module")
+def sanitized(tmp_path_factory):
+    """The same host checks built with clang's unsigned-integer-overflow sanitizer: every 64-bit column sum and 32-bit
+    limb sum of field29.hpp / curve29.hpp traps on wrap-around (the saturated reference headers, which wrap by design,
+    are on the ignore list; the few intentional wraps of field29.hpp carry CAP_WRAPS)."""
+    if not os.path.exists(CLANG):
+        pytest.skip("no clang++ for the sanitizer build")
+    out = tmp_path_factory.mktemp("f29san")
+    ign = out / "ignore.txt"
+    ign.write_text("src:*/field.hpp\nsrc:*/curve.hpp\n")
+    bins = {}
+    for name in ("curve29_check", "madd_check"):
+        exe = str(out / name)
+        subprocess.check_call([CLANG, "-O1", "-std=c++17", "-fsanitize=unsigned-integer-overflow",
+                               f"-fsanitize-ignorelist={ign}", "-fno-sanitize-recover=all",
+                               os.path.join(CPP, name + ".cpp"), "-o", exe])
+        bins[name] = exe
+    return bins
+
+
+def test_accumulation_loop_addition(tmp_path):
+    """G1L::madd_acc (the loop body of msm_accumulate, with its un-carried operands) against the saturated curve code:
+    long signed chains through doubling, cancellation, infinity and the 32-byte memory image, both multiplication
+    schedules, bound assertions on."""
+    exe = str(tmp_path / "madd_check")
+    subprocess.check_call([_cxx(), "-O1", "-std=c++17", os.path.join(CPP, "madd_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "bad=0" in out.stdout, out.stdout[-500:] + out.stderr[-500:]
+
+
+def test_no_integer_wraps_under_the_sanitizer(sanitized):
+    for name, exe in sanitized.items():
+        out = subprocess.run([exe], capture_output=True, text=True)
+        assert out.returncode == 0 and "bad=0" in out.stdout, name + ": " + out.stdout[-300:] + out.stderr[-800:]
+
+
 def test_curve29_against_saturated_curve_code(binaries):
     out = subprocess.run([binaries["curve29_check"]], capture_output=True, text=True)
     assert out.returncode == 0 and "bad=0" in out.stdout, out.stdout[-500:] + out.stderr[-500:]
