@@ -154,7 +154,7 @@ struct G1LT {
   // Compared with add_mixed the carries are propagated only where the next operation needs them:
   //   * -q.y is 16p - y with un-carried limbs (< 2^31): it is one operand of one multiplication;
   //   * r^2 - ppp - 2qq is carried once, not twice;  qq - x3 (+ 2p, limbs < 1.5 * 2^30) feeds the fused product directly;
-  //   * y3 stays a product sum (< 1.5 p) without the weak reduction.
+  //   * -acc.y is 4p - y with un-carried limbs (< 2^30);  y3 stays a product sum (< 1.5 p) without the weak reduction.
   // Invariants of acc here: x < 2p, y < 3p, zz, zzz < 1.2p, all with normalized limbs.
   static CAP_HD bool madd_acc(g1x& a, const g1a& q, bool negate) {
     const fl qy = negate ? F::neg_lazy(q.y) : q.y;
@@ -168,7 +168,9 @@ struct G1LT {
     const fl qq = F::mul(a.x, pp);
     g1x o;
     o.x = F::weak_reduce(F::sub_from_lazy(F::sub2p_lazy(F::sqr(r), ppp), F::add(qq, qq)));
-    o.y = F::mul_add_mul(r, F::sub2p_lazy(qq, o.x), F::neg(a.y), ppp);  // one reduction for both products
+    // one reduction for both products; both second operands un-carried: 9 x (2^29 * 1.5 * 2^30 + 2^30 * 2^29) plus the
+    // reduction terms stays below 2^64 per column
+    o.y = F::mul_add_mul(r, F::sub2p_lazy(qq, o.x), F::neg4p_lazy(a.y), ppp);
     o.zz = F::mul(a.zz, pp);
     o.zzz = F::mul(a.zzz, ppp);
     a = o;

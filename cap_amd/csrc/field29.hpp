@@ -42,6 +42,9 @@ struct FqP29 {
   // 2p with limbs 0..7 inflated into [2^29, 2^30)
   static constexpr uint32_t SUB2P[9] = {0x30f9fa8eu, 0x2208c16cu, 0x38e5469du, 0x25aa45a0u, 0x2b0bb2efu,
                                         0x25b68180u, 0x214dc281u, 0x3cb84c67u, 0x0060c89bu};
+  // 4p, same inflation
+  static constexpr uint32_t SUB4P[9] = {0x21f3f51cu, 0x241182dau, 0x31ca8d3bu, 0x2b548b42u, 0x361765dfu,
+                                        0x2b6d0301u, 0x229b8503u, 0x397098cfu, 0x00c19138u};
 };
 struct FrP29 {
   using Base = FrP;
@@ -60,6 +63,8 @@ struct FrP29 {
   static constexpr uint32_t K266[9] = {0x0fffead7u, 0x1d5444f4u, 0x04438aa5u, 0x03b4d096u, 0x134c84dau, 0x0e92d304u, 0x14cb95b3u, 0x041b9d3du, 0x00058003u};
   static constexpr uint32_t SUB2P[9] = {0x20000002u, 0x3e1f593eu, 0x3cb848a0u, 0x2fa121e5u, 0x2b0ba505u,
                                         0x25b68180u, 0x214dc281u, 0x3cb84c67u, 0x0060c89bu};
+  static constexpr uint32_t SUB4P[9] = {0x20000004u, 0x3c3eb27du, 0x39709142u, 0x3f4243ccu, 0x36174a0bu,
+                                        0x2b6d0301u, 0x229b8503u, 0x397098cfu, 0x00c19138u};
 };
 
 #ifdef CAP_FL_CHECK
@@ -215,6 +220,16 @@ struct Fl {
     for (int i = 0; i < 9; i++) {
       CAP_FL_ASSERT(i == 8 ? b.v[i] <= PR::SUB16P[i] : b.v[i] < (1u << 29));
       r.v[i] = PR::SUB16P[i] - b.v[i];
+    }
+    return r;
+  }
+  // 4p - b WITHOUT carrying, for a normalized b < 3.9 p: limbs < 2^30 (a lazy operand like a sum of two)
+  static CAP_HD fl neg4p_lazy(const fl& b) {
+    fl r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      CAP_FL_ASSERT(i == 8 ? b.v[i] <= PR::SUB4P[i] : b.v[i] < (1u << 29));
+      r.v[i] = PR::SUB4P[i] - b.v[i];
     }
     return r;
   }

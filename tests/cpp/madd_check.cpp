@@ -47,7 +47,7 @@ static int directed_bounds() {
   r = F::sqr(lazy30); sink += r.v[0];
   r = F::mul(lazy31, norm_max); sink += r.v[0];                // neg_lazy(q.y) * zzz
   r = F::mul(norm_max, lazy31); sink += r.v[0];
-  r = F::mul_add_mul(norm_max, lazy15, norm_max, norm_max); sink += r.v[0];   // r * (qq - x3 + 2p) + (-y) * ppp
+  r = F::mul_add_mul(norm_max, lazy15, lazy30, norm_max); sink += r.v[0];     // r * (qq - x3 + 2p) + (4p - y) * ppp
   r = F::mul_add_mul(norm_max, norm_max, norm_max, norm_max); sink += r.v[0];
   fl t = F::sub2p_lazy(norm_max, F::weak_reduce(norm_max));
   r = F::sub_from_lazy(t, lazy30); sink += r.v[0];             // (r^2 - ppp + 2p) - 2qq + 16p
