@@ -988,6 +988,10 @@ uint32_t batch_slice(const Plan& pl, uint32_t batch) {
   const size_t per_msm_entries = (size_t)pl.windows * pl.n_sub * pl.parts + ((size_t)1 << (pl.c - 1)) * pl.parts;
   size_t lim = std::min<size_t>(((size_t)1 << 28) / per_msm_rows, ((size_t)3 << 30) / per_msm_entries);
   lim = std::min<size_t>(lim, 65535 / pl.parts);  // grid y of msm_sort_level2
+  if (const char* e = getenv("CAPGPU_MSM_SLICE")) {  // test hook: force slicing at small sizes
+    const int x = atoi(e);
+    if (x >= 1) lim = std::min<size_t>(lim, (size_t)x);
+  }
   return (uint32_t)std::max<size_t>(1, std::min<size_t>(lim, batch));
 }
 

@@ -263,6 +263,39 @@ def test_msm_special_cases_inside_one_bucket(cg, n, batch):
     cg.srs_free(h)
 
 
+def test_msm_batch_run_in_slices(cg, tau, monkeypatch):
+    """Batches whose sort tables would outgrow 32-bit counters are run in slices of the batch (msm.hip: batch_slice);
+    at test sizes the slicing is forced through CAPGPU_MSM_SLICE.  Results must not depend on it - for plain batches
+    and for the prover's grouped addressing (5 polynomials per proof inside one array: slices start on a group
+    boundary), checked through whole proofs."""
+    n, batch = 4500, 37
+    h = cg.srs_generate(tau, n)
+    scs = [cr.random_field(3000 + b, 1, n, False) for b in range(batch)]
+    want = [cr.g1_to_affine(p) for p in cg.msm_g1_batch(h, scs)]
+    for limit in ("16", "7", "1"):
+        monkeypatch.setenv("CAPGPU_MSM_SLICE", limit)
+        assert cg.msm_plan(h, n, batch)["slice"] == int(limit)
+        got = [cr.g1_to_affine(p) for p in cg.msm_g1_batch(h, scs)]     # (the Jacobian triple depends on the reduction used)
+        assert all(np.array_equal(a, b) for a, b in zip(got, want)), limit
+    cg.srs_free(h)
+    # grouped addressing: a batch of 9 proofs at n = 2^12 (45-wide launches of 5 per proof) sliced to 12 -> 10 + 10 + ...
+    from cap_amd import bench_utils as bu
+    sc = bu.synthetic_circuit(12, 3, seed=31)
+    hs = cg.srs_generate(tau, sc.n + 3)
+    monkeypatch.delenv("CAPGPU_MSM_SLICE")
+    pk, _ = cg.plonk_preprocess(hs, sc.n, 3, sc.selectors_mont(), sc.sigma_mont())
+    ws, ps, bls = [], [], []
+    for p in range(9):
+        w, pubs = sc.witness(700 + p)
+        ws.append(sc.wires_mont(w)); ps.append(bu.to_mont_array(pubs)); bls.append(bu.to_mont_array(bu.blinders(800 + p)))
+    plain = cg.plonk_prove_batch(pk, np.stack(ws), np.stack(ps), np.stack(bls), b"s", 9)
+    monkeypatch.setenv("CAPGPU_MSM_SLICE", "12")
+    sliced = cg.plonk_prove_batch(pk, np.stack(ws), np.stack(ps), np.stack(bls), b"s", 9)
+    assert [bytes(cg.proof_serialize(a)) for a in plain] == [bytes(cg.proof_serialize(b)) for b in sliced]
+    cg.plonk_free_key(pk)
+    cg.srs_free(hs)
+
+
 def test_msm_affine_seq_bases(cg):
     """BASELINE config 5's synthetic bases P_i = [a + i b]G: sum k_i P_i = [sum k_i (a + i b)] G."""
     a, b, n = 12345678901234567890, 987654321987654321, 5000
