@@ -14,6 +14,9 @@
 // batched the same way); with 288 GB of HBM the proving key also keeps the coset
 // evaluations of its 18 fixed polynomials resident (set CAPGPU_RECOMPUTE_PK_COSET=1 to
 // re-transform them for every proof exactly as the reference schedule does).
+// k_quotient is one long chain of products per coset point: column-wise multiplication schedule (field29.hpp), measured
+// 16.75 -> 16.04 ms per step
+#define CAP_FL_SCHED 1
 #include <stdlib.h>
 #include <string.h>
 
