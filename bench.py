@@ -32,8 +32,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0   # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 MADS_PER_MUL = 171       # lazy 9 x 29-bit Montgomery multiplication: 81 product + 81 reduction + 9 digit multiply-adds
 # VALU wave-instructions msm_accumulate executes per mixed addition: SQ_INSTS_VALU of the kernel / (additions / 64),
-# profiles/inst_counters_r02.json (static PMC pass; the loop body's ISA counts 2334, of which 1550 are multiply-adds)
-INSTR_PER_MIXED_ADD = 2302
+# profiles/inst_counters_r02.json (static PMC pass; the loop body's ISA counts 2190, of which 1550 are multiply-adds)
+INSTR_PER_MIXED_ADD = 2160
 TRAFFIC_FILE = "profiles/traffic_r02.json"   # PMC pass (FETCH_SIZE / WRITE_SIZE) of this same command, batch 256
 
 
