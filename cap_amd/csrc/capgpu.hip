@@ -283,6 +283,7 @@ void capgpu_shutdown(void) {
   Context& c = ctx();
   std::lock_guard<std::recursive_mutex> lk(c.mu);
   if (!c.initialised) return;
+  (void)capgpu_comm_destroy();
   hipDeviceSynchronize();
   c.keys.clear();
   for (auto& kv : c.srs) msm_free_bases(&kv.second.bases);

@@ -377,6 +377,66 @@ int capgpu_srs_serialize(uint64_t handle, const uint64_t h[16], const uint64_t b
   return CAPGPU_OK;
 }
 
+// ---- Proof bytes -> capgpu_proof: host only --------------------------------------------------------------------
+// The inverse of capgpu_proof_serialize: what `Proof::deserialize` does when a TransferNote / MintNote / FreezeNote
+// arrives as bytes (src/transfer.rs:54-66).  Every encoding ark-serialize rejects is rejected: wrong vector lengths,
+// x >= p, x not on the curve, both flag bits, scalars >= r, a plookup proof.
+int capgpu_proof_deserialize(const uint8_t* bytes, size_t len, capgpu_proof* proof_out, size_t* consumed_out) {
+  if (!bytes || !proof_out) {
+    set_error("capgpu_proof_deserialize: bad argument");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  Reader rd(bytes, len);
+  auto fail = [&](const char* why) {
+    set_error("capgpu_proof_deserialize: %s (byte %zu of %zu)", why, rd.pos, len);
+    return CAPGPU_ERR_SERIALIZATION;
+  };
+  memset(proof_out, 0, sizeof(*proof_out));
+  auto g1 = [&](uint64_t out[8]) {
+    const uint8_t* b = rd.take(32);
+    g1_affine p;
+    if (!b || !g1_decompress_host(b, &p)) return false;
+    affine_to_words(p, out);
+    return true;
+  };
+  auto fr = [&](uint64_t out[4]) {
+    const uint8_t* b = rd.take(32);
+    if (!b) return false;
+    fe v;
+    memcpy(v.v, b, 32);
+    if (cmp_words(v, fr_modulus()) >= 0) return false;
+    fe_to_words(Fr::to_mont(v), out);
+    return true;
+  };
+  uint64_t cnt = 0;
+  if (!rd.count(32, &cnt)) return fail("unexpected end of input");
+  if (cnt != kNumWires) return fail("wires_poly_comms: a TurboPlonk proof has 5 of them");
+  for (int i = 0; i < kNumWires; i++)
+    if (!g1(proof_out->wires_poly_comms[i])) return fail("wires_poly_comms: invalid compressed G1 point");
+  if (!g1(proof_out->prod_perm_poly_comm)) return fail("prod_perm_poly_comm: invalid compressed G1 point");
+  if (!rd.count(32, &cnt)) return fail("unexpected end of input");
+  if (cnt != kNumWires) return fail("split_quot_poly_comms: a TurboPlonk proof has 5 of them");
+  for (int i = 0; i < kNumWires; i++)
+    if (!g1(proof_out->split_quot_poly_comms[i])) return fail("split_quot_poly_comms: invalid compressed G1 point");
+  if (!g1(proof_out->opening_proof)) return fail("opening_proof: invalid compressed G1 point");
+  if (!g1(proof_out->shifted_opening_proof)) return fail("shifted_opening_proof: invalid compressed G1 point");
+  if (!rd.count(32, &cnt)) return fail("unexpected end of input");
+  if (cnt != kNumWires) return fail("wires_evals: 5 expected");
+  for (int i = 0; i < kNumWires; i++)
+    if (!fr(proof_out->wires_evals[i])) return fail("wires_evals: scalar missing or not canonical");
+  if (!rd.count(32, &cnt)) return fail("unexpected end of input");
+  if (cnt != kNumWires - 1) return fail("wire_sigma_evals: 4 expected");
+  for (int i = 0; i < kNumWires - 1; i++)
+    if (!fr(proof_out->wire_sigma_evals[i])) return fail("wire_sigma_evals: scalar missing or not canonical");
+  if (!fr(proof_out->perm_next_eval)) return fail("perm_next_eval: scalar missing or not canonical");
+  const uint8_t* tag = rd.take(1);
+  if (!tag) return fail("unexpected end of input");
+  if (*tag > 1) return fail("invalid Option tag");
+  if (*tag) return fail("plookup proofs are not supported");
+  if (consumed_out) *consumed_out = rd.pos;
+  return CAPGPU_OK;
+}
+
 // ---- VerifyingKey blob: host only ---------------------------------------------------------------------------
 int capgpu_plonk_vk_serialize(const capgpu_verifying_key* vk, const uint64_t g[8], const uint64_t gamma_g[8],
                               const uint64_t h[16], const uint64_t beta_h[16], uint8_t* out, size_t cap,

@@ -16,7 +16,7 @@ NUM_SELECTORS = 13
 CAPGPU_OK = 0
 ERR_NAMES = {
     -1: "CAPGPU_ERR_INVALID_ARG", -2: "CAPGPU_ERR_NO_DEVICE", -3: "CAPGPU_ERR_HIP", -4: "CAPGPU_ERR_BAD_HANDLE",
-    -5: "CAPGPU_ERR_OOM", -6: "CAPGPU_ERR_NOT_INITIALISED", -7: "CAPGPU_ERR_PROOF",
+    -5: "CAPGPU_ERR_OOM", -6: "CAPGPU_ERR_NOT_INITIALISED", -7: "CAPGPU_ERR_PROOF", -8: "CAPGPU_ERR_SERIALIZATION",
 }
 
 u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -464,6 +464,14 @@ def proof_serialize(proof: Proof) -> bytes:
     n = ctypes.c_size_t(0)
     check(load().capgpu_proof_serialize(ctypes.byref(proof), buf, ctypes.c_size_t(1024), ctypes.byref(n)))
     return bytes(buf[:n.value])
+
+
+def proof_deserialize(data: bytes):
+    """-> (Proof, bytes consumed); raises CapGpuError(CAPGPU_ERR_SERIALIZATION) on a malformed encoding."""
+    pr, used = Proof(), ctypes.c_size_t(0)
+    buf = (ctypes.c_uint8 * max(len(data), 1)).from_buffer_copy(data if data else b"\0")
+    check(load().capgpu_proof_deserialize(buf, ctypes.c_size_t(len(data)), ctypes.byref(pr), ctypes.byref(used)))
+    return pr, used.value
 
 
 # ---- on-disk parameter formats (include/capgpu.h, SURVEY 8f row 3) ----------------------------------------

@@ -234,6 +234,10 @@ int capgpu_plonk_batch_verify(const capgpu_verifying_key* const* vks, const uint
  * (src/transfer.rs:60): compressed G1 (32 B), Fr little-endian, Vec = u64 length prefix, plookup_proof = None.
  * 769 bytes; *len_out receives the size. */
 int capgpu_proof_serialize(const capgpu_proof* proof, uint8_t* out, size_t cap, size_t* len_out);
+/* The inverse (`Proof::deserialize`, what reading a note from bytes does): CAPGPU_ERR_SERIALIZATION on every encoding
+ * ark-serialize rejects (vector lengths, non-canonical x or scalar, x off the curve, both flag bits, a plookup
+ * proof).  Host only.  *consumed_out receives the bytes read. */
+int capgpu_proof_deserialize(const uint8_t* bytes, size_t len, capgpu_proof* proof_out, size_t* consumed_out);
 
 /* ---- on-disk parameter formats ------------------------------------------------------
  * The reference stores and loads its parameters as ark-serialize 0.3 `CanonicalSerialize` bytes

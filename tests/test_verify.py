@@ -247,3 +247,19 @@ def test_batch_verify_and_proof_serialization(tau):
     exp += bn.fr_to_bytes_le(op.perm_next_eval) + b"\x00"
     got = cg.proof_serialize(proofs[0])
     assert got == exp and len(got) == 769
+    # and back (what reading a note from bytes does): same words, trailing bytes untouched, malformed encodings refused
+    back, used = cg.proof_deserialize(got + b"trailer")
+    assert used == 769 and bytes(back) == bytes(proofs[0])
+    assert cg.plonk_verify(vks[0], h2, bh, pubs_l[0], back, msgs[0])
+    bad_cases = {
+        "short": got[:700],
+        "wrong vector length": (4).to_bytes(8, "little") + got[8:],
+        "scalar not canonical": got[:8 + 32 * 13 + 8 + 8] + bn.R.to_bytes(32, "little") + got[8 + 32 * 13 + 8 + 8 + 32:],
+        "x off the curve": got[:8] + (4).to_bytes(32, "little") + got[40:],
+        "both flags": got[:8 + 31] + bytes([got[8 + 31] | 0xC0]) + got[8 + 32:],
+        "plookup proof": got[:-1] + b"\x01",
+    }
+    for name, blob in bad_cases.items():
+        with pytest.raises(cg.CapGpuError) as e:
+            cg.proof_deserialize(blob)
+        assert e.value.code == cg.CAPGPU_ERR_SERIALIZATION, name
