@@ -176,6 +176,29 @@ struct G1LT {
     a = o;
     return true;
   }
+  // a += b for two XYZZ points, common case only - the running sums of the bucket reduction (msm_reduce_segments).
+  // Returns false - a untouched - when the x-difference vanishes: either side at infinity (zz = 0 and x = 0 make both
+  // cross products 0), a == b, a == -b; the caller falls back to add().  Carries as in madd_acc.
+  // Invariants in and out: x < 2p, y < 3p, zz, zzz < 1.2p, normalized limbs.
+  static CAP_HD bool add_acc(g1x& a, const g1x& b) {
+    const fl u1 = F::mul(a.x, b.zz);
+    const fl u2 = F::mul(b.x, a.zz);
+    const fl p = F::sub(u2, u1);
+    if (F::is_zero(p)) return false;
+    const fl s1 = F::mul(a.y, b.zzz);
+    const fl s2 = F::mul(b.y, a.zzz);
+    const fl r = F::sub(s2, s1);
+    const fl pp = F::sqr(p);
+    const fl ppp = F::mul(p, pp);
+    const fl qq = F::mul(u1, pp);
+    g1x o;
+    o.x = F::weak_reduce(F::sub_from_lazy(F::sub2p_lazy(F::sqr(r), ppp), F::add(qq, qq)));
+    o.y = F::mul_add_mul(r, F::sub2p_lazy(qq, o.x), F::neg2p_lazy(s1), ppp);
+    o.zz = F::mul(F::mul(a.zz, b.zz), pp);
+    o.zzz = F::mul(F::mul(a.zzz, b.zzz), ppp);
+    a = o;
+    return true;
+  }
   static CAP_HD g1x add(const g1x& a, const g1x& b) {
     if (is_inf(a)) return b;
     if (is_inf(b)) return a;

@@ -223,6 +223,16 @@ struct Fl {
     }
     return r;
   }
+  // 2p - b WITHOUT carrying, for a normalized b < 1.9 p (a product): limbs < 2^30
+  static CAP_HD fl neg2p_lazy(const fl& b) {
+    fl r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      CAP_FL_ASSERT(i == 8 ? b.v[i] <= PR::SUB2P[i] : b.v[i] < (1u << 29));
+      r.v[i] = PR::SUB2P[i] - b.v[i];
+    }
+    return r;
+  }
   // 4p - b WITHOUT carrying, for a normalized b < 3.9 p: limbs < 2^30 (a lazy operand like a sum of two)
   static CAP_HD fl neg4p_lazy(const fl& b) {
     fl r;

@@ -680,13 +680,30 @@ __global__ __launch_bounds__(kThreads) void msm_reduce_segments(const g1_xyzz* _
   uint32_t j_hi = j_lo + seg_len;
   if (j_hi > half) j_hi = half;
   const g1_xyzz* bk = buckets + (size_t)b * half;
-  g1x S = G1L::inf(), T = G1L::inf();
-  g1_xyzz cur = bk[j_hi - 1];
-  for (uint32_t j = j_hi; j-- > j_lo;) {
-    const g1_xyzz nxt = bk[j > j_lo ? j - 1 : j];  // in flight while the two additions below run
-    S = G1L::add(S, G1L::load(cur));
-    T = G1L::add(T, S);
+  // The walk from infinity starts with S = T = the top bucket.  Then the fast loop: both additions in their lean form
+  // (G1L::add_acc: one test, no special cases in the hot block).  A lane whose addition hits a special case - an empty
+  // bucket, a running sum at infinity, equal or opposite points - leaves the fast loop and finishes its segment in the
+  // general loop below; with the prover's 34 entries per bucket that never happens, with a sparse MSM it is the rule.
+  g1x S = G1L::load(bk[j_hi - 1]);
+  g1x T = S;
+  uint32_t j = j_hi - 1;       // buckets j - 1, ..., j_lo are still to be walked
+  bool s_done = false;         // the S-addition of bucket j - 1 was made, its T-addition is pending
+  g1_xyzz cur = bk[j > j_lo ? j - 1 : j];
+  while (j > j_lo) {
+    const g1_xyzz nxt = bk[j - 1 > j_lo ? j - 2 : j - 1];  // in flight while the two additions below run
+    if (!G1L::add_acc(S, G1L::load(cur))) break;
+    if (!G1L::add_acc(T, S)) {
+      s_done = true;
+      break;
+    }
     cur = nxt;
+    j--;
+  }
+  while (j > j_lo) {
+    if (!s_done) S = G1L::add(S, G1L::load(bk[j - 1]));
+    s_done = false;
+    T = G1L::add(T, S);
+    j--;
   }
   seg_pts[2 * (size_t)t] = G1L::store(S);
   seg_pts[2 * (size_t)t + 1] = G1L::store(T);

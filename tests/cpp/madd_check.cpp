@@ -49,6 +49,7 @@ static int directed_bounds() {
   r = F::mul(norm_max, lazy31); sink += r.v[0];
   r = F::mul_add_mul(norm_max, lazy15, lazy30, norm_max); sink += r.v[0];     // r * (qq - x3 + 2p) + (4p - y) * ppp
   r = F::mul_add_mul(norm_max, norm_max, norm_max, norm_max); sink += r.v[0];
+  r = F::mul_add_mul(norm_max, lazy15, lazy30, norm_max); sink += r.v[0];     // ... + (2p - s1) * ppp in add_acc
   fl t = F::sub2p_lazy(norm_max, F::weak_reduce(norm_max));
   r = F::sub_from_lazy(t, lazy30); sink += r.v[0];             // (r^2 - ppp + 2p) - 2qq + 16p
   (void)sink;
@@ -96,6 +97,34 @@ static int chains() {
     }
   }
   if (!same_affine(G1::to_affine(A), G::to_affine(B))) { bad++; printf("final mismatch\n"); }
+  // the running sums of the bucket reduction: S += B_j, T += S through G::add_acc with the general add() as fallback,
+  // over "buckets" that include empty ones, repeated ones (S == B: doubling) and opposite ones
+  {
+    std::vector<g1_xyzz> bk32;
+    std::vector<g1x> bk29;
+    for (int i = 0; i < 60; i++) {
+      g1_xyzz x = G1::inf();
+      g1x y = G::inf();
+      int cnt = (i % 9 == 4) ? 0 : 1 + i % 4;                     // every ninth bucket is empty
+      for (int k = 0; k < cnt; k++) { x = G1::add_mixed(x, pts[(i * 5 + k) % N]); int r0 = 0; loop_add<G>(y, conv(pts[(i * 5 + k) % N]), false, &r0); }
+      bk32.push_back(x);
+      bk29.push_back(G::load(G::store(y)));
+    }
+    bk32[7] = bk32[6]; bk29[7] = bk29[6];                          // S == B at some point is unlikely; equal neighbours at least
+    g1_xyzz S32 = G1::inf(), T32 = G1::inf();
+    g1x S = G::inf(), T = G::inf();
+    int fallbacks = 0;
+    for (int j = 59; j >= 0; j--) {
+      S32 = G1::add(S32, bk32[j]); T32 = G1::add(T32, S32);
+      if (!G::add_acc(S, bk29[j])) { S = G::add(S, bk29[j]); fallbacks++; }
+      if (!G::add_acc(T, S)) { T = G::add(T, S); fallbacks++; }
+      if (!same_affine(G1::to_affine(S32), G::to_affine(S)) || !same_affine(G1::to_affine(T32), G::to_affine(T))) { bad++; if (bad < 5) printf("running sums differ at bucket %d\n", j); }
+    }
+    // S + S and S + (-S) through the fallback
+    g1x D = S; if (G::add_acc(D, S)) { bad++; printf("add_acc did not refuse a doubling\n"); }
+    g1x M = S; M.y = G::F::weak_reduce(G::F::neg(S.y)); D = S; if (G::add_acc(D, M)) { bad++; printf("add_acc did not refuse a cancellation\n"); }
+    if (fallbacks < 2) { bad++; printf("fallbacks %d\n", fallbacks); }
+  }
   if (rare < 8 || rare > 40) { bad++; printf("unexpected number of special cases: %d\n", rare); }
   return bad;
 }
