@@ -74,6 +74,37 @@ def test_msm_plans_of_the_baseline_sizes(cg, tau):
     cg.srs_free(h)
 
 
+def test_msm_random_configurations_known_tau(cg, tau):
+    """Seeded sweep over (points, batch, offset) combinations that land on every plan - narrow one-level, wide two-level,
+    parts, ragged tails - each checked exactly with the known-tau identity  MSM(tau-powers, coeffs f) = [f(tau)] G."""
+    rng = np.random.default_rng(2024)
+    n_srs = 300_000
+    h = cg.srs_generate(tau, n_srs)                      # > 2^18 points: the table holds the wide windows only
+    h_small = cg.srs_generate(tau, 150_000)              # <= 2^18: narrow + wide tables
+    seen = set()
+    for trial in range(14):
+        big = trial % 2 == 0
+        hh, cap = (h, n_srs) if big else (h_small, 150_000)
+        n = int(rng.choice([1, 37, 1023, 1025, 4096, 8191, 8193, 40_000, 65_536, 65_537, 73_729, 131_075, 149_000]))
+        n = min(n, cap)
+        batch = int(rng.choice([1, 2, 31, 33, 70]))
+        if n * batch > 6_000_000:
+            batch = max(1, 6_000_000 // n)
+        offset = int(rng.integers(0, cap - n + 1))
+        plan = cg.msm_plan(hh, n, batch)
+        seen.add((plan["c"], plan["sort"], plan["parts"] > 1))
+        sc = bu.random_canonical_scalars(1000 + trial, n * batch).reshape(batch, n, 4)
+        got = cg.msm_g1_batch(hh, [sc[b] for b in range(batch)], offsets=[offset] * batch)
+        for b in {0, batch - 1}:
+            f_tau = bn.from_mont(cr.poly_eval_fr(cr.vec_to_mont(1, sc[b]), bn.to_mont(tau, bn.R)), bn.R)
+            want = bn.g1_mul(bn.G1_GEN, f_tau * pow(tau, offset, bn.R) % bn.R)
+            assert cr.affine_to_ints(cr.g1_to_affine(got[b])) == want, (trial, n, batch, offset, plan)
+    # the sweep really visited the narrow one-level plan, the wide two-level plan and the split into parts
+    assert {(13, "one-level", False), (15, "two-level", False), (15, "two-level", True)} <= seen, seen
+    cg.srs_free(h)
+    cg.srs_free(h_small)
+
+
 def test_single_msm_2p20_skewed_scalars(cg):
     """All scalars equal: every window sends its 2^20 entries into one bucket (the worst case for the sort and for the
     work-item split) - on the large-MSM path."""
