@@ -415,6 +415,39 @@ def main():
                                  "note": "capgpu_plonk_prove_batch: the 5 wire columns of every proof (5 n x 32 B) are copied "
                                          "from pageable host memory inside the call"}
         del ph
+        # (2b) the reference's calling pattern: many host threads, ONE prove() per note each (rayon par_iter,
+        # src/utils/params_builder.rs:194-226), served by the library's call coalescing
+        import threading
+        T, per_thread = 64, 4
+        cg.plonk_set_coalescing(500, 256)
+        b0, p0 = cg.plonk_coalescing_stats()
+        bar = threading.Barrier(T + 1)
+        errs = []
+
+        def _worker(t):
+            bar.wait()
+            try:
+                for k in range(per_thread):
+                    i = (t * per_thread + k) % wires.shape[0]
+                    cg.plonk_prove(pk, wires[i], pubs[i], blind[i], ext_msg)
+            except Exception as e:                                  # noqa: BLE001
+                errs.append(str(e))
+
+        ths = [threading.Thread(target=_worker, args=(t,)) for t in range(T)]
+        for th in ths:
+            th.start()
+        bar.wait()
+        t0 = time.perf_counter()
+        for th in ths:
+            th.join()
+        dt_c = time.perf_counter() - t0
+        b1, p1 = cg.plonk_coalescing_stats()
+        cg.plonk_set_coalescing(0)
+        out["coalesced_single_calls"] = {"proofs_per_s": T * per_thread / dt_c, "threads": T, "calls_per_thread": per_thread,
+                                         "device_batches": b1 - b0, "proofs": p1 - p0, "errors": errs[:3],
+                                         "note": "capgpu_plonk_prove (one proof per call, host wires) from 64 host threads with "
+                                                 "capgpu_plonk_set_coalescing(500 us, 256): concurrent calls are gathered into "
+                                                 "device batches; without it they would run one by one at batch-1 latency"}
         # (3) the reference's own bench depth: n = 2^16 (TREE_DEPTH = 26, src/bench_utils/mod.rs:42)
         if log_n == 15:
             t0 = time.time()

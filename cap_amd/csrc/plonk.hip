@@ -22,9 +22,12 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <condition_variable>
 #include <functional>
+#include <map>
 #include <mutex>
+#include <string>
 #include <thread>
 #include <vector>
 
@@ -306,8 +309,10 @@ int compute_pk_coset(hipStream_t s, const ProvingKey& K, fe* dst) {
   return run_ntt3_fwd(s, K.log_m, dst, 18, NttIo{K.coef, K.ps, 0, K.n, 1, K.m, 0, 1});
 }
 
+// msgs / msg_lens (optional): one transcript init message per proof; otherwise ext_msg is shared by the batch
 int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pub_inputs, size_t num_inputs,
-                const uint8_t* ext_msg, size_t ext_len, const uint64_t* blinders, capgpu_proof* proofs) {
+                const uint8_t* ext_msg, size_t ext_len, const uint64_t* blinders, capgpu_proof* proofs,
+                const uint8_t* const* msgs = nullptr, const size_t* msg_lens = nullptr) {
   Context& c = ctx();
   hipStream_t s = c.stream;
   const size_t n = K.n, m = K.m, ps = K.ps;
@@ -337,7 +342,11 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
   // ---- transcripts (host) --------------------------------------------------------------------------------
   std::vector<SolidityTranscript> tr(P);
   parallel_for(P, [&](uint32_t p) {
-    if (ext_msg && ext_len) tr[p].append(ext_msg, ext_len);
+    if (msgs) {
+      if (msgs[p] && msg_lens[p]) tr[p].append(msgs[p], msg_lens[p]);
+    } else if (ext_msg && ext_len) {
+      tr[p].append(ext_msg, ext_len);
+    }
     tr[p].append(K.vk_bytes.data(), K.vk_bytes.size());
     for (size_t i = 0; i < num_inputs; i++) append_fr(tr[p], fe_from_words(pub_inputs + 4 * (p * num_inputs + i)));
   });
@@ -687,6 +696,38 @@ void key_set_vk(ProvingKey& K, const std::vector<g1_affine>& ha) {
   K.vk_bytes = t.buf;
 }
 
+// ---- coalescing of concurrent single-proof calls ----------------------------------------------------------------
+// The reference proves notes under rayon (`into_par_iter()`, src/utils/params_builder.rs:194-226): many host threads
+// each calling prove() for ONE note.  Behind one device and one process lock those calls would run one after the
+// other at single-proof latency (4 ms each, the chip mostly idle).  With coalescing switched on
+// (capgpu_plonk_set_coalescing) the calls that arrive for the same proving key while the device is busy - or within a
+// short window - are gathered and proved as ONE device batch; every caller gets its own proof and its own error code.
+struct ProveReq {
+  const uint64_t* wires;
+  const uint64_t* pubs;
+  size_t num_inputs;
+  const uint8_t* msg;
+  size_t msg_len;
+  const uint64_t* blinders;
+  capgpu_proof* out;
+  int rc = CAPGPU_OK;
+  std::string err;
+  bool done = false;
+};
+struct Coalescer {
+  std::mutex mu;
+  std::condition_variable cv;
+  std::map<uint64_t, std::vector<ProveReq*>> pending;  // per proving key
+  std::map<uint64_t, bool> leader;
+  uint32_t window_us = 0;  // 0 = off
+  uint32_t max_batch = 256;
+  std::atomic<uint64_t> batches{0}, proofs{0};
+};
+Coalescer& coalescer() {
+  static Coalescer c;
+  return c;
+}
+
 int lookup_key(uint64_t h, std::shared_ptr<ProvingKey>* out) {
   Context& c = ctx();
   auto it = c.keys.find(h);
@@ -995,10 +1036,128 @@ int capgpu_plonk_prove_batch(uint64_t pk_handle, int count, const uint64_t* wire
                                       blinders, proofs_out);
 }
 
+// one gathered batch: device staging of every request's wires, per-proof messages; a batch that fails because ONE
+// witness does not satisfy the circuit is re-run request by request so that only its owner sees the failure
+static void run_coalesced(uint64_t pk_handle, std::vector<ProveReq*>& reqs) {
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  auto fail_all = [&](int rc) {
+    for (ProveReq* r : reqs) {
+      r->rc = rc;
+      r->err = capgpu_last_error();
+    }
+  };
+  std::shared_ptr<ProvingKey> K;
+  int rc = lookup_key(pk_handle, &K);
+  if (rc) return fail_all(rc);
+  const size_t n = K->n, count = reqs.size(), ni = K->num_inputs;
+  for (ProveReq* r : reqs)
+    if (r->num_inputs != ni) {
+      set_error("capgpu_plonk_prove: %zu public inputs given, key expects %zu", r->num_inputs, ni);
+      r->rc = CAPGPU_ERR_INVALID_ARG;
+      r->err = capgpu_last_error();
+    }
+  std::vector<ProveReq*> good;
+  for (ProveReq* r : reqs)
+    if (r->rc == CAPGPU_OK) good.push_back(r);
+  if (good.empty()) return;
+  const size_t g = good.size();
+  (void)count;
+  const size_t per = sizeof(fe) * NW * n;
+  rc = scratch_reserve(c.stage_b, per * g);
+  if (rc) return fail_all(rc);
+  std::vector<uint64_t> pubs(4 * ni * g + 4), blind(4 * 13 * g);
+  std::vector<const uint8_t*> msgs(g);
+  std::vector<size_t> lens(g);
+  std::vector<capgpu_proof> out(g);
+  for (size_t i = 0; i < g; i++) {
+    hipError_t e = hipMemcpyAsync((char*)c.stage_b.p + per * i, good[i]->wires, per, hipMemcpyHostToDevice, c.stream);
+    if (e != hipSuccess) return fail_all(hip_fail(e, "upload of wire columns"));
+    if (ni) memcpy(&pubs[4 * ni * i], good[i]->pubs, 32 * ni);
+    memcpy(&blind[4 * 13 * i], good[i]->blinders, 32 * 13);
+    msgs[i] = good[i]->msg;
+    lens[i] = good[i]->msg_len;
+  }
+  rc = prove_batch(*K, (uint32_t)g, (const fe*)c.stage_b.p, pubs.data(), ni, nullptr, 0, blind.data(), out.data(),
+                   msgs.data(), lens.data());
+  if (rc == CAPGPU_OK) rc = take_launch_error();
+  if (rc == CAPGPU_OK) {
+    for (size_t i = 0; i < g; i++) *good[i]->out = out[i];
+  } else if (rc == CAPGPU_ERR_PROOF && g > 1) {
+    for (size_t i = 0; i < g; i++) {  // find the owner(s) of the unsatisfied witness
+      good[i]->rc = capgpu_plonk_prove_batch(pk_handle, 1, good[i]->wires, good[i]->pubs, ni, good[i]->msg,
+                                             good[i]->msg_len, good[i]->blinders, good[i]->out);
+      if (good[i]->rc) good[i]->err = capgpu_last_error();
+    }
+  } else {
+    for (ProveReq* r : good) {
+      r->rc = rc;
+      r->err = capgpu_last_error();
+    }
+  }
+  coalescer().batches++;
+  coalescer().proofs += g;
+}
+
 int capgpu_plonk_prove(uint64_t pk_handle, const uint64_t* wires, const uint64_t* pub_inputs, size_t num_inputs,
                        const uint8_t* ext_msg, size_t ext_msg_len, const uint64_t* blinders, capgpu_proof* proof_out) {
-  return capgpu_plonk_prove_batch(pk_handle, 1, wires, pub_inputs, num_inputs, ext_msg, ext_msg_len, blinders,
-                                  proof_out);
+  Coalescer& co = coalescer();
+  if (co.window_us == 0)
+    return capgpu_plonk_prove_batch(pk_handle, 1, wires, pub_inputs, num_inputs, ext_msg, ext_msg_len, blinders,
+                                    proof_out);
+  CAP_CHECK_INIT();
+  if (!wires || !blinders || !proof_out || (num_inputs && !pub_inputs)) {
+    set_error("capgpu_plonk_prove: bad argument");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  ProveReq req{wires, pub_inputs, num_inputs, ext_msg, ext_msg_len, blinders, proof_out};
+  std::unique_lock<std::mutex> lk(co.mu);
+  std::vector<ProveReq*>& q = co.pending[pk_handle];
+  q.push_back(&req);
+  if (q.size() >= co.max_batch) co.cv.notify_all();
+  bool waited_window = false;
+  while (!req.done) {
+    const bool queued = std::find(q.begin(), q.end(), &req) != q.end();
+    if (co.leader[pk_handle] || !queued) {  // somebody is gathering / proving a batch that holds (or will hold) this request
+      co.cv.wait_for(lk, std::chrono::milliseconds(1), [&] { return req.done; });
+      continue;
+    }
+    // this thread leads the key's next batch: collect for the window, and for as long as the device is busy
+    co.leader[pk_handle] = true;
+    if (!waited_window) {
+      co.cv.wait_for(lk, std::chrono::microseconds(co.window_us), [&] { return q.size() >= co.max_batch; });
+      waited_window = true;
+    }
+    Context& c = ctx();
+    while (!c.mu.try_lock()) co.cv.wait_for(lk, std::chrono::microseconds(100));  // later arrivals join meanwhile
+    const size_t take = std::min<size_t>(q.size(), co.max_batch);
+    std::vector<ProveReq*> reqs(q.begin(), q.begin() + take);
+    q.erase(q.begin(), q.begin() + take);
+    co.leader[pk_handle] = false;
+    lk.unlock();
+    run_coalesced(pk_handle, reqs);  // re-enters the (recursive) process lock this thread holds
+    c.mu.unlock();
+    lk.lock();
+    for (ProveReq* r : reqs) r->done = true;
+    co.cv.notify_all();
+  }
+  if (req.rc != CAPGPU_OK) set_error("%s", req.err.c_str());
+  return req.rc;
+}
+
+int capgpu_plonk_set_coalescing(uint32_t window_us, uint32_t max_batch) {
+  Coalescer& co = coalescer();
+  std::lock_guard<std::mutex> lk(co.mu);
+  co.window_us = window_us;
+  co.max_batch = max_batch ? max_batch : 256;
+  return CAPGPU_OK;
+}
+
+int capgpu_plonk_coalescing_stats(uint64_t* batches_out, uint64_t* proofs_out) {
+  Coalescer& co = coalescer();
+  if (batches_out) *batches_out = co.batches.load();
+  if (proofs_out) *proofs_out = co.proofs.load();
+  return CAPGPU_OK;
 }
 
 }  // extern "C"

@@ -380,6 +380,32 @@ def plonk_prove_batch(pk_handle: int, wires: np.ndarray, pub_inputs: np.ndarray,
     return list(proofs)
 
 
+def plonk_prove(pk_handle: int, wires: np.ndarray, pub_inputs: np.ndarray, blinders: np.ndarray,
+                ext_msg: bytes | None = None) -> Proof:
+    """capgpu_plonk_prove: ONE proof per call - the entry point many host threads call at once (it coalesces their
+    calls into device batches when plonk_set_coalescing is on).  wires (5, n, 4), pub_inputs (l, 4), blinders (13, 4)."""
+    wires = np.ascontiguousarray(wires, dtype=np.uint64)
+    pub_inputs = np.ascontiguousarray(pub_inputs, dtype=np.uint64).reshape(-1)
+    blinders = np.ascontiguousarray(blinders, dtype=np.uint64).reshape(-1)
+    num_inputs = _check_prove_shapes(pk_handle, 1, wires.size // 4 if wires.size % 4 == 0 else -1, pub_inputs, blinders)
+    proof = Proof()
+    mbuf, mlen = _bytes_arg(ext_msg)
+    check(load().capgpu_plonk_prove(ctypes.c_uint64(pk_handle), _p(wires.reshape(-1)),
+                                    _p(pub_inputs) if pub_inputs.size else None, ctypes.c_size_t(num_inputs), mbuf,
+                                    ctypes.c_size_t(mlen), _p(blinders), ctypes.byref(proof)))
+    return proof
+
+
+def plonk_set_coalescing(window_us: int, max_batch: int = 0):
+    check(load().capgpu_plonk_set_coalescing(ctypes.c_uint32(window_us), ctypes.c_uint32(max_batch)))
+
+
+def plonk_coalescing_stats():
+    b, p = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    check(load().capgpu_plonk_coalescing_stats(ctypes.byref(b), ctypes.byref(p)))
+    return b.value, p.value
+
+
 def plonk_prove_batch_dev(pk_handle: int, d_wires: DevBuf, pub_inputs: np.ndarray, blinders: np.ndarray,
                           ext_msg: bytes | None = None, count: int = 1):
     pub_inputs = np.ascontiguousarray(pub_inputs, dtype=np.uint64).reshape(-1)

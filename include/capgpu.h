@@ -35,7 +35,9 @@
  *     from capgpu_malloc and enqueue on the library stream (capgpu_sync waits).
  *   - Thread safety: entry points may be called from any thread (rayon workers
  *     in the reference, src/utils/params_builder.rs:194-226); calls serialise
- *     on an internal lock per process (one process drives one GPU).
+ *     on an internal lock per process (one process drives one GPU).  Concurrent
+ *     capgpu_plonk_prove calls can be gathered into device batches instead of
+ *     queueing up: capgpu_plonk_set_coalescing.
  *   - There is no CPU fallback: without a usable gfx950 device capgpu_init
  *     fails with CAPGPU_ERR_NO_DEVICE and every other call fails with
  *     CAPGPU_ERR_NOT_INITIALISED.
@@ -199,6 +201,15 @@ int capgpu_plonk_key_info(uint64_t pk_handle, size_t* domain_size_out, size_t* n
  * permutation product polynomial. */
 int capgpu_plonk_prove(uint64_t pk_handle, const uint64_t* wires, const uint64_t* pub_inputs, size_t num_inputs,
                        const uint8_t* ext_msg, size_t ext_msg_len, const uint64_t* blinders, capgpu_proof* proof_out);
+/* Coalescing of concurrent capgpu_plonk_prove calls (off by default).  The reference proves notes from many rayon
+ * worker threads, one prove() per note (src/utils/params_builder.rs:194-226); behind one device those calls would run
+ * one after the other at single-proof latency.  With window_us > 0, calls for the same proving key that arrive within
+ * window_us microseconds of each other - or while the device is busy with a previous batch - are gathered (up to
+ * max_batch; 0 = 256) and proved as ONE device batch; each caller receives its own proof and its own return code
+ * (an unsatisfied witness fails only its owner).  window_us = 0 switches it off. */
+int capgpu_plonk_set_coalescing(uint32_t window_us, uint32_t max_batch);
+/* device batches run and proofs made through the coalescer so far */
+int capgpu_plonk_coalescing_stats(uint64_t* batches_out, uint64_t* proofs_out);
 /* Same, `count` independent proofs under one key pipelined on the device; per-proof arrays are
  * consecutive (wires: count * 5 * n, pub_inputs: count * num_inputs, blinders: count * 13). */
 int capgpu_plonk_prove_batch(uint64_t pk_handle, int count, const uint64_t* wires, const uint64_t* pub_inputs,

@@ -229,3 +229,50 @@ def test_unsatisfied_witness_and_bad_arguments(cg, tau):
         cg.srs_free(x)
     cg.plonk_free_key(pkh)
     cg.srs_free(h)
+
+
+def test_concurrent_prove_calls_are_coalesced(cg, tau):
+    """The reference proves notes from rayon worker threads, one prove() per note (src/utils/params_builder.rs:194-226).
+    With coalescing on, 24 threads calling capgpu_plonk_prove at once - different witnesses, different bound data, one of
+    them an unsatisfied witness - are served by a few device batches; every caller gets exactly the proof a lone call
+    gives, and only the owner of the bad witness sees CAPGPU_ERR_PROOF."""
+    import threading
+    sc = bu.synthetic_circuit(10, 3, seed=44)
+    h, pkh, vk = gpu_key(cg, tau, sc)
+    T = 24
+    ws, ps, bls, msgs = [], [], [], []
+    for t in range(T):
+        w, pubs = sc.witness(900 + t)
+        ws.append(sc.wires_mont(w)); ps.append(pubs_arr(pubs)); bls.append(bu.to_mont_array(bu.blinders(950 + t)))
+        msgs.append(b"memo-%d" % t if t % 3 else None)
+    alone = [cg.plonk_prove(pkh, ws[t], ps[t], bls[t], msgs[t]) for t in range(T)]        # coalescing off
+    ws_bad = [w.copy() for w in ws]
+    ws_bad[5][4, 30, 0] ^= 1                                                              # caller 5's witness is wrong
+    cg.plonk_set_coalescing(2000, 16)
+    b0, p0 = cg.plonk_coalescing_stats()
+    results = [None] * T
+    start = threading.Barrier(T)
+
+    def worker(t):
+        start.wait()
+        try:
+            results[t] = cg.plonk_prove(pkh, ws_bad[t], ps[t], bls[t], msgs[t])
+        except cg.CapGpuError as e:
+            results[t] = e
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    cg.plonk_set_coalescing(0)
+    b1, p1 = cg.plonk_coalescing_stats()
+    for t in range(T):
+        if t == 5:
+            assert isinstance(results[t], cg.CapGpuError) and results[t].code == -7, results[t]
+        else:
+            assert not isinstance(results[t], Exception), (t, results[t])
+            assert bytes(results[t]) == bytes(alone[t]), t
+    assert p1 - p0 >= T - 1 and b1 - b0 <= 8, (b1 - b0, p1 - p0)       # a handful of device batches, not 24
+    cg.plonk_free_key(pkh)
+    cg.srs_free(h)
