@@ -273,6 +273,6 @@ def test_concurrent_prove_calls_are_coalesced(cg, tau):
         else:
             assert not isinstance(results[t], Exception), (t, results[t])
             assert bytes(results[t]) == bytes(alone[t]), t
-    assert p1 - p0 >= T - 1 and b1 - b0 <= 8, (b1 - b0, p1 - p0)       # a handful of device batches, not 24
+    assert p1 - p0 >= T - 1 and b1 - b0 <= 12, (b1 - b0, p1 - p0)      # a handful of device batches (typically 2-3), not 24
     cg.plonk_free_key(pkh)
     cg.srs_free(h)
