@@ -190,6 +190,30 @@ int run_ntt(hipStream_t s, uint32_t log_n, fe* data, size_t stride, uint32_t cou
   return CAPGPU_OK;
 }
 
+// out-of-place form: `count` arrays of src_len elements at src (src_stride apart; zero-extended to the transform
+// size inside the kernel) -> transforms at dst (dst_stride apart).  Saves the padded copy an in-place call needs.
+int run_ntt_from(hipStream_t s, uint32_t log_n, const fe* src, size_t src_stride, size_t src_len, fe* dst,
+                 size_t dst_stride, uint32_t count, int dir, int coset) {
+  Context& c = ctx();
+  const NttDomain* dom = nullptr;
+  int rc = get_domain(log_n, &dom);
+  if (rc) return rc;
+  rc = scratch_reserve(c.ntt_scratch, (sizeof(fe) << log_n) * count);
+  if (rc) return rc;
+  NttIo io{};
+  io.src = src;
+  io.src_outer = src_stride;
+  io.src_inner = 0;
+  io.src_group = 1;
+  io.src_len = src_len;
+  io.dst_outer = dst_stride;
+  io.dst_inner = 0;
+  io.dst_group = 1;
+  rc = ntt_run(*dom, c.small, dst, (fe*)c.ntt_scratch.p, dst_stride, count, dir, coset, s, &io);
+  if (rc) return hip_fail((hipError_t)rc, "ntt_run");
+  return CAPGPU_OK;
+}
+
 // the quotient domain: N = 6n = 3 * 2^(log n + 1) points (ntt.hpp)
 int quot_domains(uint32_t log_mm, const Ntt3Domain** d3, const NttDomain** dm) {
   int rc = get_domain3(log_mm, d3);
@@ -382,12 +406,16 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
   };
 
   // ---- round 1: wire polynomials, public-input polynomial, 5 commitments ------------------------------
-  pad_copy(s, w.wpoly, ps, 0, d_wires, n, 0, 1, P * NW, n, ps);
-  if ((rc = run_ntt(s, K.log_n, w.wpoly, ps, P * NW, 1, 0))) return rc;
-  launch("k_blind", k_blind, dim3(P * NW), dim3(64), 0, s, w.wpoly, ps, n, (const fe*)w.d_blind, (uint32_t)NW, 0u, 2u,
-         P * NW);
-  pad_copy(s, w.pi, n, 0, w.d_pub, num_inputs, 0, 1, P, num_inputs, n);
-  if ((rc = run_ntt(s, K.log_n, w.pi, n, P, 1, 0))) return rc;
+  // the interpolations read the witness columns / public inputs where they are and write the coefficient arrays (no
+  // padded copies); k_blind sets the 8-element tail of every wire polynomial (two blinders, six zeros)
+  if ((rc = run_ntt_from(s, K.log_n, d_wires, n, n, w.wpoly, ps, P * NW, 1, 0))) return rc;
+  launch("k_blind", k_blind<1>, dim3(P * NW), dim3(64), 0, s, w.wpoly, ps, n, (const fe*)w.d_blind, (uint32_t)NW, 0u,
+         2u, P * NW);
+  if (num_inputs) {
+    if ((rc = run_ntt_from(s, K.log_n, w.d_pub, num_inputs, num_inputs, w.pi, n, P, 1, 0))) return rc;
+  } else {
+    CAP_HIP(hipMemsetAsync(w.pi, 0, sizeof(fe) * (size_t)P * n, s));
+  }
   if ((rc = run_msm(s, *B, w.wpoly, ps, 1, 0, n + 2, P * NW, w.comms))) return rc;
   // round 3's coset evaluations of the wire and public-input polynomials (on the 6n quotient domain, straight from
   // their coefficient arrays: the transform zero-extends them) depend on nothing the transcript still has to produce
@@ -424,7 +452,7 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
   launch("k_perm_finish", k_perm_finish, dim3(cdiv(ps, kThreads), P), dim3(kThreads), 0, s, (const fe*)w.pre,
          (const fe*)w.sfx, (const fe*)w.den, (const fe*)w.inv_total, n, w.zpoly, ps);
   if ((rc = run_ntt(s, K.log_n, w.zpoly, ps, P, 1, 0))) return rc;
-  launch("k_blind", k_blind, dim3(P), dim3(64), 0, s, w.zpoly, ps, n, (const fe*)w.d_blind, 1u, 10u, 3u, P);
+  launch("k_blind", k_blind<0>, dim3(P), dim3(64), 0, s, w.zpoly, ps, n, (const fe*)w.d_blind, 1u, 10u, 3u, P);
   if ((rc = run_msm(s, *B, w.zpoly, ps, 1, 0, n + 3, P, w.comms))) return rc;
   if ((rc = fetch_comms(P, [&]() -> int {  // likewise the coset evaluations of z
          return run_ntt3_fwd(s, K.log_m, w.coset + 5 * m, P, NttIo{w.zpoly, ps, 0, n + 3, 1, 7 * m, 0, 1});

@@ -45,15 +45,22 @@ __global__ __launch_bounds__(kThreads) void k_pad_copy(fe* __restrict__ dst, siz
   dst[d] = v;
 }
 
-// poly_q += (b_0 + b_1 X + ...)(X^n - 1); blinder index = (q/inner)*13 + bl_off + (q%inner)*nb + t
+// poly_q += (b_0 + b_1 X + ...)(X^n - 1); blinder index = (q/inner)*13 + bl_off + (q%inner)*nb + t.
+// SET_TAIL: the coefficients n .. n + 7 hold nothing yet (the interpolation wrote n of the n + 8 slots): they are set -
+// blinders, then zeros - instead of added to.
+template <int SET_TAIL>
 __global__ void k_blind(fe* __restrict__ polys, size_t stride, size_t n, const fe* __restrict__ blinders,
                         uint32_t inner, uint32_t bl_off, uint32_t nb, uint32_t count) {
   uint32_t t = threadIdx.x, q = blockIdx.x;
-  if (q >= count || t >= nb) return;
-  fe b = blinders[(size_t)(q / inner) * 13 + bl_off + (size_t)(q % inner) * nb + t];
+  if (q >= count) return;
   fe* p = polys + (size_t)q * stride;
+  if (t >= nb) {
+    if (SET_TAIL && t < 8 && n + t < stride) p[n + t] = Fr::zero();
+    return;
+  }
+  fe b = blinders[(size_t)(q / inner) * 13 + bl_off + (size_t)(q % inner) * nb + t];
   p[t] = Fr::sub(p[t], b);
-  p[n + t] = Fr::add(p[n + t], b);
+  p[n + t] = SET_TAIL ? b : Fr::add(p[n + t], b);
 }
 
 // round 2: per-row numerator / denominator of the permutation grand product
