@@ -451,6 +451,34 @@ struct Fl {
     return reduce_cols(c);
   }
 
+  // 1 / a = a^(p-2) in the internal Montgomery form (0 for a = 0): 4-bit fixed windows, 252 squarings and at most
+  // 63 + 14 multiplications.  For single-thread inversions that sit on a latency path (the saturated field's
+  // square-and-multiply in field.hpp spends 380 multiplications of 300+ instructions each).
+  static CAP_HD fl inv(const fl& a) {
+    fl tab[16];
+    tab[0] = one();
+    tab[1] = a;
+    for (int i = 2; i < 16; i++) tab[i] = mul(tab[i - 1], a);
+    uint32_t e[9];
+#pragma unroll
+    for (int i = 0; i < 9; i++) e[i] = PR::MOD[i];
+    e[0] -= 2;  // both moduli end in a limb >= 2
+    auto window = [&](int w) {  // bits 4w .. 4w + 3 of p - 2
+      const int bit = 4 * w, l = bit / 29, o = bit % 29;
+      uint32_t v = e[l] >> o;
+      if (o > 25 && l + 1 < 9) v |= e[l + 1] << (29 - o);
+      return v & 15u;
+    };
+    fl r = tab[window(63)];  // p < 2^254: the top window is 3
+#pragma unroll 1
+    for (int w = 62; w >= 0; w--) {
+      r = sqr(sqr(sqr(sqr(r))));
+      const uint32_t d = window(w);
+      if (d) r = mul(r, tab[d]);
+    }
+    return r;
+  }
+
   // ---- forms ---------------------------------------------------------------------------------------------
   static CAP_HD fl konst(const uint32_t (&k)[9]) {
     fl r;

@@ -29,6 +29,13 @@ constexpr int kDigitThreads = 1024;       // one scalar per thread: 16 waves hid
 // short ones when a single MSM has to be spread over all CUs.
 constexpr uint32_t kMinItemLen = 32, kMaxItemLen = 256;
 
+// Two schedules of the same field arithmetic (field29.hpp).  G1L (column-wise products, 204 instructions per
+// multiplication) is for everything that runs more than a handful of waves.  G1S (row-wise, 220 instructions, 18
+// independent accumulators) is for the one-wavefront-per-MSM finishing kernels, single dependent chains of ~30 point
+// operations.  (Measured on a single proof's launches, which leave most SIMDs with one wave or none: the row-wise
+// schedule made msm_accumulate and msm_reduce_bits 5 % slower there too - only the finishing kernels gain from it.)
+using G1S = G1LT<0>;
+
 __device__ __forceinline__ fl shfl_down_fl(const fl& a, int d) {
   fl r;
 #pragma unroll
@@ -508,8 +515,8 @@ __global__ __launch_bounds__(1024) void msm_scan_add(uint32_t* __restrict__ offs
 }
 
 // bucket = sum of its work items, G lanes per bucket: lanes take items, a shuffle tree adds them up.  For the
-// single-MSM path, where a bucket has tens of items and there are only a few thousand buckets (one thread per bucket
-// is then a 20-deep serial chain on 64 waves: 1.2 ms for 2^17 points).
+// small-batch path, where there are too few buckets for one thread each (one thread per bucket is then a serial chain
+// on a handful of waves: 1.2 ms for 2^17 points).
 template <int G>
 __global__ __launch_bounds__(kThreads) void msm_combine_wave(const g1_xyzz* __restrict__ item_pts,
                                                              const uint32_t* __restrict__ counts,
@@ -524,8 +531,10 @@ __global__ __launch_bounds__(kThreads) void msm_combine_wave(const g1_xyzz* __re
   const uint32_t items = (counts[gb] + item_len - 1) / item_len;
   const uint32_t first = item_base[gb / half] + item_off[gb];
   g1x acc = G1L::inf();
-  if (items != 1)  // single-item buckets were written by msm_accumulate
-    for (uint32_t j = lane; j < items; j += G) acc = G1L::add(acc, G1L::load(item_pts[first + j]));
+  if (items != 1) {  // single-item buckets were written by msm_accumulate
+    if (lane < items) acc = G1L::load(item_pts[first + lane]);
+    for (uint32_t j = lane + G; j < items; j += G) acc = G1L::add(acc, G1L::load(item_pts[first + j]));
+  }
   for (int d = G / 2; d >= 1; d >>= 1) {
     g1x o = shfl_down_pt(acc, d);
     if (lane + d < G) acc = G1L::add(acc, o);
@@ -709,9 +718,6 @@ __global__ __launch_bounds__(kThreads) void msm_reduce_segments(const g1_xyzz* _
   seg_pts[2 * (size_t)t + 1] = G1L::store(T);
 }
 
-// The one-wavefront-per-MSM finishing kernels are single dependent chains of point operations: latency, not issue
-// slots, is their cost, and there the row-wise multiplication (18 independent accumulators) is the faster schedule.
-using G1S = G1LT<0>;
 template <class G = G1L>
 __device__ __forceinline__ g1x wave_sum(g1x v) {
   for (int d = 32; d >= 1; d >>= 1) {
@@ -800,18 +806,22 @@ __global__ __launch_bounds__(kThreads) void msm_combine(const g1_xyzz* __restric
 
 // ---- K6a: bit-plane sums ---------------------------------------------------------------------------
 // grid (chunks, c, batch).  partial[(b*c + bit)*chunks + chunk] = sum of buckets j in the chunk with
-// bit `bit` of (j+1) set.
-__global__ __launch_bounds__(kThreads) void msm_reduce_bits(const g1_xyzz* __restrict__ buckets, uint32_t half,
-                                                            uint32_t c, uint32_t chunks,
-                                                            g1_xyzz* __restrict__ partial) {
-  __shared__ g1_xyzz sh[kThreads / 64];
+// bit `bit` of (j+1) set.  The launch is a few dozen workgroups, each a dependent chain of point additions: 8 serial
+// + 6 shuffle + 2 cross-wave.  (512 threads - a chain of 4 + 6 + 3 - were measured slower, 0.93 against 0.79 ms over a
+// single proof's four launches: two waves of this code on a SIMD run at little more than the speed of one.)
+constexpr int kReduceThreads = 256;
+__global__ __launch_bounds__(kReduceThreads) void msm_reduce_bits(const g1_xyzz* __restrict__ buckets, uint32_t half,
+                                                                  uint32_t c, uint32_t chunks,
+                                                                  g1_xyzz* __restrict__ partial) {
+  constexpr int kWaves = kReduceThreads / 64;
+  __shared__ g1_xyzz sh[kWaves];
   const uint32_t chunk = blockIdx.x, bit = blockIdx.y, b = blockIdx.z;
   const g1_xyzz* bk = buckets + (size_t)b * half;
   g1x acc = G1L::inf();
   // enumerate only the weights v = j + 1 in [1, half] that have `bit` set: v = idx with a 1 inserted at `bit`
   // (every lane does useful work; a predicate on j would leave half the lanes idle for the low bits)
-  for (uint32_t q = 0; q < kReduceChunk / 2 / kThreads; q++) {
-    uint32_t idx = chunk * (kReduceChunk / 2) + q * kThreads + threadIdx.x;
+  for (uint32_t q = 0; q < kReduceChunk / 2 / kReduceThreads; q++) {
+    uint32_t idx = chunk * (kReduceChunk / 2) + q * kReduceThreads + threadIdx.x;
     uint32_t v = ((idx >> bit) << (bit + 1)) | (1u << bit) | (idx & ((1u << bit) - 1));
     if (v <= half) acc = G1L::add(acc, G1L::load(bk[v - 1]));
   }
@@ -819,13 +829,16 @@ __global__ __launch_bounds__(kThreads) void msm_reduce_bits(const g1_xyzz* __res
     g1x o = shfl_down_pt(acc, d);
     acc = G1L::add(acc, o);
   }
-  uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   if (lane == 0) sh[wave] = G1L::store(acc);
   __syncthreads();
-  if (threadIdx.x == 0) {
-    g1x r = G1L::load(sh[0]);
-    for (uint32_t w = 1; w < kThreads / 64; w++) r = G1L::add(r, G1L::load(sh[w]));
-    partial[((size_t)b * c + bit) * chunks + chunk] = G1L::store(r);
+  if (wave == 0) {  // the wave sums: a shuffle tree over the first kWaves lanes
+    g1x r = lane < kWaves ? G1L::load(sh[lane]) : G1L::inf();
+    for (int d = kWaves / 2; d >= 1; d >>= 1) {
+      g1x o = shfl_down_pt(r, d);
+      r = G1L::add(r, o);
+    }
+    if (lane == 0) partial[((size_t)b * c + bit) * chunks + chunk] = G1L::store(r);
   }
 }
 
@@ -943,7 +956,9 @@ bool use_segment_reduce(uint32_t half, uint32_t batch) {
   uint32_t seg_len = reduce_seg_len(half);
   return (size_t)((half + seg_len - 1) / seg_len) * batch >= 16384;
 }
-// about 8 waves per SIMD worth of work items (256 CUs x 4 SIMDs x 64 lanes x 8) before items grow beyond the minimum
+// about 8 waves per SIMD worth of work items (256 CUs x 4 SIMDs x 64 lanes x 8) before items grow beyond the minimum.
+// (Shorter items for a single proof's 1- and 2-MSM launches - down to 8 entries below 2^20 entries - were measured:
+// msm_accumulate 0.84 -> 0.78 ms per proof, msm_combine_wave 0.29 -> 0.45 ms.)
 uint32_t choose_item_len(size_t entries) {
   static const size_t cap = [] {
     const char* e = getenv("CAPGPU_MSM_ITEM_MAX");
@@ -1179,14 +1194,18 @@ int msm_run_slice(const MsmBases& bases, const Plan& pl, size_t offset, const fe
     launch("msm_combine", msm_combine, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0, stream,
            (const g1_xyzz*)item_pts, (const uint32_t*)counts, (const uint32_t*)item_off, (const uint32_t*)item_base, half,
            total_buckets, item_len, buckets);
-  else if (total_buckets <= 8192)  // few buckets with many items each: a wavefront per bucket
-    launch("msm_combine", msm_combine_wave<64>, dim3((unsigned)(((size_t)total_buckets * 64 + kThreads - 1) / kThreads)),
-           dim3(kThreads), 0, stream, (const g1_xyzz*)item_pts, (const uint32_t*)counts, (const uint32_t*)item_off,
+  else {
+    // G lanes per bucket: the smallest power of two that holds a bucket's items with some room for the spread of the
+    // bucket sizes (a bucket with more items than lanes loops), so that the shuffle tree is no deeper than needed
+    const size_t avg_items = (per * sb / total_buckets + item_len - 1) / item_len;
+    const size_t want = avg_items * 3 / 2;
+    const uint32_t G = want <= 8 ? 8u : (want <= 16 ? 16u : (want <= 32 ? 32u : 64u));
+    auto kern = G == 8 ? msm_combine_wave<8>
+                       : (G == 16 ? msm_combine_wave<16> : (G == 32 ? msm_combine_wave<32> : msm_combine_wave<64>));
+    launch("msm_combine", kern, dim3((unsigned)(((size_t)total_buckets * G + kThreads - 1) / kThreads)), dim3(kThreads),
+           0, stream, (const g1_xyzz*)item_pts, (const uint32_t*)counts, (const uint32_t*)item_off,
            (const uint32_t*)item_base, half, total_buckets, item_len, buckets);
-  else  // a quarter wavefront per bucket
-    launch("msm_combine", msm_combine_wave<16>, dim3((unsigned)(((size_t)total_buckets * 16 + kThreads - 1) / kThreads)),
-           dim3(kThreads), 0, stream, (const g1_xyzz*)item_pts, (const uint32_t*)counts, (const uint32_t*)item_off,
-           (const uint32_t*)item_base, half, total_buckets, item_len, buckets);
+  }
   if (use_segment_reduce(half, sb)) {
     launch("msm_reduce_segments", msm_reduce_segments, dim3((nseg * sb + kThreads - 1) / kThreads), dim3(kThreads), 0,
            stream, (const g1_xyzz*)buckets, half, seg_len, nseg, sb, partial);
@@ -1194,7 +1213,7 @@ int msm_run_slice(const MsmBases& bases, const Plan& pl, size_t offset, const fe
            out, part_pts);
   } else {
     const uint32_t chunks = (half + kReduceChunk - 1) / kReduceChunk;
-    launch("msm_reduce_bits", msm_reduce_bits, dim3(chunks, c, sb), dim3(kThreads), 0, stream, (const g1_xyzz*)buckets,
+    launch("msm_reduce_bits", msm_reduce_bits, dim3(chunks, c, sb), dim3(kReduceThreads), 0, stream, (const g1_xyzz*)buckets,
            half, c, chunks, partial);
     launch("msm_reduce_bits_final", msm_reduce_bits_final, dim3(sb), dim3(64), 0, stream, (const g1_xyzz*)partial, c,
            chunks, out, part_pts);

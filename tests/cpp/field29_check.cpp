@@ -42,6 +42,7 @@ template<class F> void run(char op, fl a, fl b){
     case 'f': r=F::unpack(F::from_mont(a)); break;
     case 'M': r=F::mul_add_mul(a,b,b,a); break;
     case 'E': r=F::zero(); r.v[0]=F::eq(a,b); break;
+    case 'i': r=F::inv(F::normalize(a)); break;
   }
   print(r);
 }

@@ -67,6 +67,8 @@ def test_field29_against_python_integers(binaries):
             if a < 8 * m and b < 8 * m:
                 add("M", 2 * a * b * inv % m)
             add("E", 1 if (a - b) % m == 0 else 0)
+            if it % 10 == 0:    # inverse in the Montgomery domain: (a / R')^-1 * R' = R'^2 / a
+                add("i", pow(a, -1, m) * RR * RR % m if a % m else 0)
         for k in range(0, 160, 7):       # every multiple of p is recognised as zero
             lines.append(f"{w} z {k * m:x} 0")
             exp.append(("z", 1, m))
