@@ -298,11 +298,22 @@ __global__ __launch_bounds__(kThreads) void msm_scatter_runs(const uint32_t* __r
 // entries in LDS, writes the per-bucket counts / offsets, and places every entry (a few KB per bin: the scattered
 // 4-byte stores stay in L2).  Up to kL2Stage entries are staged in LDS between the passes; the rest of an oversized
 // bin (skewed scalars) is simply fetched again, so any bin size works.
-constexpr uint32_t kL2Stage = 6144;  // entries of a bin staged in LDS between the two passes (24 KiB)
+// Entries of a bin staged in LDS between the two passes (18 KiB).  A bin of the prover's MSMs holds 4352 +- 66 entries;
+// the size is chosen so that eight workgroups - the CU's 32 wave slots - fit in the 160 KiB of LDS: the kernel is a
+// chain of three global round trips per workgroup, and with 6144 entries (six workgroups per CU) it ran at 7.1 ms per
+// step against 5.0 ms now, which is the HBM rate (4.5 TB/s over the entries read and written).
+#ifndef CAP_L2_STAGE
+#define CAP_L2_STAGE 4608
+#endif
+constexpr uint32_t kL2Stage = CAP_L2_STAGE;
 constexpr uint32_t kL2MaxTiles = 72;  // tiles per sub-MSM the run table in LDS holds (7-bit tile field; n = 2^16 + 3 fits)
 constexpr size_t kMaxSubPoints = (size_t)kL2MaxTiles * kDigitTile;  // longer MSMs are cut into parts (choose_plan)
 
-__global__ __launch_bounds__(kThreads) void msm_sort_level2(const uint32_t* __restrict__ chunks,
+// (8 waves per SIMD = at most 64 VGPRs: without the attribute the compiler takes 78 and the CU holds six workgroups)
+#ifndef CAP_L2_WAVES
+#define CAP_L2_WAVES __attribute__((amdgpu_waves_per_eu(8, 8)))
+#endif
+__global__ __launch_bounds__(kThreads) CAP_L2_WAVES void msm_sort_level2(const uint32_t* __restrict__ chunks,
                                                             const uint32_t* __restrict__ table,
                                                             const uint32_t* __restrict__ tloc,
                                                             const uint32_t* __restrict__ off2, size_t per,
@@ -314,8 +325,8 @@ __global__ __launch_bounds__(kThreads) void msm_sort_level2(const uint32_t* __re
                                                             uint32_t* __restrict__ sorted) {
   // The bin's entries are read straight from the tile-sorted chunks (one run per tile, ~140 entries each): the
   // run-copy pass of the one-level sort is not needed here.
-  __shared__ uint32_t hist[256];
-  __shared__ uint32_t start[256];
+  __shared__ uint32_t hist[128];  // the low bucket bits travel in 7 bits of the entry: sub_bits <= 7
+  __shared__ uint32_t start[128];
   __shared__ uint32_t run_pre[kL2MaxTiles + 1];  // exclusive prefix of the run lengths
   __shared__ uint32_t run_src[kL2MaxTiles];      // start of each run inside the chunk buffer of the batch entry
   __shared__ uint32_t stage[kL2Stage];
@@ -899,7 +910,18 @@ uint32_t wide_c() {
   }();
   return v;
 }
-constexpr uint32_t kSubBits = 7;  // buckets per level-1 bin = 128
+// Buckets per level-1 bin = 2^sub_bits: 128, or 64 when a bin of 128 would outgrow msm_sort_level2's LDS stage (a
+// sub-MSM of 2^16 points has 8704 entries per 128-bucket bin; the overflow is placed entry by entry straight to HBM).
+uint32_t pick_sub_bits(size_t n_sub, uint32_t c, uint32_t windows) {
+  static const int forced = [] {
+    const char* e = getenv("CAPGPU_MSM_SUB_BITS");  // experiments / tests: 5..7
+    const int x = e ? atoi(e) : 0;
+    return x >= 5 && x <= 7 ? x : 0;
+  }();
+  if (forced) return (uint32_t)forced;
+  const size_t bins7 = ((size_t)1 << (c - 1)) >> 7;
+  return n_sub * windows / bins7 > kL2Stage ? 6u : 7u;  // by the mean: 4352 at n = 2^15 stays at 128 (measured better)
+}
 // A launch = `batch` MSMs of n points, each cut into `parts` sub-MSMs over consecutive ranges of n_sub points (the last
 // one shorter).  Every kernel below sees batch * parts independent MSMs of at most n_sub points; msm_sum_parts adds
 // the parts.  This is how one long MSM (2^19 .. 2^24 points) gets the chip-filling batched path: 2^24 points are 256
@@ -922,7 +944,7 @@ Plan choose_plan(const MsmBases& bases, size_t n, uint32_t batch) {
   Plan pl{bases.c, bases.windows, 0, bases.ext, 1, n};
   const bool primary_wide = bases.c >= 14;  // tables of more than 2^18 points hold the wide windows only
   if (primary_wide) {
-    pl.sub_bits = kSubBits;
+    pl.sub_bits = pick_sub_bits(n, pl.c, pl.windows);
     // enough sub-MSMs to fill the chip (the running-sum reduction wants >= 64; 128 measured best), none shorter than 8192 points (below
     // that the 16384-bucket reduction of a part costs more than a third of its accumulation) nor longer than the
     // level-2 sort's run table
@@ -932,6 +954,7 @@ Plan choose_plan(const MsmBases& bases, size_t n, uint32_t batch) {
     if (n > want) {
       pl.n_sub = want;
       pl.parts = (uint32_t)((n + want - 1) / want);
+      pl.sub_bits = pick_sub_bits(want, pl.c, pl.windows);
     }
     return pl;
   }
@@ -940,7 +963,8 @@ Plan choose_plan(const MsmBases& bases, size_t n, uint32_t batch) {
   if (bases.ext2 && n >= 4096) {
     uint32_t parts = n > kMaxSubPoints ? (uint32_t)((n + 65535) / 65536) : 1;
     if ((size_t)batch * parts >= 32) {
-      pl = Plan{bases.c2, bases.windows2, kSubBits, bases.ext2, parts, parts > 1 ? (size_t)65536 : n};
+      const size_t n_sub = parts > 1 ? (size_t)65536 : n;
+      pl = Plan{bases.c2, bases.windows2, pick_sub_bits(n_sub, bases.c2, bases.windows2), bases.ext2, parts, n_sub};
       return pl;
     }
   }
@@ -1092,8 +1116,9 @@ size_t msm_workspace_bytes(const MsmBases& bases, size_t n, uint32_t batch) {
 
 const char* msm_plan_describe(const MsmBases& bases, size_t n, uint32_t batch, char* buf, size_t cap) {
   Plan pl = choose_plan(bases, n, batch);
-  snprintf(buf, cap, "c=%u windows=%u sort=%s parts=%u n_sub=%zu slice=%u", pl.c, pl.windows,
-           pl.sub_bits ? "two-level" : "one-level", pl.parts, pl.n_sub, batch_slice(pl, batch));
+  int len = snprintf(buf, cap, "c=%u windows=%u sort=%s parts=%u n_sub=%zu slice=%u", pl.c, pl.windows,
+                     pl.sub_bits ? "two-level" : "one-level", pl.parts, pl.n_sub, batch_slice(pl, batch));
+  if (pl.sub_bits && len > 0 && (size_t)len < cap) snprintf(buf + len, cap - len, " bin_buckets=%u", 1u << pl.sub_bits);
   return buf;
 }
 

@@ -55,9 +55,10 @@ def test_msm_plans_of_the_baseline_sizes(cg, tau):
     assert cg.msm_plan(h, 1 << 17, 1) == {"c": 13, "windows": 20, "sort": "one-level", "parts": 1, "n_sub": 1 << 17,
                                           "slice": 1}
     p = cg.msm_plan(h, 32770, 1280)                       # the prover's 5P-wide commitment launch at n = 2^15
-    assert (p["c"], p["sort"], p["parts"], p["slice"]) == (15, "two-level", 1, 1280)
+    assert (p["c"], p["sort"], p["parts"], p["slice"], p["bin_buckets"]) == (15, "two-level", 1, 1280, 128)
     p = cg.msm_plan(h, (1 << 17) + 2, 40)                 # a batch at n = 2^17: parts instead of the narrow table
-    assert (p["c"], p["sort"], p["parts"], p["n_sub"]) == (15, "two-level", 3, 65536)
+    # parts of 2^16 points: bins of 64 buckets, so that a bin (4352 entries) still fits the level-2 sort's LDS stage
+    assert (p["c"], p["sort"], p["parts"], p["n_sub"], p["bin_buckets"]) == (15, "two-level", 3, 65536, 64)
     # and it computes the right thing: against the one-at-a-time path and the known-tau identity
     n = (1 << 17) + 2
     sc = bu.random_canonical_scalars(17, 40 * n).reshape(40, n, 4)
