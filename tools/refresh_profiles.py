@@ -1,0 +1,56 @@
+"""Copy the outputs of tools/gpujob_final.sh TAG (gpurun_out/final_TAG, gpurun_out/prof_TAG) into profiles/ under the
+round's names.  Run here after the gpurun call:  python tools/refresh_profiles.py TAG [ROUND]"""
+import ast
+import glob
+import json
+import os
+import shutil
+import sys
+
+tag = sys.argv[1]
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+src, prof, dst = (os.path.join(root, "gpurun_out", "final_" + tag), os.path.join(root, "gpurun_out", "prof_" + tag),
+                  os.path.join(root, "profiles"))
+
+
+def one_line_json(path_in, path_out):
+    """bench.py prints one JSON line on stdout; keep exactly that line"""
+    lines = [ln for ln in open(path_in).read().splitlines() if ln.startswith("{")]
+    open(path_out, "w").write(lines[-1] + "\n")
+    return json.loads(lines[-1])
+
+
+b = one_line_json(os.path.join(src, "bench.json"), os.path.join(dst, f"bench_{rnd}_final.json"))
+b20 = one_line_json(os.path.join(src, "bench_20steps.json"), os.path.join(dst, f"bench_20steps_{rnd}.json"))
+bm = one_line_json(os.path.join(src, "bench_mixed64.json"), os.path.join(dst, f"bench_mixed64_{rnd}.json"))
+shutil.copy(os.path.join(src, "msm_single_profile.json"), os.path.join(dst, f"msm_single_profile_{rnd}.json"))
+shutil.copy(os.path.join(src, "traffic.json"), os.path.join(dst, f"traffic_{rnd}.json"))
+shutil.copy(os.path.join(src, "pytest_gpu.txt"), os.path.join(dst, f"pytest_gpu_{rnd}_final.txt"))
+w2 = [open(os.path.join(src, n)).read().strip() for n in ("bench_w2.json", "bench_w2_mixed.json")]
+open(os.path.join(dst, f"bench_world2_gloo_sameGPU_{rnd}.json"), "w").write("\n".join(w2) + "\n")
+os.makedirs(os.path.join(dst, "rocprof_" + rnd), exist_ok=True)
+shutil.copy(os.path.join(prof, "summary.txt"), os.path.join(dst, "rocprof_" + rnd, "summary.txt"))
+stats = glob.glob(os.path.join(prof, "trace", "**", "*kernel_stats.csv"), recursive=True)
+shutil.copy(stats[0], os.path.join(dst, "rocprof_" + rnd, "kernel_stats.csv"))
+
+# instruction counters: tools/gpuprof_insts.sh prints  name {counter: (sum, launches), ...}  per kernel
+kern = {}
+for ln in open(os.path.join(src, "insts.txt")):
+    if " {'SQ_" not in ln:
+        continue
+    name, rest = ln.split(" {", 1)
+    d = ast.literal_eval("{" + rest.strip())
+    launches = max(v[1] for v in d.values())
+    kern[name.strip()] = dict(launches=launches, **{k: round(v[0] / v[1]) if isinstance(v[0], float) else v[0] for k, v in d.items()})
+old = json.load(open(os.path.join(dst, f"inst_counters_{rnd}.json")))
+adds = b["alu_roofline"]["mixed_adds_per_step"] / 4           # four large msm_accumulate launches per step
+acc = kern["msm_accumulate"]
+# the PMC run has 8 large launches and the small one of preprocess; its counters are per-launch averages over all 9
+per_add = acc["SQ_INSTS_VALU"] * acc["launches"] / (acc["launches"] - 1) * 64 / adds
+old["msm_accumulate_valu_instructions_per_mixed_addition"] = int(round(per_add, -1))
+old["kernels"] = kern
+json.dump(old, open(os.path.join(dst, f"inst_counters_{rnd}.json"), "w"), indent=1)
+print("bench", round(b["value"], 1), "20 steps", round(b20["value"], 1), "mixed64", round(bm["value"], 1),
+      "instructions per addition", round(per_add))
+print(open(os.path.join(src, "pytest_gpu.txt")).read().strip().splitlines()[-1])
