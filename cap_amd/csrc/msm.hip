@@ -33,7 +33,9 @@ constexpr uint32_t kMinItemLen = 32, kMaxItemLen = 256;
 // multiplication) is for everything that runs more than a handful of waves.  G1S (row-wise, 220 instructions, 18
 // independent accumulators) is for the one-wavefront-per-MSM finishing kernels, single dependent chains of ~30 point
 // operations.  (Measured on a single proof's launches, which leave most SIMDs with one wave or none: the row-wise
-// schedule made msm_accumulate and msm_reduce_bits 5 % slower there too - only the finishing kernels gain from it.)
+// schedule made msm_accumulate and msm_reduce_bits 5 % slower there too - only the finishing kernels gain from it.  An
+// out-of-line point addition for the tree kernels, one copy instead of three inlined ones: four times slower - the
+// operands travel through scratch memory.)
 using G1S = G1LT<0>;
 
 __device__ __forceinline__ fl shfl_down_fl(const fl& a, int d) {
