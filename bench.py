@@ -447,7 +447,8 @@ def main():
                                          "device_batches": b1 - b0, "proofs": p1 - p0, "errors": errs[:3],
                                          "note": "capgpu_plonk_prove (one proof per call, host wires) from 64 host threads with "
                                                  "capgpu_plonk_set_coalescing(500 us, 256): concurrent calls are gathered into "
-                                                 "device batches; without it they would run one by one at batch-1 latency"}
+                                                 "device batches (the window restarts with every arrival); without it they "
+                                                 "would run one by one at batch-1 latency"}
         # (3) the reference's own bench depth: n = 2^16 (TREE_DEPTH = 26, src/bench_utils/mod.rs:42)
         if log_n == 15:
             t0 = time.time()

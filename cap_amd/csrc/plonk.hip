@@ -1153,7 +1153,14 @@ int capgpu_plonk_prove(uint64_t pk_handle, const uint64_t* wires, const uint64_t
     // this thread leads the key's next batch: collect for the window, and for as long as the device is busy
     co.leader[pk_handle] = true;
     if (!waited_window) {
-      co.cv.wait_for(lk, std::chrono::microseconds(co.window_us), [&] { return q.size() >= co.max_batch; });
+      // the window restarts while calls keep arriving (threads released by the previous batch come back one by one),
+      // up to 16 windows in all
+      const auto cap = std::chrono::steady_clock::now() + std::chrono::microseconds(16ull * co.window_us);
+      for (size_t seen = q.size();; seen = q.size()) {
+        const bool full =
+            co.cv.wait_for(lk, std::chrono::microseconds(co.window_us), [&] { return q.size() >= co.max_batch; });
+        if (full || q.size() == seen || std::chrono::steady_clock::now() >= cap) break;
+      }
       waited_window = true;
     }
     Context& c = ctx();
