@@ -704,29 +704,26 @@ __global__ __launch_bounds__(kThreads) void msm_reduce_segments(const g1_xyzz* _
   if (j_hi > half) j_hi = half;
   const g1_xyzz* bk = buckets + (size_t)b * half;
   // The walk from infinity starts with S = T = the top bucket.  Then the fast loop: both additions in their lean form
-  // (G1L::add_acc: one test, no special cases in the hot block).  A lane whose addition hits a special case - an empty
-  // bucket, a running sum at infinity, equal or opposite points - leaves the fast loop and finishes its segment in the
-  // general loop below; with the prover's 34 entries per bucket that never happens, with a sparse MSM it is the rule.
+  // (G1L::add_acc: one test, no special cases in the hot block).  The two special cases that do occur - an empty bucket
+  // and a running sum still at infinity: with 8 entries per bucket (a 2^20-point MSM cut into 128 parts) every other
+  // wave has such a lane - are a skipped addition or a copy, decided on the zz coordinate before the addition; they
+  // must not throw the lane out of the loop, or the wave walks the rest of that lane's segment a second time (measured:
+  // the launch 2.3 times longer).  Only equal or opposite operands (add_acc fails) leave it, for the general loop below.
   g1x S = G1L::load(bk[j_hi - 1]);
   g1x T = S;
-  uint32_t j = j_hi - 1;       // buckets j - 1, ..., j_lo are still to be walked
-  bool s_done = false;         // the S-addition of bucket j - 1 was made, its T-addition is pending
-  g1_xyzz cur = bk[j > j_lo ? j - 1 : j];
-  while (j > j_lo) {
+  g1_xyzz cur = bk[j_hi - 1 > j_lo ? j_hi - 2 : j_hi - 1];
+  for (uint32_t j = j_hi - 1; j > j_lo; j--) {  // buckets j - 1, ..., j_lo are still to be walked
     const g1_xyzz nxt = bk[j - 1 > j_lo ? j - 2 : j - 1];  // in flight while the two additions below run
-    if (!G1L::add_acc(S, G1L::load(cur))) break;
-    if (!G1L::add_acc(T, S)) {
-      s_done = true;
-      break;
+    const g1x c = G1L::load(cur);
+    if (!G1L::is_inf(c)) {
+      if (G1L::is_inf(S)) S = c;
+      else if (__builtin_expect(!G1L::add_acc(S, c), 0)) S = G1L::add(S, c);
+    }
+    if (!G1L::is_inf(S)) {
+      if (G1L::is_inf(T)) T = S;
+      else if (__builtin_expect(!G1L::add_acc(T, S), 0)) T = G1L::add(T, S);  // T == S: an empty bucket right after the first
     }
     cur = nxt;
-    j--;
-  }
-  while (j > j_lo) {
-    if (!s_done) S = G1L::add(S, G1L::load(bk[j - 1]));
-    s_done = false;
-    T = G1L::add(T, S);
-    j--;
   }
   seg_pts[2 * (size_t)t] = G1L::store(S);
   seg_pts[2 * (size_t)t + 1] = G1L::store(T);
