@@ -551,6 +551,8 @@ def main():
         try:
             if world == 1:
                 legs.append(msm_leg(cg, bu, torch, dist, rank, world, 17, coll_dev=coll_dev))
+                if args.msm_log_n is None:    # 2^20: 128 sub-MSMs of 8192 points, the sparsest buckets of any plan
+                    legs.append(msm_leg(cg, bu, torch, dist, rank, world, 20, coll_dev=coll_dev))
             big = args.msm_log_n if args.msm_log_n is not None else (22 if world == 1 else 24)
             legs.append(msm_leg(cg, bu, torch, dist, rank, world, big, coll_dev=coll_dev, use_lib_comm=lib_comm))
         except Exception as e:                # a failed secondary leg must not lose the headline line
