@@ -757,6 +757,7 @@ __device__ g1x mul_small(const g1x& p, uint32_t k) {
 // operations per launch, so it is written for depth, not for work.
 // out (one Jacobian point per MSM) or, when the MSMs of the launch are parts of longer ones, out_part (XYZZ, summed by
 // msm_sum_parts)
+// (312 VGPRs, one wave per SIMD; forcing two - 256 VGPRs, 343 spilled - was measured: 1.56 -> 1.46 ms per step, not adopted)
 __global__ __launch_bounds__(64) void msm_reduce_final(const g1_xyzz* __restrict__ seg_pts, uint32_t seg_len,
                                                        uint32_t nseg, g1_jac* __restrict__ out,
                                                        g1_xyzz* __restrict__ out_part) {
