@@ -287,12 +287,13 @@ struct BatchWs {
   g1_jac* comms;
   EvalDesc* edesc;
   LinTerm* terms;
+  const fe** key_ptrs;  // [2][P]: sigma evaluations / coset columns of every proof's key (mixed-key batches)
   size_t total;
 };
 constexpr uint32_t kEvalChunks = 16;
 constexpr uint32_t kLinTerms = 29;
 
-BatchWs carve(void* base, const ProvingKey& K, uint32_t P) {
+BatchWs carve(void* base, const ProvingKey& K, uint32_t P, size_t num_inputs) {
   Carver c(base);
   BatchWs w{};
   size_t n = K.n, m = K.m, ps = K.ps;
@@ -316,7 +317,7 @@ BatchWs carve(void* base, const ProvingKey& K, uint32_t P) {
   w.quot = c.take<fe>((size_t)P * 2 * ps);
   w.evals = c.take<fe>((size_t)P * 10);
   w.eval_partial = c.take<fe>((size_t)P * 10 * kEvalChunks);
-  w.d_pub = c.take<fe>((size_t)P * (K.num_inputs ? K.num_inputs : 1));
+  w.d_pub = c.take<fe>((size_t)P * (num_inputs ? num_inputs : 1));
   w.d_blind = c.take<fe>((size_t)P * 13);
   w.chal = c.take<Chal>(P);
   w.chal29 = c.take<Chal>(P);
@@ -324,6 +325,7 @@ BatchWs carve(void* base, const ProvingKey& K, uint32_t P) {
   w.comms = c.take<g1_jac>((size_t)P * 5);
   w.edesc = c.take<EvalDesc>((size_t)P * 10);
   w.terms = c.take<LinTerm>((size_t)P * kLinTerms);
+  w.key_ptrs = c.take<const fe*>((size_t)P * 2);
   w.total = c.off + 256;
   return w;
 }
@@ -333,14 +335,35 @@ int compute_pk_coset(hipStream_t s, const ProvingKey& K, fe* dst) {
   return run_ntt3_fwd(s, K.log_m, dst, 18, NttIo{K.coef, K.ps, 0, K.n, 1, K.m, 0, 1});
 }
 
-// msgs / msg_lens (optional): one transcript init message per proof; otherwise ext_msg is shared by the batch
+// msgs / msg_lens (optional): one transcript init message per proof; otherwise ext_msg is shared by the batch.
+// keys (optional): the proving key of every proof - keys of ONE domain size under ONE SRS (the reference proves transfer,
+// mint and freeze notes side by side, src/utils/params_builder.rs:194-226; proofs of different circuits on the same
+// domain share every MSM and NTT launch, only k_perm_numden / k_quotient and the descriptors of rounds 4-5 read key
+// data).  K is then keys[0] - it lends the domain-level tables and the workspace - and pub_inputs holds P rows of
+// `num_inputs` = the largest count among the keys, a key with fewer inputs using the first of its row.
 int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pub_inputs, size_t num_inputs,
                 const uint8_t* ext_msg, size_t ext_len, const uint64_t* blinders, capgpu_proof* proofs,
-                const uint8_t* const* msgs = nullptr, const size_t* msg_lens = nullptr) {
+                const uint8_t* const* msgs = nullptr, const size_t* msg_lens = nullptr,
+                const std::vector<ProvingKey*>* keys = nullptr) {
   Context& c = ctx();
   hipStream_t s = c.stream;
   const size_t n = K.n, m = K.m, ps = K.ps;
-  if (num_inputs != K.num_inputs) {
+  auto key_of = [&](uint32_t p) -> const ProvingKey& { return keys ? *(*keys)[p] : K; };
+  if (keys) {
+    size_t max_ni = 0;
+    for (uint32_t p = 0; p < P; p++) {
+      const ProvingKey& Kp = key_of(p);
+      if (Kp.n != K.n || Kp.srs_handle != K.srs_handle || Kp.recompute || K.recompute) {
+        set_error("capgpu_plonk_prove_multi: the keys of one batch must share the domain size and the SRS");
+        return CAPGPU_ERR_INVALID_ARG;
+      }
+      max_ni = std::max(max_ni, Kp.num_inputs);
+    }
+    if (num_inputs != max_ni) {
+      set_error("capgpu_plonk_prove_multi: rows of %zu public inputs given, the keys need %zu", num_inputs, max_ni);
+      return CAPGPU_ERR_INVALID_ARG;
+    }
+  } else if (num_inputs != K.num_inputs) {
     set_error("capgpu_plonk_prove: %zu public inputs given, key expects %zu", num_inputs, K.num_inputs);
     return CAPGPU_ERR_INVALID_ARG;
   }
@@ -348,7 +371,7 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
   int rc = find_srs(K.srs_handle, &B);
   if (rc) return rc;
   // workspace
-  size_t need = carve(nullptr, K, P).total;
+  size_t need = carve(nullptr, K, P, num_inputs).total;
   if (need > K.ws_bytes) {
     CAP_HIP(hipStreamSynchronize(s));
     if (K.ws) CAP_HIP(hipFree(K.ws));
@@ -357,7 +380,7 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
     CAP_HIP(hipMalloc(&K.ws, need));
     K.ws_bytes = need;
   }
-  BatchWs w = carve(K.ws, K, P);
+  BatchWs w = carve(K.ws, K, P, num_inputs);
   const NttDomain* dom_n = nullptr;
   const Ntt3Domain* dom_q = nullptr;
   if ((rc = get_domain(K.log_n, &dom_n))) return rc;
@@ -371,11 +394,33 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
     } else if (ext_msg && ext_len) {
       tr[p].append(ext_msg, ext_len);
     }
-    tr[p].append(K.vk_bytes.data(), K.vk_bytes.size());
-    for (size_t i = 0; i < num_inputs; i++) append_fr(tr[p], fe_from_words(pub_inputs + 4 * (p * num_inputs + i)));
+    const ProvingKey& Kp = key_of(p);
+    tr[p].append(Kp.vk_bytes.data(), Kp.vk_bytes.size());
+    for (size_t i = 0; i < Kp.num_inputs; i++) append_fr(tr[p], fe_from_words(pub_inputs + 4 * (p * num_inputs + i)));
   });
+  std::vector<uint64_t> pub_rows;  // mixed keys: the unused tail of a shorter key's row must be zero on the device
+  if (keys && num_inputs) {
+    pub_rows.assign(pub_inputs, pub_inputs + (size_t)4 * P * num_inputs);
+    for (uint32_t p = 0; p < P; p++)
+      for (size_t i = key_of(p).num_inputs; i < num_inputs; i++)
+        for (int k = 0; k < 4; k++) pub_rows[4 * (p * num_inputs + i) + k] = 0;
+    pub_inputs = pub_rows.data();
+  }
   if (num_inputs)
     CAP_HIP(hipMemcpyAsync(w.d_pub, pub_inputs, sizeof(fe) * P * num_inputs, hipMemcpyHostToDevice, s));
+  std::vector<const fe*> key_ptrs;
+  const fe* const* sig_of = nullptr;
+  const fe* const* pkc_of = nullptr;
+  if (keys) {
+    key_ptrs.resize((size_t)2 * P);
+    for (uint32_t p = 0; p < P; p++) {
+      key_ptrs[p] = key_of(p).sig_eval;
+      key_ptrs[P + p] = key_of(p).pk_coset;
+    }
+    CAP_HIP(hipMemcpyAsync(w.key_ptrs, key_ptrs.data(), sizeof(const fe*) * key_ptrs.size(), hipMemcpyHostToDevice, s));
+    sig_of = w.key_ptrs;
+    pkc_of = w.key_ptrs + P;
+  }
   CAP_HIP(hipMemcpyAsync(w.d_blind, blinders, sizeof(fe) * P * 13, hipMemcpyHostToDevice, s));
   CAP_HIP(hipMemsetAsync(w.flags, 0, sizeof(uint32_t) * P, s));
 
@@ -441,7 +486,7 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
 
   // ---- round 2: permutation grand product --------------------------------------------------------------
   launch("k_perm_numden", k_perm_numden, dim3(cdiv(n, kThreads), P), dim3(kThreads), 0, s, d_wires,
-         (const fe*)K.sig_eval, (const fe*)dom_n->tw_fwd, (const Chal*)w.chal, K.qc, n, w.num, w.den);
+         (const fe*)K.sig_eval, sig_of, (const fe*)dom_n->tw_fwd, (const Chal*)w.chal, K.qc, n, w.num, w.den);
   {
     uint32_t nb = cdiv(n, kScanBlock);
     scan_exclusive<0, 0>(s, w.num, w.pre, n, n, P, w.scan_tot);
@@ -483,7 +528,7 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
       if ((rc = compute_pk_coset(s, K, w.pkc))) return rc;
     pkc = w.pkc;
   }
-  launch("k_quotient", k_quotient, dim3(P, cdiv(m, kThreads)), dim3(kThreads), 0, s, pkc, (const fe*)w.coset,
+  launch("k_quotient", k_quotient, dim3(P, cdiv(m, kThreads)), dim3(kThreads), 0, s, pkc, pkc_of, (const fe*)w.coset,
          (const fe*)dom_q->xs29, (const fe*)K.inv_nx1, (const Chal*)w.chal29, K.qc29, m, w.t);
   if ((rc = run_ntt3_inv(s, K.log_m, w.t, P))) return rc;
   {
@@ -538,7 +583,8 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
     const fe* pz = w.pows + ((size_t)p * 4 + 0) * ps;
     const fe* pzw = w.pows + ((size_t)p * 4 + 1) * ps;
     for (int i = 0; i < NW; i++) ed[p * 10 + i] = EvalDesc{w.wpoly + ((size_t)p * NW + i) * ps, pz, (uint32_t)(n + 2), 0};
-    for (int i = 0; i < NW - 1; i++) ed[p * 10 + NW + i] = EvalDesc{K.coef + (size_t)(NS + i) * ps, pz, (uint32_t)n, 0};
+    for (int i = 0; i < NW - 1; i++)
+      ed[p * 10 + NW + i] = EvalDesc{key_of(p).coef + (size_t)(NS + i) * ps, pz, (uint32_t)n, 0};
     ed[p * 10 + 9] = EvalDesc{w.zpoly + (size_t)p * ps, pzw, (uint32_t)(n + 3), 0};
   }
   CAP_HIP(hipMemcpyAsync(w.edesc, ed.data(), sizeof(EvalDesc) * ed.size(), hipMemcpyHostToDevice, s));
@@ -579,7 +625,8 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
       T[t].len = (uint32_t)len;
       t++;
     };
-    auto sel = [&](int i) { return K.coef + (size_t)i * ps; };
+    const fe* const coef = key_of(p).coef;
+    auto sel = [&](int i) { return coef + (size_t)i * ps; };
     for (int j = 0; j < 4; j++) add_term(sel(j), we[j], n);
     fe w01 = Fr::mul(we[0], we[1]), w23 = Fr::mul(we[2], we[3]);
     add_term(sel(4), w01, n);
@@ -601,7 +648,7 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
     // last sigma polynomial: - alpha beta z(zeta w) prod_{i<4}(w_i + beta sigma_i + gamma)
     fe cs = Fr::mul(Fr::mul(ch.alpha, ch.beta), znext);
     for (int j = 0; j < NW - 1; j++) cs = Fr::mul(cs, Fr::add(Fr::add(we[j], ch.gamma), Fr::mul(ch.beta, se[j])));
-    add_term(K.coef + (size_t)(NS + NW - 1) * ps, Fr::neg(cs), n);
+    add_term(coef + (size_t)(NS + NW - 1) * ps, Fr::neg(cs), n);
     // quotient part: - Z_H(zeta) * sum zeta^(i(n+2)) t_i(X)
     uint32_t e_n2[8] = {(uint32_t)(n + 2), (uint32_t)((uint64_t)(n + 2) >> 32), 0, 0, 0, 0, 0, 0};
     fe zp = Fr::pow(zeta[p], e_n2);
@@ -617,7 +664,7 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
       cf = Fr::mul(cf, v);
     }
     for (int j = 0; j < NW - 1; j++) {
-      add_term(K.coef + (size_t)(NS + j) * ps, cf, n);
+      add_term(coef + (size_t)(NS + j) * ps, cf, n);
       cf = Fr::mul(cf, v);
     }
     if (t != (int)kLinTerms) lin_err = t;
@@ -1061,6 +1108,52 @@ int capgpu_plonk_prove_batch(uint64_t pk_handle, int count, const uint64_t* wire
   if (rc) return rc;
   CAP_HIP(hipMemcpyAsync(c.stage_b.p, wires, bytes, hipMemcpyHostToDevice, c.stream));
   return capgpu_plonk_prove_batch_dev(pk_handle, count, c.stage_b.p, pub_inputs, num_inputs, ext_msg, ext_msg_len,
+                                      blinders, proofs_out);
+}
+
+// Proofs of several proving keys in one device batch (see prove_batch): pk_handles[i] is the key of proof i.
+int capgpu_plonk_prove_multi_dev(const uint64_t* pk_handles, int count, const void* d_wires, const uint64_t* pub_inputs,
+                                 size_t num_inputs, const uint8_t* const* ext_msgs, const size_t* ext_msg_lens,
+                                 const uint64_t* blinders, capgpu_proof* proofs_out) {
+  CAP_CHECK_INIT();
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  if (count < 0 || (count && (!pk_handles || !d_wires || !blinders || !proofs_out || (num_inputs && !pub_inputs) ||
+                              (ext_msgs && !ext_msg_lens)))) {
+    set_error("capgpu_plonk_prove_multi: bad argument");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  if (count == 0) return CAPGPU_OK;
+  std::vector<std::shared_ptr<ProvingKey>> hold(count);
+  std::vector<ProvingKey*> keys(count);
+  for (int i = 0; i < count; i++) {
+    int rc = lookup_key(pk_handles[i], &hold[i]);
+    if (rc) return rc;
+    keys[i] = hold[i].get();
+  }
+  return prove_batch(*keys[0], (uint32_t)count, (const fe*)d_wires, pub_inputs, num_inputs, nullptr, 0, blinders,
+                     proofs_out, ext_msgs, ext_msg_lens, &keys);
+}
+
+int capgpu_plonk_prove_multi(const uint64_t* pk_handles, int count, const uint64_t* wires, const uint64_t* pub_inputs,
+                             size_t num_inputs, const uint8_t* const* ext_msgs, const size_t* ext_msg_lens,
+                             const uint64_t* blinders, capgpu_proof* proofs_out) {
+  CAP_CHECK_INIT();
+  Context& c = ctx();
+  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  if (count < 0 || (count && (!wires || !pk_handles))) {
+    set_error("capgpu_plonk_prove_multi: bad argument");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  if (count == 0) return CAPGPU_OK;
+  std::shared_ptr<ProvingKey> K;
+  int rc = lookup_key(pk_handles[0], &K);
+  if (rc) return rc;
+  size_t bytes = sizeof(fe) * (size_t)count * NW * K->n;
+  rc = scratch_reserve(c.stage_b, bytes);
+  if (rc) return rc;
+  CAP_HIP(hipMemcpyAsync(c.stage_b.p, wires, bytes, hipMemcpyHostToDevice, c.stream));
+  return capgpu_plonk_prove_multi_dev(pk_handles, count, c.stage_b.p, pub_inputs, num_inputs, ext_msgs, ext_msg_lens,
                                       blinders, proofs_out);
 }
 

@@ -64,14 +64,17 @@ __global__ void k_blind(fe* __restrict__ polys, size_t stride, size_t n, const f
 }
 
 // round 2: per-row numerator / denominator of the permutation grand product
+// sig_of (optional): the sigma evaluations of proof p's own key - a batch may mix proofs of several keys on one domain
 __global__ __launch_bounds__(kThreads) void k_perm_numden(const fe* __restrict__ wires /*[P][5][n]*/,
                                                           const fe* __restrict__ sig_eval /*[5][n]*/,
+                                                          const fe* const* __restrict__ sig_of,
                                                           const fe* __restrict__ tw_n, const Chal* __restrict__ chal,
                                                           QuotConst qc, size_t n, fe* __restrict__ num,
                                                           fe* __restrict__ den) {
   size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= n) return;
   uint32_t p = blockIdx.y;
+  if (sig_of) sig_eval = sig_of[p];
   fe beta = chal[p].beta, gamma = chal[p].gamma;
   fe bx = Fr::mul(beta, tw_n[j]);
   fe a = Fr::one(), b = Fr::one();
@@ -235,8 +238,9 @@ struct ColAcc {
   __device__ __forceinline__ fl reduce() { return Fr29::reduce_cols(c); }
 };
 
-__global__ __launch_bounds__(kThreads) void k_quotient(const fe* __restrict__ pkc, const fe* __restrict__ cos,
-                                                       const fe* __restrict__ xs,
+// pkc_of (optional): the key columns of proof p's own key (mixed-key batches), otherwise pkc for all
+__global__ __launch_bounds__(kThreads) void k_quotient(const fe* __restrict__ pkc, const fe* const* __restrict__ pkc_of,
+                                                       const fe* __restrict__ cos, const fe* __restrict__ xs,
                                                        const fe* __restrict__ inv_nx1,
                                                        const Chal* __restrict__ chal, QuotConst qc, size_t m,
                                                        fe* __restrict__ t_out) {
@@ -246,6 +250,7 @@ __global__ __launch_bounds__(kThreads) void k_quotient(const fe* __restrict__ pk
   size_t i = (size_t)blockIdx.y * blockDim.x + threadIdx.x;
   if (i >= m) return;
   const uint32_t p = blockIdx.x;
+  if (pkc_of) pkc = pkc_of[p];
   const uint32_t mm = (uint32_t)(m / 3);                                  // block length M (uniform: scalar unit)
   const uint32_t blk = (i >= mm ? 1u : 0u) + (i >= 2 * (size_t)mm ? 1u : 0u);  // which of the three cosets
   const fe* c = cos + (size_t)p * 7 * m;

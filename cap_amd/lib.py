@@ -421,6 +421,48 @@ def plonk_prove_batch_dev(pk_handle: int, d_wires: DevBuf, pub_inputs: np.ndarra
     return list(proofs)
 
 
+def plonk_prove_multi(pk_handles, wires, pub_rows: np.ndarray, blinders: np.ndarray, ext_msgs=None):
+    """Proofs of several proving keys (one domain size, one SRS) in one device batch: pk_handles[i] is proof i's key.
+    wires: (count, 5, n, 4) numpy array or a DevBuf of that content; pub_rows: (count, max_inputs, 4) - a key with fewer
+    public inputs uses the first of its row; ext_msgs: one bytes object per proof, or None."""
+    count = len(pk_handles)
+    shapes = [plonk_key_info(h) for h in pk_handles]
+    n = shapes[0][0]
+    max_in = max(sh[1] for sh in shapes)
+    pub_rows = np.ascontiguousarray(pub_rows, dtype=np.uint64).reshape(-1)
+    blinders = np.ascontiguousarray(blinders, dtype=np.uint64).reshape(-1)
+    if any(sh[0] != n for sh in shapes):
+        raise ValueError("plonk_prove_multi: the keys of one batch must share the domain size")
+    if pub_rows.size != count * max_in * 4 or blinders.size != count * 13 * 4:
+        raise ValueError(f"plonk_prove_multi: pub_rows must hold {count} x {max_in} and blinders {count} x 13 elements")
+    handles = (ctypes.c_uint64 * count)(*pk_handles)
+    msgs_arg = lens_arg = None
+    keep = []
+    if ext_msgs is not None:
+        if len(ext_msgs) != count:
+            raise ValueError("plonk_prove_multi: one message per proof")
+        msgs_arg = (ctypes.c_char_p * count)()
+        lens_arg = (ctypes.c_size_t * count)()
+        for i, m in enumerate(ext_msgs):
+            keep.append(bytes(m) if m else b"")
+            msgs_arg[i] = keep[-1] if keep[-1] else None
+            lens_arg[i] = len(keep[-1])
+    proofs = (Proof * count)()
+    pub_ptr = _p(pub_rows) if pub_rows.size else None
+    if isinstance(wires, DevBuf):
+        if wires.nbytes != count * NUM_WIRE_TYPES * n * 32:
+            raise ValueError("plonk_prove_multi: the wire buffer does not hold count x 5 x n elements")
+        check(load().capgpu_plonk_prove_multi_dev(handles, count, wires.ptr, pub_ptr, ctypes.c_size_t(max_in), msgs_arg,
+                                                  lens_arg, _p(blinders), proofs))
+    else:
+        wires = np.ascontiguousarray(wires, dtype=np.uint64).reshape(-1)
+        if wires.size != count * NUM_WIRE_TYPES * n * 4:
+            raise ValueError("plonk_prove_multi: wires must hold count x 5 x n elements")
+        check(load().capgpu_plonk_prove_multi(handles, count, _p(wires), pub_ptr, ctypes.c_size_t(max_in), msgs_arg,
+                                              lens_arg, _p(blinders), proofs))
+    return list(proofs)
+
+
 def proof_to_arrays(pr: Proof) -> dict:
     """ctypes Proof -> dict of numpy arrays (Montgomery words)."""
     def a(x):

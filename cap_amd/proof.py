@@ -138,6 +138,17 @@ def prove_batch(proving_key: ProvingKey, wires: np.ndarray, public_inputs: np.nd
         raise TxnApiError.FailedSnark(f"Proof Creation failure: {e}") from e
 
 
+def prove_mixed(proving_keys, wires: np.ndarray, public_input_rows: np.ndarray, blinders: np.ndarray, ext_msgs=None):
+    """One proof per entry of `proving_keys` (keys of ONE domain size under ONE SRS, e.g. transfer 2x3 and freeze 3) in a
+    single device batch - the device-side form of the reference proving its transfer / mint / freeze notes side by side
+    (src/utils/params_builder.rs:194-226).  public_input_rows: (count, max inputs, 4); a key with fewer inputs uses the
+    first of its row."""
+    try:
+        return _lib.plonk_prove_multi([k.handle for k in proving_keys], wires, public_input_rows, blinders, ext_msgs)
+    except (_lib.CapGpuError, ValueError) as e:
+        raise TxnApiError.FailedSnark(f"Proof Creation failure: {e}") from e
+
+
 def verify(verifying_key: VerifyingKey, public_inputs: np.ndarray, proof, ext_msg: bytes | None = None) -> None:
     """src/proof/transfer.rs:192-212 / mint.rs:124-140 / freeze.rs:162-178: Ok(()) or TxnApiError::FailedSnark.
     Runs on the host (pairing check); it does not need the GPU."""

@@ -215,6 +215,20 @@ int capgpu_plonk_coalescing_stats(uint64_t* batches_out, uint64_t* proofs_out);
 int capgpu_plonk_prove_batch(uint64_t pk_handle, int count, const uint64_t* wires, const uint64_t* pub_inputs,
                              size_t num_inputs, const uint8_t* ext_msg, size_t ext_msg_len,
                              const uint64_t* blinders, capgpu_proof* proofs_out);
+/* Proofs of SEVERAL proving keys in one device batch: pk_handles[i] is the key of proof i.  The reference proves its
+ * transfer, mint and freeze notes side by side (TxnsParams::generate_txns, src/utils/params_builder.rs:194-226); on the
+ * device, proofs of different circuits over the same evaluation domain share every MSM and NTT launch.  All keys of a
+ * call must have the same domain size and come from the same SRS (CAPGPU_ERR_INVALID_ARG otherwise).  wires: count * 5
+ * * n field elements; pub_inputs: count rows of num_inputs elements, num_inputs = the largest public-input count among
+ * the keys - a key with fewer inputs uses the first of its row, the rest is ignored; ext_msgs / ext_msg_lens: one
+ * transcript init message per proof, or NULL; blinders: count * 13.  Every proof is bit-identical to the one
+ * capgpu_plonk_prove makes for the same inputs. */
+int capgpu_plonk_prove_multi(const uint64_t* pk_handles, int count, const uint64_t* wires, const uint64_t* pub_inputs,
+                             size_t num_inputs, const uint8_t* const* ext_msgs, const size_t* ext_msg_lens,
+                             const uint64_t* blinders, capgpu_proof* proofs_out);
+int capgpu_plonk_prove_multi_dev(const uint64_t* pk_handles, int count, const void* d_wires, const uint64_t* pub_inputs,
+                                 size_t num_inputs, const uint8_t* const* ext_msgs, const size_t* ext_msg_lens,
+                                 const uint64_t* blinders, capgpu_proof* proofs_out);
 /* Device-resident witness form used by the benchmark (inputs already in HBM). */
 int capgpu_plonk_prove_batch_dev(uint64_t pk_handle, int count, const void* d_wires, const uint64_t* pub_inputs,
                                  size_t num_inputs, const uint8_t* ext_msg, size_t ext_msg_len,

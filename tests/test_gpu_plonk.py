@@ -276,3 +276,54 @@ def test_concurrent_prove_calls_are_coalesced(cg, tau):
     assert p1 - p0 >= T - 1 and b1 - b0 <= 12, (b1 - b0, p1 - p0)      # a handful of device batches (typically 2-3), not 24
     cg.plonk_free_key(pkh)
     cg.srs_free(h)
+
+
+def test_proofs_of_several_keys_in_one_device_batch(cg, tau):
+    """capgpu_plonk_prove_multi: proofs of different circuits (keys) over one domain size share the device batch - what
+    the reference's side-by-side proving of transfer / mint / freeze notes (src/utils/params_builder.rs:194-226) becomes
+    on the device.  Every proof equals, bit for bit, the one its own key makes alone, whatever the order and the mix,
+    with per-proof messages and different numbers of public inputs; keys of another domain size are refused."""
+    log_n = 9
+    n = 1 << log_n
+    srs = cg.srs_generate(tau, n + 3)
+    shapes = [(3, 11), (9, 12), (0, 13)]              # (public inputs, circuit seed): three different circuits
+    circuits = [bu.synthetic_circuit(log_n, ni, seed=seed) for ni, seed in shapes]
+    keys = [cg.plonk_preprocess(srs, n, sc.num_inputs, sc.selectors_mont(), sc.sigma_mont()) for sc in circuits]
+    order = [0, 1, 1, 2, 0, 2, 1]
+    max_in = max(ni for ni, _ in shapes)
+    wires, rows, blinds, msgs, alone = [], [], [], [], []
+    for i, k in enumerate(order):
+        sc = circuits[k]
+        w, pubs = sc.witness(500 + i)
+        bl = bu.to_mont_array(bu.blinders(600 + i))
+        msg = b"note-%d" % i if i != 3 else b""
+        row = np.zeros((max_in, 4), np.uint64)
+        if pubs:
+            row[:len(pubs)] = bu.to_mont_array(pubs)
+        row[len(pubs):] = 0xFFFF                       # garbage beyond a key's own inputs must be ignored
+        wires.append(sc.wires_mont(w)); rows.append(row); blinds.append(bl); msgs.append(msg)
+        alone.append(cg.plonk_prove_batch(keys[k][0], sc.wires_mont(w)[None], pubs_arr(pubs)[None], bl[None],
+                                          msg or None, 1)[0])
+    handles = [keys[k][0] for k in order]
+    got = cg.plonk_prove_multi(handles, np.stack(wires), np.stack(rows), np.stack(blinds), msgs)
+    for i in range(len(order)):
+        assert bytes(got[i]) == bytes(alone[i]), i
+    # the same through the device-resident form
+    d = cg.DevBuf.from_numpy(np.stack(wires))
+    got_dev = cg.plonk_prove_multi(handles, d, np.stack(rows), np.stack(blinds), msgs)
+    assert [bytes(p) for p in got_dev] == [bytes(p) for p in alone]
+    d.free()
+    # and the product verifier accepts each under its own key
+    h2 = cg.g2_generator()
+    bh = cg.g2_mul(h2, tau)
+    for i, k in enumerate(order):
+        pubs = rows[i][:shapes[k][0]]
+        assert cg.plonk_verify(keys[k][1], h2, bh, pubs, got[i], msgs[i] or None)
+    # a key of another domain size cannot join the batch
+    sc_small = bu.synthetic_circuit(log_n - 1, 3, seed=5)
+    k_small = cg.plonk_preprocess(srs, n // 2, 3, sc_small.selectors_mont(), sc_small.sigma_mont())
+    with pytest.raises((cg.CapGpuError, ValueError)):
+        cg.plonk_prove_multi([handles[0], k_small[0]], np.stack(wires[:2]), np.stack(rows[:2]), np.stack(blinds[:2]))
+    for pkh, _ in keys + [k_small]:
+        cg.plonk_free_key(pkh)
+    cg.srs_free(srs)
