@@ -174,6 +174,7 @@ def test_mixed_batch_of_64_full_size(cg, tau):
     bh = cg.g2_mul(g2h, tau)
     all_vks, all_pubs, all_proofs, all_msgs = [], [], [], []
     keys = []
+    same_domain = []                               # (key, wires, pubs, blind, msg, proofs) of the groups on n = 2^15
     for gi, (kind, count) in enumerate(mix):
         sc = bu.note_circuit(kind, seed=40 + gi)
         pkh, vk = cg.plonk_preprocess(h, sc.n, sc.num_inputs, sc.selectors_mont(), sc.sigma_mont())
@@ -192,10 +193,21 @@ def test_mixed_batch_of_64_full_size(cg, tau):
         ck = cr.PlonkKey(srs_host[:sc.n + 3], sc.n, sc.num_inputs, sc.selectors_mont(), sc.sigma_mont())
         rc, comms, evals = ck.prove(wires[0], pubs[0], blind[0], msg)
         assert rc == 0 and H.proof_points(proofs[0]) == H.cref_proof_points(comms, evals), kind
+        if sc.n == n_max:
+            same_domain.append((pkh, wires, pubs, blind, msg, proofs))
         all_vks += [vk] * count
         all_pubs += [pubs[i] for i in range(count)]
         all_proofs += proofs
         all_msgs += [msg] * count
+    # the 32 transfers and the 19 freezes share the domain size: as ONE device batch of two keys they come out the same
+    assert len(same_domain) == 2
+    max_in = max(g[2].shape[1] for g in same_domain)
+    rows = np.concatenate([np.pad(g[2], ((0, 0), (0, max_in - g[2].shape[1]), (0, 0))) for g in same_domain])
+    multi = cg.plonk_prove_multi([g[0] for g in same_domain for _ in range(len(g[5]))],
+                                 np.concatenate([g[1] for g in same_domain]), rows,
+                                 np.concatenate([g[3] for g in same_domain]),
+                                 [g[4] for g in same_domain for _ in range(len(g[5]))])
+    assert [bytes(p) for p in multi] == [bytes(p) for g in same_domain for p in g[5]]
     # txn_batch_verify (src/lib.rs:455-529): one pairing product for all 64 proofs under three keys
     assert cg.plonk_batch_verify(all_vks, g2h, bh, all_pubs, all_proofs, all_msgs)
     swapped = list(all_proofs)
