@@ -778,6 +778,7 @@ void key_set_vk(ProvingKey& K, const std::vector<g1_affine>& ha) {
 // (capgpu_plonk_set_coalescing) the calls that arrive for the same proving key while the device is busy - or within a
 // short window - are gathered and proved as ONE device batch; every caller gets its own proof and its own error code.
 struct ProveReq {
+  uint64_t pk;
   const uint64_t* wires;
   const uint64_t* pubs;
   size_t num_inputs;
@@ -792,8 +793,12 @@ struct ProveReq {
 struct Coalescer {
   std::mutex mu;
   std::condition_variable cv;
-  std::map<uint64_t, std::vector<ProveReq*>> pending;  // per proving key
+  // Calls are gathered per GROUP of proving keys - the keys of one domain size under one SRS, which one device batch
+  // can mix (prove_batch) - so that the transfer, mint and freeze notes the reference proves concurrently
+  // (src/utils/params_builder.rs:194-226) end up in as few batches as their domain sizes allow.
+  std::map<uint64_t, std::vector<ProveReq*>> pending;  // per group
   std::map<uint64_t, bool> leader;
+  std::map<uint64_t, uint64_t> group_of;               // proving-key handle -> group id (handles are never reused)
   uint32_t window_us = 0;  // 0 = off
   uint32_t max_batch = 256;
   std::atomic<uint64_t> batches{0}, proofs{0};
@@ -1157,57 +1162,81 @@ int capgpu_plonk_prove_multi(const uint64_t* pk_handles, int count, const uint64
                                       blinders, proofs_out);
 }
 
-// one gathered batch: device staging of every request's wires, per-proof messages; a batch that fails because ONE
-// witness does not satisfy the circuit is re-run request by request so that only its owner sees the failure
-static void run_coalesced(uint64_t pk_handle, std::vector<ProveReq*>& reqs) {
+// one gathered batch: device staging of every request's wires, per-proof messages and keys; a batch that fails because
+// ONE witness does not satisfy its circuit is re-run request by request so that only its owner sees the failure
+static void run_coalesced(std::vector<ProveReq*>& reqs) {
   Context& c = ctx();
   std::lock_guard<std::recursive_mutex> lk(c.mu);
   auto fail_all = [&](int rc) {
     for (ProveReq* r : reqs) {
+      if (r->rc != CAPGPU_OK) continue;
       r->rc = rc;
       r->err = capgpu_last_error();
     }
   };
-  std::shared_ptr<ProvingKey> K;
-  int rc = lookup_key(pk_handle, &K);
-  if (rc) return fail_all(rc);
-  const size_t n = K->n, count = reqs.size(), ni = K->num_inputs;
-  for (ProveReq* r : reqs)
-    if (r->num_inputs != ni) {
-      set_error("capgpu_plonk_prove: %zu public inputs given, key expects %zu", r->num_inputs, ni);
-      r->rc = CAPGPU_ERR_INVALID_ARG;
-      r->err = capgpu_last_error();
-    }
   std::vector<ProveReq*> good;
-  for (ProveReq* r : reqs)
-    if (r->rc == CAPGPU_OK) good.push_back(r);
+  std::vector<std::shared_ptr<ProvingKey>> hold;
+  for (ProveReq* r : reqs) {
+    std::shared_ptr<ProvingKey> K;
+    int rc = lookup_key(r->pk, &K);
+    if (rc == CAPGPU_OK && r->num_inputs != K->num_inputs) {
+      set_error("capgpu_plonk_prove: %zu public inputs given, key expects %zu", r->num_inputs, K->num_inputs);
+      rc = CAPGPU_ERR_INVALID_ARG;
+    }
+    if (rc != CAPGPU_OK) {
+      r->rc = rc;
+      r->err = capgpu_last_error();
+      continue;
+    }
+    good.push_back(r);
+    hold.push_back(K);
+  }
   if (good.empty()) return;
-  const size_t g = good.size();
-  (void)count;
+  const size_t g = good.size(), n = hold[0]->n;
+  size_t ni = 0;  // row length of the public inputs: the largest count among the batch's keys
+  bool mixed = false;
+  for (size_t i = 0; i < g; i++) {
+    ni = std::max(ni, hold[i]->num_inputs);
+    mixed = mixed || hold[i].get() != hold[0].get();
+  }
+  bool recompute = false;
+  for (size_t i = 0; i < g; i++) recompute = recompute || hold[i]->recompute;
+  if (mixed && recompute) {  // the reference-schedule test mode keeps one key per batch: prove these one by one
+    for (size_t i = 0; i < g; i++) {
+      good[i]->rc = capgpu_plonk_prove_batch(good[i]->pk, 1, good[i]->wires, good[i]->pubs, good[i]->num_inputs,
+                                             good[i]->msg, good[i]->msg_len, good[i]->blinders, good[i]->out);
+      if (good[i]->rc) good[i]->err = capgpu_last_error();
+    }
+    coalescer().batches += g;
+    coalescer().proofs += g;
+    return;
+  }
   const size_t per = sizeof(fe) * NW * n;
-  rc = scratch_reserve(c.stage_b, per * g);
+  int rc = scratch_reserve(c.stage_b, per * g);
   if (rc) return fail_all(rc);
-  std::vector<uint64_t> pubs(4 * ni * g + 4), blind(4 * 13 * g);
+  std::vector<uint64_t> pubs(4 * ni * g + 4, 0), blind(4 * 13 * g);
   std::vector<const uint8_t*> msgs(g);
   std::vector<size_t> lens(g);
   std::vector<capgpu_proof> out(g);
+  std::vector<ProvingKey*> keys(g);
   for (size_t i = 0; i < g; i++) {
     hipError_t e = hipMemcpyAsync((char*)c.stage_b.p + per * i, good[i]->wires, per, hipMemcpyHostToDevice, c.stream);
     if (e != hipSuccess) return fail_all(hip_fail(e, "upload of wire columns"));
-    if (ni) memcpy(&pubs[4 * ni * i], good[i]->pubs, 32 * ni);
+    if (good[i]->num_inputs) memcpy(&pubs[4 * ni * i], good[i]->pubs, 32 * good[i]->num_inputs);
     memcpy(&blind[4 * 13 * i], good[i]->blinders, 32 * 13);
     msgs[i] = good[i]->msg;
     lens[i] = good[i]->msg_len;
+    keys[i] = hold[i].get();
   }
-  rc = prove_batch(*K, (uint32_t)g, (const fe*)c.stage_b.p, pubs.data(), ni, nullptr, 0, blind.data(), out.data(),
-                   msgs.data(), lens.data());
+  rc = prove_batch(*keys[0], (uint32_t)g, (const fe*)c.stage_b.p, pubs.data(), ni, nullptr, 0, blind.data(), out.data(),
+                   msgs.data(), lens.data(), mixed ? &keys : nullptr);
   if (rc == CAPGPU_OK) rc = take_launch_error();
   if (rc == CAPGPU_OK) {
     for (size_t i = 0; i < g; i++) *good[i]->out = out[i];
   } else if (rc == CAPGPU_ERR_PROOF && g > 1) {
     for (size_t i = 0; i < g; i++) {  // find the owner(s) of the unsatisfied witness
-      good[i]->rc = capgpu_plonk_prove_batch(pk_handle, 1, good[i]->wires, good[i]->pubs, ni, good[i]->msg,
-                                             good[i]->msg_len, good[i]->blinders, good[i]->out);
+      good[i]->rc = capgpu_plonk_prove_batch(good[i]->pk, 1, good[i]->wires, good[i]->pubs, good[i]->num_inputs,
+                                             good[i]->msg, good[i]->msg_len, good[i]->blinders, good[i]->out);
       if (good[i]->rc) good[i]->err = capgpu_last_error();
     }
   } else {
@@ -1231,20 +1260,38 @@ int capgpu_plonk_prove(uint64_t pk_handle, const uint64_t* wires, const uint64_t
     set_error("capgpu_plonk_prove: bad argument");
     return CAPGPU_ERR_INVALID_ARG;
   }
-  ProveReq req{wires, pub_inputs, num_inputs, ext_msg, ext_msg_len, blinders, proof_out};
+  ProveReq req{pk_handle, wires, pub_inputs, num_inputs, ext_msg, ext_msg_len, blinders, proof_out};
   std::unique_lock<std::mutex> lk(co.mu);
-  std::vector<ProveReq*>& q = co.pending[pk_handle];
+  uint64_t group = 0;
+  {
+    auto it = co.group_of.find(pk_handle);
+    if (it == co.group_of.end()) {
+      // first call for this key: its domain size and SRS make the group (the lookup takes the process lock, which a
+      // running batch holds - once per key)
+      lk.unlock();
+      size_t kn = 0;
+      uint64_t ksrs = 0;
+      int rc = capgpu_plonk_key_info(pk_handle, &kn, nullptr, &ksrs);
+      if (rc) return rc;
+      lk.lock();
+      group = (ksrs << 8) ^ (uint64_t)__builtin_ctzll(kn | (1ull << 63));
+      co.group_of[pk_handle] = group;
+    } else {
+      group = it->second;
+    }
+  }
+  std::vector<ProveReq*>& q = co.pending[group];
   q.push_back(&req);
   if (q.size() >= co.max_batch) co.cv.notify_all();
   bool waited_window = false;
   while (!req.done) {
     const bool queued = std::find(q.begin(), q.end(), &req) != q.end();
-    if (co.leader[pk_handle] || !queued) {  // somebody is gathering / proving a batch that holds (or will hold) this request
+    if (co.leader[group] || !queued) {  // somebody is gathering / proving a batch that holds (or will hold) this request
       co.cv.wait_for(lk, std::chrono::milliseconds(1), [&] { return req.done; });
       continue;
     }
-    // this thread leads the key's next batch: collect for the window, and for as long as the device is busy
-    co.leader[pk_handle] = true;
+    // this thread leads the group's next batch: collect for the window, and for as long as the device is busy
+    co.leader[group] = true;
     if (!waited_window) {
       // the window restarts while calls keep arriving (threads released by the previous batch come back one by one),
       // up to 16 windows in all
@@ -1261,9 +1308,9 @@ int capgpu_plonk_prove(uint64_t pk_handle, const uint64_t* wires, const uint64_t
     const size_t take = std::min<size_t>(q.size(), co.max_batch);
     std::vector<ProveReq*> reqs(q.begin(), q.begin() + take);
     q.erase(q.begin(), q.begin() + take);
-    co.leader[pk_handle] = false;
+    co.leader[group] = false;
     lk.unlock();
-    run_coalesced(pk_handle, reqs);  // re-enters the (recursive) process lock this thread holds
+    run_coalesced(reqs);  // re-enters the (recursive) process lock this thread holds
     c.mu.unlock();
     lk.lock();
     for (ProveReq* r : reqs) r->done = true;

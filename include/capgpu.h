@@ -203,7 +203,8 @@ int capgpu_plonk_prove(uint64_t pk_handle, const uint64_t* wires, const uint64_t
                        const uint8_t* ext_msg, size_t ext_msg_len, const uint64_t* blinders, capgpu_proof* proof_out);
 /* Coalescing of concurrent capgpu_plonk_prove calls (off by default).  The reference proves notes from many rayon
  * worker threads, one prove() per note (src/utils/params_builder.rs:194-226); behind one device those calls would run
- * one after the other at single-proof latency.  With window_us > 0, calls for the same proving key that arrive within
+ * one after the other at single-proof latency.  With window_us > 0, calls for proving keys of one domain size under one
+ * SRS (the notes of different kinds the reference proves side by side share batches) that arrive within
  * window_us microseconds of each other (the window restarts with every arrival, 16 windows at most) - or while the
  * device is busy with a previous batch - are gathered (up to max_batch; 0 = 256) and proved as ONE device batch; each caller receives its own proof and its own return code
  * (an unsatisfied witness fails only its owner).  window_us = 0 switches it off. */

@@ -327,3 +327,50 @@ def test_proofs_of_several_keys_in_one_device_batch(cg, tau):
     for pkh, _ in keys + [k_small]:
         cg.plonk_free_key(pkh)
     cg.srs_free(srs)
+
+
+def test_concurrent_calls_for_different_keys_share_device_batches(cg, tau):
+    """Coalescing gathers per (domain size, SRS), not per key: threads proving notes of three different circuits at once
+    (the reference's generate_txns does exactly that) are served by a few mixed-key device batches, a circuit of another
+    domain size by its own, and every caller still gets the proof a lone call gives."""
+    import threading
+    srs = cg.srs_generate(tau, (1 << 9) + 3)
+    specs = [(9, 3, 21), (9, 8, 22), (9, 0, 23), (8, 2, 24)]          # (log n, public inputs, seed); the last: another domain
+    circuits = [bu.synthetic_circuit(ln, ni, seed=sd) for ln, ni, sd in specs]
+    keys = [cg.plonk_preprocess(srs, sc.n, sc.num_inputs, sc.selectors_mont(), sc.sigma_mont())[0] for sc in circuits]
+    T = 20
+    args = []
+    for t in range(T):
+        k = t % len(circuits)
+        w, pubs = circuits[k].witness(700 + t)
+        args.append((keys[k], circuits[k].wires_mont(w), pubs_arr(pubs), bu.to_mont_array(bu.blinders(800 + t)),
+                     b"m%d" % t if t % 2 else None))
+    alone = [cg.plonk_prove(*a) for a in args]
+    cg.plonk_set_coalescing(3000, 64)
+    b0, p0 = cg.plonk_coalescing_stats()
+    results = [None] * T
+    start = threading.Barrier(T)
+
+    def worker(t):
+        start.wait()
+        try:
+            results[t] = cg.plonk_prove(*args[t])
+        except Exception as e:                                      # noqa: BLE001
+            results[t] = e
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(T)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join(timeout=300)
+    cg.plonk_set_coalescing(0)
+    b1, p1 = cg.plonk_coalescing_stats()
+    for t in range(T):
+        assert not isinstance(results[t], Exception), (t, results[t])
+        assert bytes(results[t]) == bytes(alone[t]), t
+    # 15 calls on n = 2^9 under three keys and 5 on n = 2^8: with per-key queues that would be at least four batches per
+    # round of arrivals; mixed-key batches need two
+    assert p1 - p0 == T and b1 - b0 <= 8, (b1 - b0, p1 - p0)
+    for k in keys:
+        cg.plonk_free_key(k)
+    cg.srs_free(srs)
