@@ -115,11 +115,25 @@ int capgpu_pairing_check(const uint64_t* g1_points, const uint64_t* g2_points, s
   return CAPGPU_OK;
 }
 
-// Everything of the verifier up to the pairing: on success *valid = 1 and the proof holds iff
-// e(A, [tau]H) == e(B, H); *valid = 0 means the proof is already known to be invalid.
-static int verifier_prepare(const capgpu_verifying_key* vk, const uint64_t* pub_inputs, size_t num_inputs,
-                            const capgpu_proof* proof, const uint8_t* ext_msg, size_t ext_msg_len, g1_affine* a_out,
-                            g1_affine* b_out, int* valid) {
+// The pairing inputs of one proof as linear combinations of group elements: A = sum a[k].s * a[k].p, likewise B, and the
+// proof holds iff e(A, [tau]H) == e(B, H).  Kept as (point, scalar) terms so that the caller chooses how to evaluate
+// them: the single verifier and the host batch verifier multiply on the CPU, capgpu_plonk_batch_verify_dev hands the
+// terms of the whole batch to the device MSM (K3-K6).  `u` is the last transcript challenge: it depends on every byte
+// of the statement and the proof.
+struct Term {
+  g1_affine p;
+  fe s;  // Montgomery
+};
+struct ProofTerms {
+  std::vector<Term> a, b;
+  fe u;
+};
+
+// Everything of the verifier up to the group arithmetic: on success *valid = 1 and `out` holds the terms; *valid = 0
+// means the proof is already known to be invalid.
+static int verifier_terms(const capgpu_verifying_key* vk, const uint64_t* pub_inputs, size_t num_inputs,
+                          const capgpu_proof* proof, const uint8_t* ext_msg, size_t ext_msg_len, ProofTerms* out,
+                          int* valid) {
   const uint64_t n = vk->domain_size;
   if (n < 4 || (n & (n - 1)) || num_inputs != vk->num_inputs) {
     set_error("capgpu_plonk_verify: %zu public inputs given, key expects %llu (domain %llu)", num_inputs,
@@ -224,8 +238,10 @@ static int verifier_prepare(const capgpu_verifying_key* vk, const uint64_t* pub_
   const fe r0 = Fr::sub(Fr::sub(pi, Fr::mul(alpha2, l1)), tt);
 
   // ---- D: commitment of the linearisation polynomial -----------------------------------------------------------
-  g1_xyzz acc = G1::inf();
-  auto add_term = [&](const g1_affine& c, const fe& s) { acc = G1::add(acc, g1_smul(c, s)); };
+  out->a.clear();
+  out->b.clear();
+  out->b.reserve(34);
+  auto add_term = [&](const g1_affine& c, const fe& s) { out->b.push_back(Term{c, s}); };
   for (int j = 0; j < 4; j++) add_term(sel[j], we[j]);
   const fe w01 = Fr::mul(we[0], we[1]), w23 = Fr::mul(we[2], we[3]);
   add_term(sel[4], w01);
@@ -235,7 +251,7 @@ static int verifier_prepare(const capgpu_verifying_key* vk, const uint64_t* pub_
     add_term(sel[6 + j], Fr::mul(Fr::sqr(w2), we[j]));
   }
   add_term(sel[10], Fr::neg(we[4]));
-  acc = G1::add_mixed(acc, sel[11]);
+  add_term(sel[11], one);
   add_term(sel[12], Fr::mul(Fr::mul(w01, w23), we[4]));
   fe bz = Fr::mul(beta, zeta), cz = alpha;
   for (int j = 0; j < kNumWires; j++) cz = Fr::mul(cz, Fr::add(Fr::add(we[j], gamma), Fr::mul(kk[j], bz)));
@@ -264,16 +280,81 @@ static int verifier_prepare(const capgpu_verifying_key* vk, const uint64_t* pub_
   add_term(zc, u);
   e_acc = Fr::add(e_acc, Fr::mul(u, znext));
   // A = W_zeta + u W_zetaw ;  B = zeta W_zeta + u zeta omega W_zetaw + F - E G
-  g1_xyzz a_pt = G1::add(G1::from_affine(w_zeta), g1_smul(w_zeta_w, u));
+  out->a.push_back(Term{w_zeta, one});
+  out->a.push_back(Term{w_zeta_w, u});
   g1_affine gen;
   gen.x = Fq::one();
   gen.y = Fq::dbl(Fq::one());
-  g1_xyzz b_pt = G1::add(g1_smul(w_zeta, zeta), g1_smul(w_zeta_w, Fr::mul(Fr::mul(u, zeta), omega)));
-  b_pt = G1::add(b_pt, acc);
-  b_pt = G1::add(b_pt, g1_smul(gen, Fr::neg(e_acc)));
-  *a_out = G1::to_affine(a_pt);
-  *b_out = G1::to_affine(b_pt);
+  add_term(w_zeta, zeta);
+  add_term(w_zeta_w, Fr::mul(Fr::mul(u, zeta), omega));
+  add_term(gen, Fr::neg(e_acc));
+  out->u = u;
   *valid = 1;
+  return CAPGPU_OK;
+}
+
+// sum weight * t.s * t.p on the host
+static g1_xyzz eval_terms_host(const std::vector<Term>& terms, const fe* weight) {
+  g1_xyzz acc = G1::inf();
+  const fe one = Fr::one();
+  for (const Term& t : terms) {
+    const fe sc = weight ? Fr::mul(*weight, t.s) : t.s;
+    if (Fr::eq(sc, one)) acc = G1::add_mixed(acc, t.p);
+    else acc = G1::add(acc, g1_smul(t.p, sc));
+  }
+  return acc;
+}
+
+// Weights of the random linear combination of a batch: r_0 = 1, r_i = challenges of a transcript over every proof's
+// last challenge u_i (each of which already binds its statement and proof).
+static std::vector<fe> batch_weights(const std::vector<ProofTerms>& pt) {
+  SolidityTranscript seed;
+  for (const ProofTerms& t : pt) append_fr(seed, t.u);
+  std::vector<fe> rs(pt.size());
+  for (size_t i = 0; i < pt.size(); i++) rs[i] = i == 0 ? Fr::one() : get_challenge(seed);
+  return rs;
+}
+
+// terms of every proof of a batch, in parallel on host threads; returns a negative code for malformed arguments,
+// *all_valid = 0 when some proof is already known to be invalid
+static int batch_terms(const capgpu_verifying_key* const* vks, const uint64_t* const* pub_inputs,
+                       const size_t* num_inputs, const capgpu_proof* const* proofs, const uint8_t* const* ext_msgs,
+                       const size_t* ext_msg_lens, size_t count, std::vector<ProofTerms>* out, int* all_valid) {
+  out->assign(count, ProofTerms{});
+  std::vector<int> rcs(count, CAPGPU_OK), valids(count, 0);
+  for (size_t i = 0; i < count; i++)
+    if (!vks[i] || !proofs[i] || (num_inputs[i] && !pub_inputs[i])) return CAPGPU_ERR_INVALID_ARG;
+  auto prepare = [&](size_t i) {
+    rcs[i] = verifier_terms(vks[i], pub_inputs[i], num_inputs[i], proofs[i], ext_msgs ? ext_msgs[i] : nullptr,
+                            (ext_msgs && ext_msg_lens) ? ext_msg_lens[i] : 0, &(*out)[i], &valids[i]);
+  };
+  const unsigned nt = (unsigned)std::min<size_t>(count, std::max(1u, std::min(std::thread::hardware_concurrency(), 32u)));
+  if (nt <= 1) {
+    for (size_t i = 0; i < count; i++) prepare(i);
+  } else {
+    std::atomic<size_t> next{0};
+    std::vector<std::thread> th;
+    auto work = [&] {
+      for (;;) {
+        size_t i = next.fetch_add(1);
+        if (i >= count) break;
+        prepare(i);
+      }
+    };
+    for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
+    work();
+    for (auto& t : th) t.join();
+  }
+  *all_valid = 1;
+  for (size_t i = 0; i < count; i++) {
+    if (rcs[i]) {  // the message was recorded on a worker thread: redo the failing one here for this thread's string
+      int v = 0;
+      ProofTerms scratch;
+      return verifier_terms(vks[i], pub_inputs[i], num_inputs[i], proofs[i], ext_msgs ? ext_msgs[i] : nullptr,
+                            (ext_msgs && ext_msg_lens) ? ext_msg_lens[i] : 0, &scratch, &v);
+    }
+    if (!valids[i]) *all_valid = 0;
+  }
   return CAPGPU_OK;
 }
 
@@ -298,10 +379,11 @@ int capgpu_plonk_verify(const capgpu_verifying_key* vk, const uint64_t g2_h[16],
   g2_affine h, beta_h;
   int rc = load_open_key(g2_h, g2_beta_h, &h, &beta_h);
   if (rc) return rc;
-  g1_affine a, b;
+  ProofTerms pt;
   int valid = 0;
-  rc = verifier_prepare(vk, pub_inputs, num_inputs, proof, ext_msg, ext_msg_len, &a, &b, &valid);
+  rc = verifier_terms(vk, pub_inputs, num_inputs, proof, ext_msg, ext_msg_len, &pt, &valid);
   if (rc || !valid) return rc;
+  g1_affine a = G1::to_affine(eval_terms_host(pt.a, nullptr)), b = G1::to_affine(eval_terms_host(pt.b, nullptr));
   // e(A, [tau]H) == e(B, H)   <=>   e(A, [tau]H) e(-B, H) == 1
   b.y = Fq::neg(b.y);
   std::vector<std::pair<g1_affine, g2_affine>> pairs = {{a, beta_h}, {b, h}};
@@ -310,8 +392,9 @@ int capgpu_plonk_verify(const capgpu_verifying_key* vk, const uint64_t g2_h[16],
 }
 
 // Replaces PlonkKzgSnark::batch_verify as used by txn_batch_verify (src/lib.rs:455-529, call at :517-522): the
-// per-proof pairing inputs (A_i, B_i) are folded with pseudo-random weights r_i (Keccak of all of them) and one
-// pairing product decides the whole batch.  Proofs may belong to different circuits / keys of one SRS.
+// per-proof pairing inputs (A_i, B_i) are folded with pseudo-random weights r_i and one pairing product decides the
+// whole batch.  Proofs may belong to different circuits / keys of one SRS.  Host only: the ~35 scalar multiplications of
+// each proof go to a pool of host threads.
 int capgpu_plonk_batch_verify(const capgpu_verifying_key* const* vks, const uint64_t g2_h[16],
                               const uint64_t g2_beta_h[16], const uint64_t* const* pub_inputs,
                               const size_t* num_inputs, const capgpu_proof* const* proofs,
@@ -328,64 +411,103 @@ int capgpu_plonk_batch_verify(const capgpu_verifying_key* const* vks, const uint
     *ok_out = 1;
     return CAPGPU_OK;
   }
-  // Everything up to the pairing is independent per proof (the reference runs it under rayon): the ~27 scalar
-  // multiplications of each proof go to a pool of host threads.  (They are variable-base - proof and key points differ
-  // per proof - so the device's fixed-base window tables do not apply; at the reference's batch sizes this is
-  // milliseconds of host work, the pairing product dominates.)
-  std::vector<g1_affine> as(count), bs(count);
-  std::vector<int> rcs(count, CAPGPU_OK), valids(count, 0);
-  for (size_t i = 0; i < count; i++)
-    if (!vks[i] || !proofs[i] || (num_inputs[i] && !pub_inputs[i])) return CAPGPU_ERR_INVALID_ARG;
-  auto prepare = [&](size_t i) {
-    rcs[i] = verifier_prepare(vks[i], pub_inputs[i], num_inputs[i], proofs[i], ext_msgs ? ext_msgs[i] : nullptr,
-                              (ext_msgs && ext_msg_lens) ? ext_msg_lens[i] : 0, &as[i], &bs[i], &valids[i]);
-  };
-  const unsigned nt = (unsigned)std::min<size_t>(count, std::max(1u, std::min(std::thread::hardware_concurrency(), 32u)));
-  auto run_parallel = [&](const std::function<void(size_t)>& fn) {
-    if (nt <= 1) {
-      for (size_t i = 0; i < count; i++) fn(i);
-      return;
-    }
+  std::vector<ProofTerms> pt;
+  int all_valid = 0;
+  rc = batch_terms(vks, pub_inputs, num_inputs, proofs, ext_msgs, ext_msg_lens, count, &pt, &all_valid);
+  if (rc || !all_valid) return rc;
+  const std::vector<fe> rs = batch_weights(pt);
+  std::vector<g1_xyzz> ra(count), rb(count);
+  {
+    const unsigned nt = (unsigned)std::min<size_t>(count, std::max(1u, std::min(std::thread::hardware_concurrency(), 32u)));
     std::atomic<size_t> next{0};
-    std::vector<std::thread> th;
     auto work = [&] {
       for (;;) {
         size_t i = next.fetch_add(1);
         if (i >= count) break;
-        fn(i);
+        ra[i] = eval_terms_host(pt[i].a, &rs[i]);
+        rb[i] = eval_terms_host(pt[i].b, &rs[i]);
       }
     };
+    std::vector<std::thread> th;
     for (unsigned t = 1; t < nt; t++) th.emplace_back(work);
     work();
     for (auto& t : th) t.join();
-  };
-  run_parallel(prepare);
-  for (size_t i = 0; i < count; i++) {
-    if (rcs[i]) {  // the message was recorded on a worker thread: redo the failing one here for this thread's string
-      int v = 0;
-      return verifier_prepare(vks[i], pub_inputs[i], num_inputs[i], proofs[i], ext_msgs ? ext_msgs[i] : nullptr,
-                              (ext_msgs && ext_msg_lens) ? ext_msg_lens[i] : 0, &as[i], &bs[i], &v);
-    }
-    if (!valids[i]) return CAPGPU_OK;
   }
-  SolidityTranscript seed;
-  for (size_t i = 0; i < count; i++) {
-    append_g1(seed, as[i]);
-    append_g1(seed, bs[i]);
-  }
-  std::vector<fe> rs(count);
-  for (size_t i = 0; i < count; i++) rs[i] = i == 0 ? Fr::one() : get_challenge(seed);
-  std::vector<g1_xyzz> ra(count), rb(count);
-  run_parallel([&](size_t i) {
-    ra[i] = g1_smul(as[i], rs[i]);
-    rb[i] = g1_smul(bs[i], rs[i]);
-  });
   g1_xyzz a_sum = G1::inf(), b_sum = G1::inf();
   for (size_t i = 0; i < count; i++) {
     a_sum = G1::add(a_sum, ra[i]);
     b_sum = G1::add(b_sum, rb[i]);
   }
   g1_affine a = G1::to_affine(a_sum), b = G1::to_affine(b_sum);
+  b.y = Fq::neg(b.y);
+  std::vector<std::pair<g1_affine, g2_affine>> pairs = {{a, beta_h}, {b, h}};
+  *ok_out = pairing::pairing_product_is_one(pairs) ? 1 : 0;
+  return CAPGPU_OK;
+}
+
+// The same predicate with the group arithmetic on the device: the (point, scalar) terms of ALL proofs - 35 per proof,
+// the weight r_i folded into the scalars - are two multi-scalar multiplications, run by the MSM kernels of the prover
+// (K3-K6; the bases are uploaded like an SRS, their window tables built on the device).  SURVEY 8f row 4.  Needs an
+// initialised library (CAPGPU_ERR_NOT_INITIALISED otherwise - there is no silent host path behind this entry point);
+// the transcript work per proof and the final pairing product stay on the host.  Accepts and rejects exactly what
+// capgpu_plonk_batch_verify does: both evaluate the same terms with the same weights.
+int capgpu_plonk_batch_verify_dev(const capgpu_verifying_key* const* vks, const uint64_t g2_h[16],
+                                  const uint64_t g2_beta_h[16], const uint64_t* const* pub_inputs,
+                                  const size_t* num_inputs, const capgpu_proof* const* proofs,
+                                  const uint8_t* const* ext_msgs, const size_t* ext_msg_lens, size_t count,
+                                  int* ok_out) {
+  if (!ok_out || !g2_h || !g2_beta_h || (count && (!vks || !pub_inputs || !num_inputs || !proofs))) {
+    set_error("capgpu_plonk_batch_verify_dev: bad argument");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  *ok_out = 0;
+  int rc = capgpu_device_info(nullptr, nullptr, nullptr);  // fails loudly without an initialised device
+  if (rc) return rc;
+  g2_affine h, beta_h;
+  rc = load_open_key(g2_h, g2_beta_h, &h, &beta_h);
+  if (rc) return rc;
+  if (count == 0) {
+    *ok_out = 1;
+    return CAPGPU_OK;
+  }
+  std::vector<ProofTerms> pt;
+  int all_valid = 0;
+  rc = batch_terms(vks, pub_inputs, num_inputs, proofs, ext_msgs, ext_msg_lens, count, &pt, &all_valid);
+  if (rc || !all_valid) return rc;
+  const std::vector<fe> rs = batch_weights(pt);
+  // bases: all A terms, then all B terms; scalars canonical (what the MSM entry point takes)
+  size_t na = 0, nb = 0;
+  for (const ProofTerms& t : pt) {
+    na += t.a.size();
+    nb += t.b.size();
+  }
+  std::vector<uint64_t> bases(8 * (na + nb)), scalars(4 * (na + nb));
+  size_t ia = 0, ib = na;
+  for (size_t i = 0; i < count; i++) {
+    auto put = [&](size_t at, const Term& t) {
+      fe_to_words(t.p.x, &bases[8 * at]);
+      fe_to_words(t.p.y, &bases[8 * at + 4]);
+      fe_to_words(Fr::from_mont(Fr::mul(rs[i], t.s)), &scalars[4 * at]);
+    };
+    for (const Term& t : pt[i].a) put(ia++, t);
+    for (const Term& t : pt[i].b) put(ib++, t);
+  }
+  uint64_t hbases = 0;
+  rc = capgpu_srs_upload(bases.data(), na + nb, 64, 1, &hbases);
+  if (rc) return rc;
+  uint64_t a_xyz[12], b_xyz[12];
+  rc = capgpu_msm_g1(hbases, 0, scalars.data(), na, a_xyz);
+  if (rc == CAPGPU_OK) rc = capgpu_msm_g1(hbases, na, scalars.data() + 4 * na, nb, b_xyz);
+  capgpu_srs_free(hbases);
+  if (rc) return rc;
+  auto to_affine = [](const uint64_t w[12]) {
+    g1_jac j;
+    j.x = fe_from_words(w);
+    j.y = fe_from_words(w + 4);
+    j.z = fe_from_words(w + 8);
+    return G1::jac_to_affine(j);
+  };
+  g1_affine a = to_affine(a_xyz), b = to_affine(b_xyz);
   b.y = Fq::neg(b.y);
   std::vector<std::pair<g1_affine, g2_affine>> pairs = {{a, beta_h}, {b, h}};
   *ok_out = pairing::pairing_product_is_one(pairs) ? 1 : 0;

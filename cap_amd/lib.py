@@ -509,7 +509,10 @@ def plonk_verify(vk: VerifyingKey, g2_h: np.ndarray, g2_beta_h: np.ndarray, pub_
     return bool(ok.value)
 
 
-def plonk_batch_verify(vks, g2_h: np.ndarray, g2_beta_h: np.ndarray, pub_inputs_list, proofs, ext_msgs=None) -> bool:
+def plonk_batch_verify(vks, g2_h: np.ndarray, g2_beta_h: np.ndarray, pub_inputs_list, proofs, ext_msgs=None,
+                       on_device: bool = False) -> bool:
+    """One pairing product for all proofs.  on_device: the group arithmetic (two MSMs over ~35 terms per proof) runs on
+    the GPU through the prover's MSM kernels (capgpu_plonk_batch_verify_dev; needs init()), otherwise on host threads."""
     cnt = len(proofs)
     vk_arr = (ctypes.POINTER(VerifyingKey) * cnt)(*[ctypes.pointer(v) for v in vks])
     pubs = [np.ascontiguousarray(p, dtype=np.uint64).reshape(-1) for p in pub_inputs_list]
@@ -521,9 +524,10 @@ def plonk_batch_verify(vks, g2_h: np.ndarray, g2_beta_h: np.ndarray, pub_inputs_
     msg_arr = (ctypes.POINTER(ctypes.c_uint8) * cnt)(*[ctypes.cast(b, ctypes.POINTER(ctypes.c_uint8)) for b in bufs])
     len_arr = (ctypes.c_size_t * cnt)(*[len(m) for m in msgs])
     ok = ctypes.c_int(0)
-    check(load().capgpu_plonk_batch_verify(vk_arr, _p(np.ascontiguousarray(g2_h, dtype=np.uint64)),
-                                           _p(np.ascontiguousarray(g2_beta_h, dtype=np.uint64)), pub_arr, nin, pr_arr,
-                                           msg_arr, len_arr, ctypes.c_size_t(cnt), ctypes.byref(ok)))
+    fn = load().capgpu_plonk_batch_verify_dev if on_device else load().capgpu_plonk_batch_verify
+    check(fn(vk_arr, _p(np.ascontiguousarray(g2_h, dtype=np.uint64)),
+             _p(np.ascontiguousarray(g2_beta_h, dtype=np.uint64)), pub_arr, nin, pr_arr,
+             msg_arr, len_arr, ctypes.c_size_t(cnt), ctypes.byref(ok)))
     return bool(ok.value)
 
 

@@ -256,6 +256,15 @@ int capgpu_plonk_batch_verify(const capgpu_verifying_key* const* vks, const uint
                               const uint64_t g2_beta_h[16], const uint64_t* const* pub_inputs,
                               const size_t* num_inputs, const capgpu_proof* const* proofs,
                               const uint8_t* const* ext_msgs, const size_t* ext_msg_lens, size_t count, int* ok_out);
+/* The same predicate with its group arithmetic on the device: the ~35 (point, scalar) terms of every
+ * proof, weights folded in, are two multi-scalar multiplications on the prover's MSM kernels (the bases are uploaded
+ * like an SRS and their window tables built on the device); the transcripts and the final pairing product stay on the
+ * host.  Accepts and rejects exactly what capgpu_plonk_batch_verify does.  Needs capgpu_init
+ * (CAPGPU_ERR_NOT_INITIALISED otherwise: no host path hides behind this entry point). */
+int capgpu_plonk_batch_verify_dev(const capgpu_verifying_key* const* vks, const uint64_t g2_h[16],
+                                  const uint64_t g2_beta_h[16], const uint64_t* const* pub_inputs,
+                                  const size_t* num_inputs, const capgpu_proof* const* proofs,
+                                  const uint8_t* const* ext_msgs, const size_t* ext_msg_lens, size_t count, int* ok_out);
 /* ark-serialize 0.3 CanonicalSerialize bytes of the Proof as it sits inside a TransferNote / MintNote / FreezeNote
  * (src/transfer.rs:60): compressed G1 (32 B), Fr little-endian, Vec = u64 length prefix, plookup_proof = None.
  * 769 bytes; *len_out receives the size. */

@@ -213,6 +213,12 @@ def test_mixed_batch_of_64_full_size(cg, tau):
     swapped = list(all_proofs)
     swapped[0], swapped[1] = swapped[1], swapped[0]
     assert not cg.plonk_batch_verify(all_vks, g2h, bh, all_pubs, swapped, all_msgs)
+    # the same with the group arithmetic on the device (two MSMs of 64 x 2 and 64 x 33 terms on the prover's kernels)
+    assert cg.plonk_batch_verify(all_vks, g2h, bh, all_pubs, all_proofs, all_msgs, on_device=True)
+    assert not cg.plonk_batch_verify(all_vks, g2h, bh, all_pubs, swapped, all_msgs, on_device=True)
+    wrong = [p.copy() for p in all_pubs]
+    wrong[40][0, 0] ^= 1
+    assert not cg.plonk_batch_verify(all_vks, g2h, bh, wrong, all_proofs, all_msgs, on_device=True)
     for k in keys:
         cg.plonk_free_key(k)
     cg.srs_free(h)

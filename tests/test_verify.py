@@ -236,6 +236,12 @@ def test_batch_verify_and_proof_serialization(tau):
     assert not cg.plonk_batch_verify(vks, h2, bh, [pubs_l[0], bad], proofs, msgs)
     assert not cg.plonk_batch_verify(vks, h2, bh, pubs_l, proofs, [msgs[0], b"x"])
     assert not cg.plonk_batch_verify(vks, h2, bh, pubs_l, [proofs[0], proofs[0]], msgs)
+    # the device form of the batch verifier has no host path behind it: without an initialised GPU it says so
+    import torch
+    if not torch.cuda.is_available():
+        with pytest.raises(cg.CapGpuError) as e:
+            cg.plonk_batch_verify(vks, h2, bh, pubs_l, proofs, msgs, on_device=True)
+        assert e.value.code in (-6, -2)
     # ark-serialize bytes of the proof = what the oracle's encoders give
     op = oproofs[0]
     exp = (5).to_bytes(8, "little") + b"".join(bn.g1_serialize_compressed(p) for p in op.wires_poly_comms)
