@@ -363,6 +363,39 @@ inline Result<Unit> verify(const FreezeVerifyingKey& vk, const std::vector<Fr>& 
 }  // namespace freeze
 }  // namespace proof
 
+// txn_batch_verify's SNARK part (src/lib.rs:455-529, PlonkKzgSnark::batch_verify at :517-522): one pairing product for
+// proofs of different keys under one SRS.  on_device: the group arithmetic runs on the GPU (capgpu_plonk_batch_verify_dev).
+struct BatchItem {
+  const VerifyingKey* verifying_key;
+  const std::vector<Fr>* public_inputs;
+  const Proof* proof;
+  const std::vector<uint8_t>* ext_msg;  // the bound message of that note (may be null)
+};
+inline Result<Unit> batch_verify(const std::vector<BatchItem>& items, bool on_device = false) {
+  if (items.empty()) return Unit{};
+  std::vector<const capgpu_verifying_key*> vks;
+  std::vector<const uint64_t*> pubs;
+  std::vector<size_t> nin, lens;
+  std::vector<const capgpu_proof*> proofs;
+  std::vector<const uint8_t*> msgs;
+  for (const BatchItem& it : items) {
+    vks.push_back(&it.verifying_key->raw);
+    pubs.push_back(it.public_inputs->empty() ? nullptr : (*it.public_inputs)[0].data());
+    nin.push_back(it.public_inputs->size());
+    proofs.push_back(it.proof);
+    msgs.push_back(it.ext_msg && !it.ext_msg->empty() ? it.ext_msg->data() : nullptr);
+    lens.push_back(it.ext_msg ? it.ext_msg->size() : 0);
+  }
+  const VerifyingKey& k0 = *items[0].verifying_key;
+  int ok = 0;
+  auto fn = on_device ? capgpu_plonk_batch_verify_dev : capgpu_plonk_batch_verify;
+  int rc = fn(vks.data(), k0.h.data(), k0.beta_h.data(), pubs.data(), nin.data(), proofs.data(), msgs.data(), lens.data(),
+              items.size(), &ok);
+  if (rc != CAPGPU_OK) return detail::map_error(rc, "Batch Proof Verification failure");
+  if (!ok) return TxnApiError::failed_snark("Batch Proof Verification failure: WrongProof");
+  return Unit{};
+}
+
 // `Proof` inside a note is ark-serialize bytes (src/transfer.rs:60): CanonicalSerialize / CanonicalDeserialize
 inline Result<std::vector<uint8_t>> serialize(const Proof& p) {
   std::vector<uint8_t> out(1024);

@@ -235,6 +235,17 @@ int main(int argc, char** argv) {
                .is_err());
     ASSERT(pre.unwrap().proving_key.num_input == 2);
   }
+  // txn_batch_verify's SNARK part: both proofs (two keys, one SRS) under one pairing product, host and device forms
+  {
+    const std::vector<uint8_t> msg = proof::detail_snark::bound_message(recv_memos_ver_key, extra_proof_bound_data);
+    std::vector<BatchItem> items = {{&verifying_key_1.verifying_key, &pub_input_1, &validity_proof_1.unwrap(), &msg},
+                                    {&verifying_key_2.verifying_key, &pub_input_2, &validity_proof_2.unwrap(), &msg}};
+    ASSERT(batch_verify(items).is_ok());
+    ASSERT(batch_verify(items, true).is_ok());
+    std::swap(items[0].proof, items[1].proof);
+    ASSERT(batch_verify(items).is_err());
+    ASSERT(batch_verify(items, true).is_err());
+  }
   // a circuit larger than the universal parameters is refused at preprocessing, as Err
   {
     auto small = proof::universal_setup(in2.n / 2, in1.tau);
