@@ -486,7 +486,7 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
 
   // ---- round 2: permutation grand product --------------------------------------------------------------
   launch("k_perm_numden", k_perm_numden, dim3(cdiv(n, kThreads), P), dim3(kThreads), 0, s, d_wires,
-         (const fe*)K.sig_eval, sig_of, (const fe*)dom_n->tw_fwd, (const Chal*)w.chal, K.qc, n, w.num, w.den);
+         (const fe*)K.sig_eval, sig_of, (const fe*)dom_n->tw_fwd, (const Chal*)w.chal, K.qc29, n, w.num, w.den);
   {
     uint32_t nb = cdiv(n, kScanBlock);
     scan_exclusive<0, 0>(s, w.num, w.pre, n, n, P, w.scan_tot);
