@@ -8,7 +8,7 @@ python -m pytest tests -m gpu -q --durations=10 > $O/pytest_gpu.txt 2>&1; tail -
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err
 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-reference-schedule --no-msm > $O/bench_20steps.json 2>/dev/null
-python bench.py --workload mixed64 --steps 6 --warmup 2 --no-msm > $O/bench_mixed64.json 2>/dev/null
+python bench.py --workload mixed64 --steps 12 --warmup 3 --no-msm > $O/bench_mixed64.json 2>/dev/null
 MSM_LOGS=15,17,20,22,24 python tools/gpu_msm_profile.py > $O/msm_single_profile.json 2>/dev/null
 bash tools/gpuprof.sh $tag > $O/gpuprof.log 2>&1
 python tools/make_traffic.py gpurun_out/prof_$tag 256 $O/traffic.json > $O/traffic.log 2>&1
