@@ -831,8 +831,9 @@ int capgpu_plonk_preprocess(uint64_t srs_handle, size_t n, size_t num_inputs, co
   CAP_CHECK_INIT();
   Context& c = ctx();
   std::lock_guard<std::recursive_mutex> lk(c.mu);
-  if (!selectors || !sigma_evals || !pk_handle_out || n < 8 || (n & (n - 1)) || num_inputs >= n) {
-    set_error("capgpu_plonk_preprocess: bad argument (n must be a power of two >= 8, num_inputs < n)");
+  // n >= 16: the five split-quotient commitments read 5 (n + 2) coefficients of the 6n-point quotient array
+  if (!selectors || !sigma_evals || !pk_handle_out || n < 16 || (n & (n - 1)) || num_inputs >= n) {
+    set_error("capgpu_plonk_preprocess: bad argument (n must be a power of two >= 16, num_inputs < n)");
     return CAPGPU_ERR_INVALID_ARG;
   }
   const MsmBases* B = nullptr;
@@ -991,7 +992,8 @@ int capgpu_plonk_key_deserialize(const uint8_t* bytes, size_t len, uint64_t* srs
   if (!tag) return fail("unexpected end of input");
   if (*tag) return fail("plookup proving keys are not supported");
   const size_t n = vk.domain_size;
-  if (n < 8 || (n & (n - 1)) || vk.num_inputs >= n) return fail("domain_size must be a power of two above num_inputs");
+  if (n < 16 || (n & (n - 1)) || vk.num_inputs >= n)
+    return fail("domain_size must be a power of two >= 16 above num_inputs");
   if (n_ck < n + 3) return fail("commit key shorter than domain_size + 3");
   for (int i = 0; i < 18; i++)
     if (polys[i].len > n) return fail("polynomial longer than the domain");

@@ -183,8 +183,8 @@ typedef struct capgpu_verifying_key {
 
 /* selectors: 13 columns of n Fr (Montgomery), column-major, gate order above; sigma_evals: 5 columns
  * of n Fr = sigma_i(omega^j) (the extended permutation as field elements k_i' * omega^j').
- * n must be a power of two, 8 <= n (the quotient is interpolated on 6n points, which must hold its 5n + 8
- * coefficients), n + 3 <= SRS size. */
+ * n must be a power of two, 16 <= n (the quotient is interpolated on 6n points, which must hold its 5n + 8
+ * coefficients and the 5 (n + 2) the split-quotient commitments read), n + 3 <= SRS size. */
 int capgpu_plonk_preprocess(uint64_t srs_handle, size_t n, size_t num_inputs, const uint64_t* selectors,
                             const uint64_t* sigma_evals, uint64_t* pk_handle_out, capgpu_verifying_key* vk_out);
 int capgpu_plonk_free_key(uint64_t pk_handle);

@@ -195,6 +195,12 @@ def test_unsatisfied_witness_and_bad_arguments(cg, tau):
     with pytest.raises(cg.CapGpuError) as e:             # wrong number of public inputs
         cg.plonk_prove_batch(pkh, wm[None], pubs_arr(pubs[:1])[None], bl[None], None, 1)
     assert e.value.code == -1
+    # an 8-row domain is refused at preprocessing: its five split-quotient commitments would read 5 (n + 2) = 50
+    # coefficients of a 48-point quotient array (found by tools/gpu_fuzz_prover.py; the smallest CAP circuit has 2^14 rows)
+    sc8 = bu.synthetic_circuit(3, 1, seed=3)
+    with pytest.raises(cg.CapGpuError) as e:
+        cg.plonk_preprocess(h, 8, 1, sc8.selectors_mont(), sc8.sigma_mont())
+    assert e.value.code == -1
     with pytest.raises(cg.CapGpuError) as e:             # unknown key
         cg.plonk_prove_batch(424242, wm[None], pubs_arr(pubs)[None], bl[None], None, 1)
     assert e.value.code == -4

@@ -181,8 +181,8 @@ def test_ref_ntt_gpu(cg):
 def test_ref_proof_gpu(cg):
     g = ref("ref_proof.json")
     n, sel, sig, wires, pubs, blinders, tau, msg = proof_instance(g)
-    if n < 8:
-        pytest.skip("the device prover needs n >= 8")
+    if n < 16:
+        pytest.skip("the device prover needs n >= 16")
     h = cg.srs_generate(tau, n + 3)
     pkh, vk = cg.plonk_preprocess(h, n, len(pubs), np.concatenate([bu.to_mont_array(c) for c in sel]).reshape(13, n, 4),
                                   np.concatenate([bu.to_mont_array(c) for c in sig]).reshape(5, n, 4))
