@@ -105,7 +105,10 @@ int capgpu_srs_download(uint64_t handle, size_t offset, size_t n, void* out);
 int capgpu_srs_free(uint64_t handle);
 
 /* ---- MSM: replaces VariableBaseMSM::multi_scalar_mul ------------------------------------------ */
-/* out = sum_i scalars[i] * bases[offset + i];  scalars canonical 4 x u64; out Jacobian 96 B. */
+/* out = sum_i scalars[i] * bases[offset + i];  scalars canonical 4 x u64; out Jacobian 96 B (X, Y, Z Montgomery; Z = 0:
+ * infinity).  The triple is A representative of the point - like ark-ec's G1Projective it depends on the order the
+ * additions were made in, which on the device varies from run to run (bucket lists are filled with atomics): compare
+ * results in affine form (X / Z^2, Y / Z^3), as every caller of the reference does through into_affine(). */
 int capgpu_msm_g1(uint64_t srs_handle, size_t offset, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]);
 int capgpu_msm_g1_batch(uint64_t srs_handle, const size_t* offsets, const uint64_t* const* scalars,
                         const size_t* ns, int count, uint64_t* out_xyz /* count*12 */);
