@@ -15,8 +15,14 @@ rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
 cg.init(0)
 tau = bu.SplitMix64(77).field()
 bad = 0
+# "big" as third argument: shapes that cross the plan thresholds of the prover's MSM launches (narrow / wide tables at
+# 32 MSMs per launch, log-depth / running-sum reduction at 64 of them) instead of random ones
+BIG = [(12, 6), (12, 7), (12, 12), (12, 13), (12, 33), (13, 7), (13, 14), (11, 64), (14, 3)]
+big = len(sys.argv) > 3 and sys.argv[3] == "big"
+if big:
+    rounds = len(BIG)
 for r in range(rounds):
-    log_n = rng.choice([4, 4, 5, 5, 6, 7, 8, 9, 10, 11, 12, 13])
+    log_n = BIG[r][0] if big else rng.choice([4, 4, 5, 5, 6, 7, 8, 9, 10, 11, 12, 13])
     n = 1 << log_n
     srs = cg.srs_generate(tau, n + 3)
     srs_host = cg.srs_download(srs, 0, n + 3)
@@ -28,7 +34,7 @@ for r in range(rounds):
         circuits.append(sc)
         keys.append(cg.plonk_preprocess(srs, n, ni, sc.selectors_mont(), sc.sigma_mont())[0])
         ckeys.append(cr.PlonkKey(srs_host, n, ni, sc.selectors_mont(), sc.sigma_mont()))
-    P = rng.choice([1, 2, 3, 5, 8, 13, 40]) if log_n <= 10 else rng.randint(1, 4)
+    P = BIG[r][1] if big else (rng.choice([1, 2, 3, 5, 8, 13, 40]) if log_n <= 10 else rng.randint(1, 4))
     order = [rng.randrange(nkeys) for _ in range(P)]
     max_in = max(circuits[k].num_inputs for k in order)      # the row length follows the keys actually in the batch
     wires, rows, blinds, msgs, exp = [], [], [], [], []
