@@ -335,6 +335,24 @@ int compute_pk_coset(hipStream_t s, const ProvingKey& K, fe* dst) {
   return run_ntt3_fwd(s, K.log_m, dst, 18, NttIo{K.coef, K.ps, 0, K.n, 1, K.m, 0, 1});
 }
 
+// The stream the chunks of host-resident wire columns are copied on: a copy on the launch stream itself would queue up
+// behind the kernels of the chunk before it (calls are serialised by the process lock; created on first use).
+hipStream_t h2d_stream() {
+  static hipStream_t st = nullptr;
+  if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
+  return st;
+}
+// chunks of proofs the host-resident wire columns of a batch are copied and committed in (round 1 of prove_batch)
+uint32_t h2d_chunks(uint32_t P) {
+  static const int forced = [] {
+    const char* e = getenv("CAPGPU_PROVE_CHUNKS");  // tests: any batch in 1..16 chunks
+    const int x = e ? atoi(e) : 0;
+    return x >= 1 && x <= 16 ? x : 0;
+  }();
+  if (forced) return std::min<uint32_t>((uint32_t)forced, P);
+  return P >= 64 ? 4u : (P >= 32 ? 2u : 1u);  // a chunk's commitments should still fill the chip (>= 80 MSMs)
+}
+
 // msgs / msg_lens (optional): one transcript init message per proof; otherwise ext_msg is shared by the batch.
 // keys (optional): the proving key of every proof - keys of ONE domain size under ONE SRS (the reference proves transfer,
 // mint and freeze notes side by side, src/utils/params_builder.rs:194-226; proofs of different circuits on the same
@@ -344,7 +362,11 @@ int compute_pk_coset(hipStream_t s, const ProvingKey& K, fe* dst) {
 int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pub_inputs, size_t num_inputs,
                 const uint8_t* ext_msg, size_t ext_len, const uint64_t* blinders, capgpu_proof* proofs,
                 const uint8_t* const* msgs = nullptr, const size_t* msg_lens = nullptr,
-                const std::vector<ProvingKey*>* keys = nullptr) {
+                const std::vector<ProvingKey*>* keys = nullptr, const uint64_t* const* h_wires = nullptr) {
+  // h_wires (optional): the wire columns are still in host memory - h_wires[p] points to the 5 n elements of proof p -
+  // and d_wires is an empty device buffer for them.
+  // Round 1 then runs in chunks of proofs - copy, interpolate, blind, commit - so that the copy of a chunk (pageable
+  // memory: the call blocks the host, not the device) overlaps the commitments of the one before.
   Context& c = ctx();
   hipStream_t s = c.stream;
   const size_t n = K.n, m = K.m, ps = K.ps;
@@ -453,15 +475,42 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
   // ---- round 1: wire polynomials, public-input polynomial, 5 commitments ------------------------------
   // the interpolations read the witness columns / public inputs where they are and write the coefficient arrays (no
   // padded copies); k_blind sets the 8-element tail of every wire polynomial (two blinders, six zeros)
-  if ((rc = run_ntt_from(s, K.log_n, d_wires, n, n, w.wpoly, ps, P * NW, 1, 0))) return rc;
-  launch("k_blind", k_blind<1>, dim3(P * NW), dim3(64), 0, s, w.wpoly, ps, n, (const fe*)w.d_blind, (uint32_t)NW, 0u,
-         2u, P * NW);
+  const uint32_t chunks = h_wires ? h2d_chunks(P) : 1;
+  for (uint32_t ck = 0; ck < chunks; ck++) {
+    const uint32_t p0 = (uint32_t)((uint64_t)P * ck / chunks), p1 = (uint32_t)((uint64_t)P * (ck + 1) / chunks);
+    const uint32_t cnt = p1 - p0;
+    const size_t wo = (size_t)p0 * NW * n;
+    if (h_wires) {
+      hipStream_t cs = chunks > 1 ? h2d_stream() : nullptr;
+      if (!cs) cs = s;
+      // one copy per run of proofs that are contiguous in host memory (a plain batch: one per chunk)
+      for (uint32_t p = p0; p < p1;) {
+        uint32_t q = p + 1;
+        while (q < p1 && h_wires[q] == h_wires[q - 1] + (size_t)4 * NW * n) q++;
+        CAP_HIP(hipMemcpyAsync(const_cast<fe*>(d_wires) + (size_t)p * NW * n, h_wires[p],
+                               sizeof(fe) * (size_t)(q - p) * NW * n, hipMemcpyHostToDevice, cs));
+        p = q;
+      }
+      if (cs != s) {  // the chunk's kernels wait for its copy, not for the copies after it
+        hipEvent_t ev;
+        CAP_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e1 = hipEventRecord(ev, cs), e2 = e1 == hipSuccess ? hipStreamWaitEvent(s, ev, 0) : e1;
+        (void)hipEventDestroy(ev);  // released once the recorded work is done
+        CAP_HIP(e2);
+      }
+    }
+    fe* wp = w.wpoly + (size_t)p0 * NW * ps;
+    if ((rc = run_ntt_from(s, K.log_n, d_wires + wo, n, n, wp, ps, cnt * NW, 1, 0))) return rc;
+    launch("k_blind", k_blind<1>, dim3(cnt * NW), dim3(64), 0, s, wp, ps, n, (const fe*)(w.d_blind + (size_t)p0 * 13),
+           (uint32_t)NW, 0u, 2u, cnt * NW);
+    if (chunks > 1 && (rc = run_msm(s, *B, wp, ps, 1, 0, n + 2, cnt * NW, w.comms + (size_t)p0 * NW))) return rc;
+  }
   if (num_inputs) {
     if ((rc = run_ntt_from(s, K.log_n, w.d_pub, num_inputs, num_inputs, w.pi, n, P, 1, 0))) return rc;
   } else {
     CAP_HIP(hipMemsetAsync(w.pi, 0, sizeof(fe) * (size_t)P * n, s));
   }
-  if ((rc = run_msm(s, *B, w.wpoly, ps, 1, 0, n + 2, P * NW, w.comms))) return rc;
+  if (chunks == 1 && (rc = run_msm(s, *B, w.wpoly, ps, 1, 0, n + 2, P * NW, w.comms))) return rc;
   // round 3's coset evaluations of the wire and public-input polynomials (on the 6n quotient domain, straight from
   // their coefficient arrays: the transform zero-extends them) depend on nothing the transcript still has to produce
   if ((rc = fetch_comms(P * NW, [&]() -> int {
@@ -1110,12 +1159,18 @@ int capgpu_plonk_prove_batch(uint64_t pk_handle, int count, const uint64_t* wire
   std::shared_ptr<ProvingKey> K;
   int rc = lookup_key(pk_handle, &K);
   if (rc) return rc;
+  if (!blinders || !proofs_out || (num_inputs && !pub_inputs)) {
+    set_error("capgpu_plonk_prove: bad argument");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
   size_t bytes = sizeof(fe) * (size_t)count * NW * K->n;
   rc = scratch_reserve(c.stage_b, bytes);
   if (rc) return rc;
-  CAP_HIP(hipMemcpyAsync(c.stage_b.p, wires, bytes, hipMemcpyHostToDevice, c.stream));
-  return capgpu_plonk_prove_batch_dev(pk_handle, count, c.stage_b.p, pub_inputs, num_inputs, ext_msg, ext_msg_len,
-                                      blinders, proofs_out);
+  // the columns are copied inside round 1, chunk by chunk, behind the commitments of the chunk before
+  std::vector<const uint64_t*> rows(count);
+  for (int i = 0; i < count; i++) rows[i] = wires + (size_t)4 * i * NW * K->n;
+  return prove_batch(*K, (uint32_t)count, (const fe*)c.stage_b.p, pub_inputs, num_inputs, ext_msg, ext_msg_len, blinders,
+                     proofs_out, nullptr, nullptr, nullptr, rows.data());
 }
 
 // Proofs of several proving keys in one device batch (see prove_batch): pk_handles[i] is the key of proof i.
@@ -1156,12 +1211,23 @@ int capgpu_plonk_prove_multi(const uint64_t* pk_handles, int count, const uint64
   std::shared_ptr<ProvingKey> K;
   int rc = lookup_key(pk_handles[0], &K);
   if (rc) return rc;
+  if (!blinders || !proofs_out || (num_inputs && !pub_inputs) || (ext_msgs && !ext_msg_lens)) {
+    set_error("capgpu_plonk_prove_multi: bad argument");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  std::vector<std::shared_ptr<ProvingKey>> hold(count);
+  std::vector<ProvingKey*> keys(count);
+  for (int i = 0; i < count; i++) {
+    if ((rc = lookup_key(pk_handles[i], &hold[i]))) return rc;
+    keys[i] = hold[i].get();
+  }
   size_t bytes = sizeof(fe) * (size_t)count * NW * K->n;
   rc = scratch_reserve(c.stage_b, bytes);
   if (rc) return rc;
-  CAP_HIP(hipMemcpyAsync(c.stage_b.p, wires, bytes, hipMemcpyHostToDevice, c.stream));
-  return capgpu_plonk_prove_multi_dev(pk_handles, count, c.stage_b.p, pub_inputs, num_inputs, ext_msgs, ext_msg_lens,
-                                      blinders, proofs_out);
+  std::vector<const uint64_t*> rows(count);
+  for (int i = 0; i < count; i++) rows[i] = wires + (size_t)4 * i * NW * K->n;
+  return prove_batch(*keys[0], (uint32_t)count, (const fe*)c.stage_b.p, pub_inputs, num_inputs, nullptr, 0, blinders,
+                     proofs_out, ext_msgs, ext_msg_lens, &keys, rows.data());
 }
 
 // one gathered batch: device staging of every request's wires, per-proof messages and keys; a batch that fails because
@@ -1221,9 +1287,9 @@ static void run_coalesced(std::vector<ProveReq*>& reqs) {
   std::vector<size_t> lens(g);
   std::vector<capgpu_proof> out(g);
   std::vector<ProvingKey*> keys(g);
+  std::vector<const uint64_t*> rows(g);  // every caller's own buffer: copied inside round 1, chunk by chunk
   for (size_t i = 0; i < g; i++) {
-    hipError_t e = hipMemcpyAsync((char*)c.stage_b.p + per * i, good[i]->wires, per, hipMemcpyHostToDevice, c.stream);
-    if (e != hipSuccess) return fail_all(hip_fail(e, "upload of wire columns"));
+    rows[i] = good[i]->wires;
     if (good[i]->num_inputs) memcpy(&pubs[4 * ni * i], good[i]->pubs, 32 * good[i]->num_inputs);
     memcpy(&blind[4 * 13 * i], good[i]->blinders, 32 * 13);
     msgs[i] = good[i]->msg;
@@ -1231,7 +1297,7 @@ static void run_coalesced(std::vector<ProveReq*>& reqs) {
     keys[i] = hold[i].get();
   }
   rc = prove_batch(*keys[0], (uint32_t)g, (const fe*)c.stage_b.p, pubs.data(), ni, nullptr, 0, blind.data(), out.data(),
-                   msgs.data(), lens.data(), mixed ? &keys : nullptr);
+                   msgs.data(), lens.data(), mixed ? &keys : nullptr, rows.data());
   if (rc == CAPGPU_OK) rc = take_launch_error();
   if (rc == CAPGPU_OK) {
     for (size_t i = 0; i < g; i++) *good[i]->out = out[i];
