@@ -441,7 +441,7 @@ def main():
         out["pcie_inclusive"] = {"proofs_per_s": P / dt_h, "ms_per_step": dt_h * 1e3,
                                  "host_bytes_per_step": int(wires.nbytes),
                                  "note": "capgpu_plonk_prove_batch: the 5 wire columns of every proof (5 n x 32 B) are copied "
-                                         "from pageable host memory inside the call"}
+                                         "from pageable host memory inside the call, in chunks behind round 1's commitments"}
         del ph
         # (2b) the reference's calling pattern: many host threads, ONE prove() per note each (rayon par_iter,
         # src/utils/params_builder.rs:194-226), served by the library's call coalescing
