@@ -299,7 +299,8 @@ void capgpu_shutdown(void) {
     s->cap = 0;
   }
   if (c.own_stream) hipStreamDestroy(c.own_stream);
-  c.own_stream = c.stream = nullptr;
+  if (c.copy_stream) hipStreamDestroy(c.copy_stream);
+  c.own_stream = c.stream = c.copy_stream = nullptr;
   c.initialised = false;
 }
 

@@ -35,6 +35,7 @@ struct Context {
   bool initialised = false;
   int device = 0;
   hipStream_t own_stream = nullptr;
+  hipStream_t copy_stream = nullptr;  // H2D of host-resident witnesses (plonk.hip), created on first use
   hipStream_t stream = nullptr;  // the stream work is enqueued on (own_stream unless capgpu_set_stream)
   NttSmallTables small;
   std::map<uint32_t, NttDomain> domains;

@@ -338,9 +338,10 @@ int compute_pk_coset(hipStream_t s, const ProvingKey& K, fe* dst) {
 // The stream the chunks of host-resident wire columns are copied on: a copy on the launch stream itself would queue up
 // behind the kernels of the chunk before it (calls are serialised by the process lock; created on first use).
 hipStream_t h2d_stream() {
-  static hipStream_t st = nullptr;
-  if (!st && hipStreamCreateWithFlags(&st, hipStreamNonBlocking) != hipSuccess) st = nullptr;
-  return st;
+  Context& c = ctx();
+  if (!c.copy_stream && hipStreamCreateWithFlags(&c.copy_stream, hipStreamNonBlocking) != hipSuccess)
+    c.copy_stream = nullptr;
+  return c.copy_stream;
 }
 // chunks of proofs the host-resident wire columns of a batch are copied and committed in (round 1 of prove_batch)
 uint32_t h2d_chunks(uint32_t P) {
