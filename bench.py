@@ -126,6 +126,11 @@ def msm_leg(cg, bu, torch, dist, rank, world, log_n, iters=5, coll_dev="cuda", u
 
 
 def main():
+    # stdout carries exactly ONE line, the JSON: whatever the libraries print on file descriptor 1 meanwhile (RCCL's
+    # version banner, gloo's connection notes) is sent to stderr
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
@@ -608,7 +613,8 @@ def main():
             legs.append({"error": str(e)})
         out["msm"] = legs
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(out) + "\n").encode())
     if lib_comm:
         cg.comm_destroy()
     if dist is not None:
