@@ -794,7 +794,20 @@ __global__ __launch_bounds__(64) void msm_reduce_final(const g1_xyzz* __restrict
 // ---- K6 for small batches --------------------------------------------------------------------------------------
 // The running-sum walk needs thousands of independent segments to fill the chip; one large MSM (or a handful) does
 // not have them.  There the buckets are combined per bucket and reduced through bit planes, both log-depth.
-constexpr uint32_t kReduceChunk = 4096;  // buckets per msm_reduce_bits workgroup
+// msm_reduce_bits splits the buckets of a sub-MSM into chunks, one workgroup per (chunk, bit plane): up to 16 chunks of
+// at least 512 buckets - 256 of them in a plane, one per thread - so that a workgroup's chain of dependent additions is
+// 1-2 + 6 (wave) + 2 (workgroup) instead of the 8 + 6 + 2 of one workgroup per plane; msm_reduce_bits_final folds the
+// chunks of a plane with a 16-lane shuffle tree.  (A single proof's four MSM launches: reduce_bits + final 1.16 -> 1.11 ms,
+// a 2^17-point MSM 0.83 -> 0.80 ms: every tree level of the final kernel costs what a serial step of the first saved.)
+constexpr uint32_t kReduceMaxChunks = 16;
+// ... as many chunks as keep the launch at about one workgroup per CU (c * chunks * sub-MSMs <= 320): a second wave of
+// this code on a SIMD buys little (measured: 8 chunks for a 5-MSM launch made every addition 35 % slower)
+uint32_t reduce_chunks(uint32_t half, uint32_t c, uint32_t sb) {
+  const uint32_t cap = std::min<uint32_t>(kReduceMaxChunks, std::max<uint32_t>(1, half / 512));
+  uint32_t chunks = 1;
+  while (chunks * 2 <= cap && (uint64_t)c * (chunks * 2) * sb <= 320) chunks *= 2;
+  return chunks;
+}
 // bucket = sum of its work items (a handful of full additions per bucket)
 __global__ __launch_bounds__(kThreads) void msm_combine(const g1_xyzz* __restrict__ item_pts,
                                                         const uint32_t* __restrict__ counts,
@@ -835,11 +848,13 @@ __global__ __launch_bounds__(kReduceThreads) void msm_reduce_bits(const g1_xyzz*
   const g1_xyzz* bk = buckets + (size_t)b * half;
   g1x acc = G1L::inf();
   // enumerate only the weights v = j + 1 in [1, half] that have `bit` set: v = idx with a 1 inserted at `bit`
-  // (every lane does useful work; a predicate on j would leave half the lanes idle for the low bits)
-  for (uint32_t q = 0; q < kReduceChunk / 2 / kReduceThreads; q++) {
-    uint32_t idx = chunk * (kReduceChunk / 2) + q * kReduceThreads + threadIdx.x;
-    uint32_t v = ((idx >> bit) << (bit + 1)) | (1u << bit) | (idx & ((1u << bit) - 1));
-    if (v <= half) acc = G1L::add(acc, G1L::load(bk[v - 1]));
+  // (every lane does useful work; a predicate on j would leave half the lanes idle for the low bits); the chunk owns
+  // the indices [chunk * per_chunk, (chunk + 1) * per_chunk) of the half / 2 such weights
+  const uint32_t per_chunk = (half / 2 + chunks - 1) / chunks;
+  for (uint32_t q = threadIdx.x; q < per_chunk; q += kReduceThreads) {
+    const uint32_t idx = chunk * per_chunk + q;
+    const uint32_t v = ((idx >> bit) << (bit + 1)) | (1u << bit) | (idx & ((1u << bit) - 1));
+    if (idx < half / 2 && v <= half) acc = G1L::add(acc, G1L::load(bk[v - 1]));  // (the top plane holds v = half only)
   }
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int d = 32; d >= 1; d >>= 1) {
@@ -859,21 +874,30 @@ __global__ __launch_bounds__(kReduceThreads) void msm_reduce_bits(const g1_xyzz*
 }
 
 // ---- K6b: sum_b 2^b T_b ------------------------------------------------------------------------------
-// one wavefront per batch entry; lane = bit.
-__global__ __launch_bounds__(64) void msm_reduce_bits_final(const g1_xyzz* __restrict__ partial, uint32_t c,
-                                                       uint32_t chunks, g1_jac* __restrict__ out,
-                                                       g1_xyzz* __restrict__ out_part) {
-  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+// One workgroup of 256 threads per batch entry.  Thread (bit, k) = (t / 16, t % 16) takes chunk k of plane `bit`; a
+// 16-lane shuffle tree folds the chunks of each plane (planes never straddle a wave: four of them per wave), then the
+// first wave has T_bit in lane `bit`, doubles it `bit` times and adds the planes up.  c <= 16, chunks <= 16.
+__global__ __launch_bounds__(256) void msm_reduce_bits_final(const g1_xyzz* __restrict__ partial, uint32_t c,
+                                                        uint32_t chunks, g1_jac* __restrict__ out,
+                                                        g1_xyzz* __restrict__ out_part) {
+  __shared__ g1_xyzz planes[16];
+  const uint32_t b = blockIdx.x, t = threadIdx.x, bit = t >> 4, k = t & 15;
   g1x acc = G1S::inf();
-  if (lane < c) {
-    const g1_xyzz* p = partial + ((size_t)b * c + lane) * chunks;
-    for (uint32_t k = 0; k < chunks; k++) acc = G1S::add(acc, G1S::load(p[k]));
+  if (bit < c && k < chunks) acc = G1S::load(partial[((size_t)b * c + bit) * chunks + k]);
+  for (int d = 8; d >= 1; d >>= 1) {
+    g1x o = shfl_down_pt(acc, d);
+    if (k < (uint32_t)d && k + d < chunks) acc = G1S::add(acc, o);
   }
-  for (uint32_t k = 0; k + 1 < c; k++) {
+  if (k == 0 && bit < 16) planes[bit] = G1S::store(acc);
+  __syncthreads();
+  if (t >= 64) return;
+  const uint32_t lane = t;
+  acc = lane < c ? G1S::load(planes[lane]) : G1S::inf();
+  for (uint32_t j = 0; j + 1 < c; j++) {
     g1x d = G1S::dbl(acc);
-    if (lane > k && lane < c) acc = d;
+    if (lane > j && lane < c) acc = d;
   }
-  for (int d = 16; d >= 1; d >>= 1) {
+  for (int d = 8; d >= 1; d >>= 1) {
     g1x o = shfl_down_pt(acc, d);
     if (lane < (uint32_t)d) acc = G1S::add(acc, o);  // see wave_sum
   }
@@ -1015,7 +1039,7 @@ WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t sb, uint32_t
   L.offsets = o; o = align_up(o + sizeof(uint32_t) * half * sb, 256);
   L.sorted = o;  o = align_up(o + sizeof(uint32_t) * per * sb, 256);
   {
-    size_t chunks = (half + kReduceChunk - 1) / kReduceChunk;
+    size_t chunks = kReduceMaxChunks;  // room for any choice of reduce_chunks
     size_t npart = use_segment_reduce((uint32_t)half, sb) ? 2 * nseg : c * chunks;
     L.buckets = o; o = align_up(o + sizeof(g1_xyzz) * half * sb, 256);
     L.partial = o; o = align_up(o + sizeof(g1_xyzz) * npart * sb, 256);
@@ -1242,10 +1266,10 @@ int msm_run_slice(const MsmBases& bases, const Plan& pl, size_t offset, const fe
     launch("msm_reduce_final", msm_reduce_final, dim3(sb), dim3(64), 0, stream, (const g1_xyzz*)partial, seg_len, nseg,
            out, part_pts);
   } else {
-    const uint32_t chunks = (half + kReduceChunk - 1) / kReduceChunk;
+    const uint32_t chunks = reduce_chunks(half, c, sb);
     launch("msm_reduce_bits", msm_reduce_bits, dim3(chunks, c, sb), dim3(kReduceThreads), 0, stream, (const g1_xyzz*)buckets,
            half, c, chunks, partial);
-    launch("msm_reduce_bits_final", msm_reduce_bits_final, dim3(sb), dim3(64), 0, stream, (const g1_xyzz*)partial, c,
+    launch("msm_reduce_bits_final", msm_reduce_bits_final, dim3(sb), dim3(256), 0, stream, (const g1_xyzz*)partial, c,
            chunks, out, part_pts);
   }
   if (parts > 1)
