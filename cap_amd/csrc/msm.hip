@@ -530,6 +530,20 @@ __global__ __launch_bounds__(1024) void msm_scan_add(uint32_t* __restrict__ offs
 // bucket = sum of its work items, G lanes per bucket: lanes take items, a shuffle tree adds them up.  For the
 // small-batch path, where there are too few buckets for one thread each (one thread per bucket is then a serial chain
 // on a handful of waves: 1.2 ms for 2^17 points).
+// a += b in the reduction trees: an operand at infinity (an empty bucket, a padding lane) is a skip or a copy decided
+// on zz, everything else goes through the lean addition; equal or opposite operands - never with real data - fall back
+// to the general one.  (tools/ubench_lonewave.hip: 6.5 against 7.8 us per dependent addition; one wave per SIMD already
+// runs at 91 % of what two or three reach together, so these chains only get faster by executing fewer instructions.)
+template <class G>
+__device__ __forceinline__ void add_tree(g1x& a, const g1x& b) {
+  if (G::is_inf(b)) return;
+  if (G::is_inf(a)) {
+    a = b;
+    return;
+  }
+  if (__builtin_expect(!G::add_acc(a, b), 0)) a = G::add(a, b);
+}
+
 template <int G>
 __global__ __launch_bounds__(kThreads) void msm_combine_wave(const g1_xyzz* __restrict__ item_pts,
                                                              const uint32_t* __restrict__ counts,
@@ -546,12 +560,12 @@ __global__ __launch_bounds__(kThreads) void msm_combine_wave(const g1_xyzz* __re
   g1x acc = G1L::inf();
   if (items != 1) {  // single-item buckets were written by msm_accumulate
     if (lane < items) acc = G1L::load(item_pts[first + lane]);
-    for (uint32_t j = lane + G; j < items; j += G) acc = G1L::add(acc, G1L::load(item_pts[first + j]));
+    for (uint32_t j = lane + G; j < items; j += G) add_tree<G1L>(acc, G1L::load(item_pts[first + j]));
   }
   for (int d = G / 2; d >= 1; d >>= 1) {
     g1x o = shfl_down_pt(acc, d);
     // (lanes d .. G - d - 1 add too, uselessly; restricting the addition to lane < d was measured 20 % slower here)
-    if (lane + d < G) acc = G1L::add(acc, o);
+    if (lane + d < G) add_tree<G1L>(acc, o);
   }
   if (lane == 0 && items != 1) buckets[gb] = G1L::store(acc);
 }
@@ -737,7 +751,7 @@ __device__ __forceinline__ g1x wave_sum(g1x v) {
   const uint32_t lane = threadIdx.x & 63;
   for (int d = 32; d >= 1; d >>= 1) {
     g1x o = shfl_down_pt(v, d);
-    if (lane < (uint32_t)d) v = G::add(v, o);
+    if (lane < (uint32_t)d) add_tree<G>(v, o);
   }
   return v;  // lane 0 holds the sum
 }
@@ -770,15 +784,15 @@ __global__ __launch_bounds__(64) void msm_reduce_final(const g1_xyzz* __restrict
   g1x S = G1S::inf(), T = G1S::inf(), A = G1S::inf();
   for (uint32_t s = s_hi; s > s_lo;) {
     s--;
-    T = G1S::add(T, S);                       // every segment above s gains one more unit of weight
-    S = G1S::add(S, G1S::load(sp[2 * s]));
-    A = G1S::add(A, G1S::load(sp[2 * s + 1]));
+    add_tree<G1S>(T, S);                      // every segment above s gains one more unit of weight
+    add_tree<G1S>(S, G1S::load(sp[2 * s]));
+    add_tree<G1S>(A, G1S::load(sp[2 * s + 1]));
   }
   // S = sum S_s, T = sum (s - s_lo) S_s, A = sum T_s over the lane's segments
   g1x suf = S;  // inclusive suffix sum over lanes
   for (int d = 1; d < 64; d <<= 1) {
     g1x o = shfl_down_pt(suf, d);
-    if (lane + d < 64) suf = G1S::add(suf, o);
+    if (lane + d < 64) add_tree<G1S>(suf, o);
   }
   if (lane == 0) suf = G1S::inf();
   // per lane: A + seg_len * (T + q * suf); their sum over the wave is the result
@@ -854,12 +868,12 @@ __global__ __launch_bounds__(kReduceThreads) void msm_reduce_bits(const g1_xyzz*
   for (uint32_t q = threadIdx.x; q < per_chunk; q += kReduceThreads) {
     const uint32_t idx = chunk * per_chunk + q;
     const uint32_t v = ((idx >> bit) << (bit + 1)) | (1u << bit) | (idx & ((1u << bit) - 1));
-    if (idx < half / 2 && v <= half) acc = G1L::add(acc, G1L::load(bk[v - 1]));  // (the top plane holds v = half only)
+    if (idx < half / 2 && v <= half) add_tree<G1L>(acc, G1L::load(bk[v - 1]));  // (the top plane holds v = half only)
   }
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int d = 32; d >= 1; d >>= 1) {
     g1x o = shfl_down_pt(acc, d);
-    if (lane < (uint32_t)d) acc = G1L::add(acc, o);  // see wave_sum
+    if (lane < (uint32_t)d) add_tree<G1L>(acc, o);  // see wave_sum
   }
   if (lane == 0) sh[wave] = G1L::store(acc);
   __syncthreads();
@@ -867,7 +881,7 @@ __global__ __launch_bounds__(kReduceThreads) void msm_reduce_bits(const g1_xyzz*
     g1x r = lane < kWaves ? G1L::load(sh[lane]) : G1L::inf();
     for (int d = kWaves / 2; d >= 1; d >>= 1) {
       g1x o = shfl_down_pt(r, d);
-      if (lane < (uint32_t)d) r = G1L::add(r, o);
+      if (lane < (uint32_t)d) add_tree<G1L>(r, o);
     }
     if (lane == 0) partial[((size_t)b * c + bit) * chunks + chunk] = G1L::store(r);
   }
@@ -886,7 +900,7 @@ __global__ __launch_bounds__(256) void msm_reduce_bits_final(const g1_xyzz* __re
   if (bit < c && k < chunks) acc = G1S::load(partial[((size_t)b * c + bit) * chunks + k]);
   for (int d = 8; d >= 1; d >>= 1) {
     g1x o = shfl_down_pt(acc, d);
-    if (k < (uint32_t)d && k + d < chunks) acc = G1S::add(acc, o);
+    if (k < (uint32_t)d && k + d < chunks) add_tree<G1S>(acc, o);
   }
   if (k == 0 && bit < 16) planes[bit] = G1S::store(acc);
   __syncthreads();
@@ -899,7 +913,7 @@ __global__ __launch_bounds__(256) void msm_reduce_bits_final(const g1_xyzz* __re
   }
   for (int d = 8; d >= 1; d >>= 1) {
     g1x o = shfl_down_pt(acc, d);
-    if (lane < (uint32_t)d) acc = G1S::add(acc, o);  // see wave_sum
+    if (lane < (uint32_t)d) add_tree<G1S>(acc, o);  // see wave_sum
   }
   if (lane == 0) {
     if (out_part) out_part[b] = G1S::store(acc);
