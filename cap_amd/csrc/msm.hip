@@ -14,6 +14,7 @@
 #include "curve29.hpp"
 #include "launch.hpp"
 
+#include <math.h>
 #include <stdio.h>
 #include <stdlib.h>
 
@@ -1026,7 +1027,7 @@ bool use_segment_reduce(uint32_t half, uint32_t batch) {
 // about 8 waves per SIMD worth of work items (256 CUs x 4 SIMDs x 64 lanes x 8) before items grow beyond the minimum.
 // (Shorter items for a single proof's 1- and 2-MSM launches - down to 8 entries below 2^20 entries - were measured:
 // msm_accumulate 0.84 -> 0.78 ms per proof, msm_combine_wave 0.29 -> 0.45 ms.)
-uint32_t choose_item_len(size_t entries) {
+uint32_t choose_item_len(size_t entries, size_t buckets) {
   static const size_t cap = [] {
     const char* e = getenv("CAPGPU_MSM_ITEM_MAX");
     int x = e ? atoi(e) : (int)kMaxItemLen;
@@ -1037,6 +1038,23 @@ uint32_t choose_item_len(size_t entries) {
     int x = e ? atoi(e) : (int)kMinItemLen;
     return (size_t)(x >= 4 && x <= (int)kMaxItemLen ? x : (int)kMinItemLen);
   }();
+  // Small launches (a single proof's MSMs, single MSMs up to 2^18 points): one wave per SIMD already saturates it
+  // (tools/ubench_lonewave.hip), and a SIMD that gets two waves takes twice as long - so the launch should be ONE wave
+  // of items per SIMD at most (65536 items), every item as short as that allows.  With `buckets` buckets of about
+  // `entries / buckets` entries each that is m = 65536 / buckets items per bucket, and the item length is chosen so that
+  // a bucket 4 sigma above the average still needs no more than m.
+  static const bool tune_small = [] {
+    const char* e = getenv("CAPGPU_MSM_ITEM_SMALL");
+    return !e || atoi(e) != 0;
+  }();
+  if (tune_small && buckets && buckets <= 8192 && entries >= buckets) {  // (1 or 2 MSMs; with 5 the items get long and a
+                                                                         // lone wave cannot hide its gathers: measured worse)
+    const double avg = (double)entries / (double)buckets;
+    const double hi = avg + 4.0 * sqrt(avg);
+    const size_t m = std::max<size_t>(1, 65536 / buckets);
+    const size_t l = (size_t)ceil(hi / (double)m);
+    return (uint32_t)std::min<size_t>(std::max<size_t>(l, 8), cap);
+  }
   size_t l = entries / ((size_t)1 << 19);
   return (uint32_t)std::min<size_t>(std::max<size_t>(l, std::min<size_t>(floor_len, cap)), cap);
 }
@@ -1058,7 +1076,7 @@ WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t sb, uint32_t
     L.buckets = o; o = align_up(o + sizeof(g1_xyzz) * half * sb, 256);
     L.partial = o; o = align_up(o + sizeof(g1_xyzz) * npart * sb, 256);
   }
-  L.max_items = per * sb / choose_item_len(per * sb) + half * sb;  // sum ceil(cnt/L) <= entries/L + buckets
+  L.max_items = per * sb / choose_item_len(per * sb, half * sb) + half * sb;  // sum ceil(cnt/L) <= entries/L + buckets
   L.item_off = o;    o = align_up(o + sizeof(uint32_t) * half * sb, 256);
   L.item_base = o;   o = align_up(o + sizeof(uint32_t) * ((size_t)sb + 1), 256);
   L.totals = o;      o = align_up(o + sizeof(uint32_t) * sb, 256);
@@ -1243,7 +1261,7 @@ int msm_run_slice(const MsmBases& bases, const Plan& pl, size_t offset, const fe
   uint32_t* item_bucket = reinterpret_cast<uint32_t*>(base + L.item_bucket);
   g1_xyzz* item_pts = reinterpret_cast<g1_xyzz*>(base + L.item_pts);
   uint32_t* item_sub = reinterpret_cast<uint32_t*>(base + L.item_sub);
-  const uint32_t item_len = choose_item_len(per * sb);
+  const uint32_t item_len = choose_item_len(per * sb, (size_t)half * sb);
   launch("msm_scan_items", msm_scan<1>, dim3(sb), dim3(1024), 0, stream, (const uint32_t*)counts, item_off, half,
          totals, item_len);
   launch("msm_item_bases", msm_item_bases, dim3(1), dim3(1024), 0, stream, (const uint32_t*)totals, sb, item_base);
