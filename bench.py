@@ -431,8 +431,9 @@ def main():
         a, b = cg.proof_to_arrays(p1[0]), cg.proof_to_arrays(proofs[0])
         out["latency_ms_batch1"] = {"median": sorted(lat)[len(lat) // 2], "min": min(lat), "max": max(lat), "runs": len(lat),
                                     "same_proof_as_in_the_batch": bool(all(np.array_equal(a[k], b[k]) for k in a)),
-                                    "note": "capgpu_plonk_prove_batch_dev with count = 1, witness resident; the GPU is mostly "
-                                            "idle at this size (latency-bound launches)"}
+                                    "note": "capgpu_plonk_prove_batch_dev with count = 1, witness resident; most SIMDs are "
+                                            "idle at this size: the small MSM launches are chains of dependent point "
+                                            "additions on a few hundred waves"}
         d1.free()
         # (2) the boundary handing over HOST buffers: wires cross PCIe inside the timed region (never `value`)
         for _ in range(1):
