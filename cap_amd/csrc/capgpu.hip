@@ -1,10 +1,14 @@
-// C-ABI entry points of libcapgpu.so (include/capgpu.h): lifecycle, device
-// memory plumbing, SRS management, MSM and NTT.  The PLONK entry points live in
+// C-ABI entry points of libcapgpu.so (include/capgpu.h): lifecycle, the device contexts and the table of logical
+// handles (context.hpp), device memory plumbing, SRS management, MSM and NTT.  The PLONK entry points live in
 // plonk.hip.  There is no CPU fallback anywhere in this library.
 #include <stdarg.h>
 #include <stdio.h>
 #include <string.h>
 
+#include <algorithm>
+#include <functional>
+#include <string>
+#include <thread>
 #include <vector>
 
 #include "context.hpp"
@@ -14,25 +18,48 @@
 namespace cap {
 
 static thread_local char g_err[512] = "";
+static thread_local Context* tl_ctx = nullptr;  // set by ScopedCtx
+static thread_local int tl_bound = -1;          // capgpu_set_device
 
+Runtime& rt() {
+  static Runtime r;
+  return r;
+}
 Context& ctx() {
-  static Context c;
-  return c;
+  if (tl_ctx) return *tl_ctx;
+  Runtime& R = rt();
+  if (!R.initialised.load(std::memory_order_acquire) || R.ctxs.empty()) {
+    static Context inert;  // initialised == false: every entry point refuses
+    return inert;
+  }
+  const int s = tl_bound >= 0 && (size_t)tl_bound < R.ctxs.size() ? tl_bound : 0;
+  return *R.ctxs[s];
 }
-Profiler& profiler() {
-  static Profiler p;
-  return p;
+int thread_bound_slot() { return tl_bound; }
+int& thread_entry_depth() {
+  static thread_local int d = 0;
+  return d;
 }
-LaunchError& launch_error() {
-  static LaunchError e;
-  return e;
+
+ScopedCtx::ScopedCtx(Context& c) : prev(tl_ctx) {
+  tl_ctx = &c;
+  (void)hipSetDevice(c.device);
 }
+ScopedCtx::~ScopedCtx() {
+  tl_ctx = prev;
+  if (prev) (void)hipSetDevice(prev->device);
+}
+
+Profiler& profiler() { return ctx().prof; }
+LaunchError& launch_error() { return ctx().lerr; }
+
 void set_error(const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof(g_err), fmt, ap);
   va_end(ap);
 }
+const char* last_error() { return g_err; }
 int hip_fail(hipError_t e, const char* what) {
   set_error("capgpu: HIP error %d (%s) in %s", (int)e, hipGetErrorString(e), what);
   (void)hipGetLastError();
@@ -89,12 +116,44 @@ int get_domain3(uint32_t log_m, const Ntt3Domain** out) {
   return CAPGPU_OK;
 }
 
+hipError_t copy_between(void* dst, int dst_device, const void* src, int src_device, size_t bytes, hipStream_t s) {
+  if (bytes == 0) return hipSuccess;
+  if (dst_device == src_device) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, s);
+  return hipMemcpyPeerAsync(dst, dst_device, src, src_device, bytes, s);
+}
+
+Context* try_acquire_context() {
+  Runtime& R = rt();
+  const size_t n = R.ctxs.size();
+  const uint32_t start = R.rr.load(std::memory_order_relaxed);
+  for (size_t i = 0; i < n; i++) {
+    Context* c = R.ctxs[(start + i) % n].get();
+    if (c->mu.try_lock()) {
+      R.rr.store((uint32_t)((start + i + 1) % n), std::memory_order_relaxed);
+      return c;
+    }
+  }
+  return nullptr;
+}
+Context& pick_context() {
+  Runtime& R = rt();
+  if (tl_ctx) return *tl_ctx;  // already placed by a dispatcher
+  if (tl_bound >= 0 || R.ctxs.size() <= 1) return ctx();
+  if (Context* c = try_acquire_context()) {
+    c->mu.unlock();  // the caller takes the lock through Entry; losing the race to another thread only costs a wait
+    return *c;
+  }
+  return *R.ctxs[R.rr.fetch_add(1, std::memory_order_relaxed) % R.ctxs.size()];
+}
+
 namespace {
 
 // ---- SRS generation kernels ---------------------------------------------------------------
 // scalar_i = mode 0: table[i] (Montgomery Fr, e.g. tau^i); mode 1: a + i*b.  out[i] = [scalar_i] G.
+// `first`: logical index of out[0] (a shard of a sharded SRS generates its own point range)
 __global__ __launch_bounds__(256) void srs_fixed_base_kernel(g1_affine* __restrict__ out, size_t n, int mode,
-                                                             const fe* __restrict__ table, fe a_mont, fe b_mont) {
+                                                             const fe* __restrict__ table, fe a_mont, fe b_mont,
+                                                             size_t first) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   fe s;
@@ -102,8 +161,8 @@ __global__ __launch_bounds__(256) void srs_fixed_base_kernel(g1_affine* __restri
     s = table[i];
   } else {
     fe idx = Fr::zero();
-    idx.v[0] = (uint32_t)i;
-    idx.v[1] = (uint32_t)((uint64_t)i >> 32);
+    idx.v[0] = (uint32_t)(first + i);
+    idx.v[1] = (uint32_t)((uint64_t)(first + i) >> 32);
     s = Fr::add(a_mont, Fr::mul(Fr::to_mont(idx), b_mont));
   }
   s = Fr::from_mont(s);
@@ -124,9 +183,11 @@ __global__ __launch_bounds__(256) void srs_fixed_base_kernel(g1_affine* __restri
   out[i] = G1::to_affine(acc);
 }
 
-__global__ void fr_powers_kernel(fe* out, size_t n, const fe* __restrict__ pw) {
+__global__ void fr_powers_kernel(fe* out, size_t n, const fe* __restrict__ pw, size_t first) {
   size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= n) return;
+  fe* dst = out + e;
+  e += first;
   fe r = Fr::one();
   bool started = false;
   for (int b = 0; (e >> b) != 0; b++) {
@@ -135,7 +196,7 @@ __global__ void fr_powers_kernel(fe* out, size_t n, const fe* __restrict__ pw) {
       started = true;
     }
   }
-  out[e] = r;
+  *dst = r;
 }
 
 __global__ void fq_to_mont_kernel(fe* data, size_t count) {
@@ -205,51 +266,268 @@ fe fe_from_u64x4(const uint64_t v[4]) {
   return r;
 }
 
+
+// a new SRS entry on the current context: window tables of `n` device-resident bases
+int make_srs_entry(g1_affine* d_bases, size_t n, size_t range_lo, std::shared_ptr<SrsEntry>* out) {
+  Context& c = ctx();
+  auto e = std::make_shared<SrsEntry>();
+  e->device = c.device;
+  e->range_lo = range_lo;
+  uint32_t cw = msm_choose_window(n);
+  int rc = msm_precompute(&e->bases, d_bases, n, cw, c.stream);
+  if (rc) return hip_fail((hipError_t)rc, "msm_precompute");
+  CAP_HIP(hipStreamSynchronize(c.stream));
+  *out = e;
+  return CAPGPU_OK;
+}
+
+// peer copy of a resident SRS onto the current context
+int clone_srs_to_current(const SrsEntry& src, std::shared_ptr<SrsEntry>* out) {
+  Context& c = ctx();
+  auto e = std::make_shared<SrsEntry>();
+  e->device = c.device;
+  e->range_lo = src.range_lo;
+  e->gamma_deg = src.gamma_deg;
+  e->gamma_pts = src.gamma_pts;
+  e->neg_h = src.neg_h;
+  e->ck_gamma_pts = src.ck_gamma_pts;
+  MsmBases& b = e->bases;
+  b.n = src.bases.n;
+  b.c = src.bases.c;
+  b.windows = src.bases.windows;
+  b.c2 = src.bases.c2;
+  b.windows2 = src.bases.windows2;
+  b.c3 = src.bases.c3;
+  b.windows3 = src.bases.windows3;
+  const size_t n1 = b.n ? b.n : 1;
+  CAP_HIP(hipMalloc(&b.ext, sizeof(g1_affine) * n1 * b.windows));
+  CAP_HIP(copy_between(b.ext, c.device, src.bases.ext, src.device, sizeof(g1_affine) * n1 * b.windows, c.stream));
+  if (src.bases.ext2) {
+    CAP_HIP(hipMalloc(&b.ext2, sizeof(g1_affine) * n1 * b.windows2));
+    CAP_HIP(copy_between(b.ext2, c.device, src.bases.ext2, src.device, sizeof(g1_affine) * n1 * b.windows2, c.stream));
+  }
+  if (src.bases.ext3) {
+    CAP_HIP(hipMalloc(&b.ext3, sizeof(g1_affine) * n1 * b.windows3));
+    CAP_HIP(copy_between(b.ext3, c.device, src.bases.ext3, src.device, sizeof(g1_affine) * n1 * b.windows3, c.stream));
+  }
+  CAP_HIP(hipStreamSynchronize(c.stream));
+  *out = e;
+  return CAPGPU_OK;
+}
+
 }  // namespace
 
 int register_srs(g1_affine* d_bases, size_t n, uint64_t* handle_out) {
   Context& c = ctx();
-  SrsEntry e;
-  uint32_t cw = msm_choose_window(n);
-  int rc = msm_precompute(&e.bases, d_bases, n, cw, c.stream);
-  if (rc) return hip_fail((hipError_t)rc, "msm_precompute");
-  CAP_HIP(hipStreamSynchronize(c.stream));
-  uint64_t h = c.next_handle++;
+  std::shared_ptr<SrsEntry> e;
+  int rc = make_srs_entry(d_bases, n, 0, &e);
+  if (rc) return rc;
+  Runtime& R = rt();
+  const uint64_t h = R.next_handle.fetch_add(1);
+  {
+    std::lock_guard<std::mutex> lk(R.mu);
+    SrsRecord rec;
+    rec.full = e;
+    rec.total_n = n;
+    R.srs[h] = rec;
+  }
   c.srs[h] = e;
   *handle_out = h;
+  return CAPGPU_OK;
+}
+
+int srs_record(uint64_t h, SrsRecord* out) {
+  Runtime& R = rt();
+  std::lock_guard<std::mutex> lk(R.mu);
+  auto it = R.srs.find(h);
+  if (it == R.srs.end()) {
+    set_error("capgpu: unknown SRS handle %llu", (unsigned long long)h);
+    return CAPGPU_ERR_BAD_HANDLE;
+  }
+  *out = it->second;
   return CAPGPU_OK;
 }
 
 SrsEntry* find_srs_entry(uint64_t h) {
   Context& c = ctx();
   auto it = c.srs.find(h);
-  return it == c.srs.end() ? nullptr : &it->second;
+  return it == c.srs.end() ? nullptr : it->second.get();
 }
 
 int find_srs(uint64_t h, const MsmBases** out) {
   Context& c = ctx();
   auto it = c.srs.find(h);
   if (it == c.srs.end()) {
-    set_error("capgpu: unknown SRS handle %llu", (unsigned long long)h);
-    return CAPGPU_ERR_BAD_HANDLE;
+    // first use on this context: replicate from the home context (tables are immutable, the record keeps them alive)
+    SrsRecord rec;
+    int rc = srs_record(h, &rec);
+    if (rc) return rc;
+    if (rec.sharded()) {
+      set_error("capgpu: SRS %llu is sharded by point range over the %zu devices of this process (MSM only)",
+                (unsigned long long)h, rec.shards.size());
+      return CAPGPU_ERR_INVALID_ARG;
+    }
+    std::shared_ptr<SrsEntry> rep;
+    if (rec.full->device == c.device) rep = rec.full;
+    else if ((rc = clone_srs_to_current(*rec.full, &rep))) return rc;
+    {
+      Runtime& R = rt();
+      std::lock_guard<std::mutex> lk(R.mu);
+      if (R.srs.find(h) == R.srs.end()) {  // freed while it was being copied
+        set_error("capgpu: unknown SRS handle %llu", (unsigned long long)h);
+        return CAPGPU_ERR_BAD_HANDLE;
+      }
+    }
+    it = c.srs.emplace(h, rep).first;
   }
-  *out = &it->second.bases;
+  if (it->second->is_shard) {  // entries of a sharded handle are only ever used through the sharded MSM path
+    set_error("capgpu: SRS %llu is sharded by point range over the devices of this process (MSM only)",
+              (unsigned long long)h);
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  *out = &it->second->bases;
   return CAPGPU_OK;
 }
+
+uint64_t register_key(const std::shared_ptr<ProvingKey>& K) {
+  Runtime& R = rt();
+  const uint64_t h = R.next_handle.fetch_add(1);
+  {
+    std::lock_guard<std::mutex> lk(R.mu);
+    R.keys[h] = K;
+  }
+  ctx().keys[h] = K;
+  return h;
+}
+
 
 }  // namespace cap
 
 using namespace cap;
 
+namespace {
+
+// ---- sharded SRS (one process, several devices: SURVEY 8e inside the process) ------------------------------------
+// An SRS of at least this many points is cut by point range over the contexts when it is created.
+size_t shard_min_points() {
+  const char* e = getenv("CAPGPU_SHARD_MIN_POINTS");
+  long long x = e ? atoll(e) : (1ll << 20);
+  return (size_t)(x >= 2 ? x : 2);
+}
+bool should_shard(size_t n) { return num_contexts() > 1 && n >= shard_min_points() && n >= num_contexts(); }
+// range of shard r of S over n points
+void shard_range(size_t n, size_t S, size_t r, size_t* lo, size_t* len) {
+  const size_t base = n / S, rem = n % S;
+  *lo = r * base + std::min(r, rem);
+  *len = base + (r < rem ? 1 : 0);
+}
+
+// runs job(r) for every context r on its own host thread, each thread placed on its context (the caller holds all
+// context locks: AllEntries); returns the first failure and makes its message the caller's
+int for_each_context(const std::function<int(size_t)>& job) {
+  const size_t S = num_contexts();
+  std::vector<int> rcs(S, CAPGPU_OK);
+  std::vector<std::string> errs(S);
+  auto body = [&](size_t r) {
+    ScopedCtx sc(*rt().ctxs[r]);
+    rcs[r] = job(r);
+    if (rcs[r]) errs[r] = last_error();
+  };
+  std::vector<std::thread> th;
+  for (size_t r = 1; r < S; r++) th.emplace_back(body, r);
+  body(0);
+  for (auto& t : th) t.join();
+  for (size_t r = 0; r < S; r++)
+    if (rcs[r]) {
+      set_error("%s", errs[r].c_str());
+      return rcs[r];
+    }
+  return CAPGPU_OK;
+}
+
+// publishes the shards built by for_each_context as one logical handle
+uint64_t register_shards(std::vector<std::shared_ptr<SrsEntry>>& shards, size_t n) {
+  Runtime& R = rt();
+  const uint64_t h = R.next_handle.fetch_add(1);
+  for (size_t r = 0; r < shards.size(); r++) {
+    shards[r]->is_shard = true;
+    R.ctxs[r]->srs[h] = shards[r];
+  }
+  std::lock_guard<std::mutex> lk(R.mu);
+  SrsRecord rec;
+  rec.shards = shards;
+  rec.total_n = n;
+  R.srs[h] = rec;
+  return h;
+}
+
+// `count` MSMs over logical points [offset, offset + n) of a sharded SRS.  scalars: host memory (h_scalars) or device
+// memory of context `home` (d_scalars), array k at + k * stride elements.  Every context runs the part of the range it
+// holds down to one point per MSM; the partials travel to `home` (peer copies of count * 96 bytes: the exchange step of
+// SURVEY 8e) and one wavefront per MSM adds them up into d_out (on home).  The caller holds AllEntries and is on home.
+int msm_sharded(const SrsRecord& rec, Context& home, size_t offset, const uint64_t* h_scalars, const fe* d_scalars,
+                size_t stride, size_t n, int count, int montgomery, g1_jac* d_out) {
+  const size_t S = rec.shards.size();
+  int rc = scratch_reserve(home.gather, sizeof(g1_jac) * S * (size_t)count);
+  if (rc) return rc;
+  g1_jac* gather = (g1_jac*)home.gather.p;
+  CAP_HIP(hipMemsetAsync(gather, 0, sizeof(g1_jac) * S * (size_t)count, home.stream));  // Z = 0: infinity
+  hipEvent_t ready = nullptr;  // home's stream up to here: the device scalars exist, the gather buffer is cleared
+  CAP_HIP(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+  CAP_HIP(hipEventRecord(ready, home.stream));
+  std::vector<hipEvent_t> done(S, nullptr);
+  rc = for_each_context([&](size_t r) -> int {
+    Context& c = ctx();
+    const SrsEntry& sh = *rec.shards[r];
+    const size_t lo = std::max(offset, sh.range_lo), hi = std::min(offset + n, sh.range_lo + sh.bases.n);
+    if (lo >= hi) return CAPGPU_OK;
+    const size_t len = hi - lo;
+    int r2 = scratch_reserve(c.stage_a, sizeof(fe) * len * (size_t)count + sizeof(g1_jac) * (size_t)count);
+    if (r2) return r2;
+    fe* d_sc = (fe*)c.stage_a.p;
+    g1_jac* d_part = (g1_jac*)((char*)c.stage_a.p + sizeof(fe) * len * (size_t)count);
+    CAP_HIP(hipStreamWaitEvent(c.stream, ready, 0));
+    for (int k = 0; k < count; k++) {
+      if (h_scalars)
+        CAP_HIP(hipMemcpyAsync(d_sc + (size_t)k * len, h_scalars + 4 * ((size_t)k * stride + (lo - offset)),
+                               sizeof(fe) * len, hipMemcpyHostToDevice, c.stream));
+      else
+        CAP_HIP(copy_between(d_sc + (size_t)k * len, c.device, d_scalars + (size_t)k * stride + (lo - offset),
+                             home.device, sizeof(fe) * len, c.stream));
+    }
+    if ((r2 = scratch_reserve(c.msm_ws, msm_workspace_bytes(sh.bases, len, (uint32_t)count)))) return r2;
+    r2 = msm_run(sh.bases, lo - sh.range_lo, d_sc, len, 1, 0, len, (uint32_t)count, montgomery, d_part, c.msm_ws.p,
+                 c.msm_ws.cap, c.stream);
+    if (r2) return hip_fail((hipError_t)r2, "msm_run");
+    CAP_HIP(copy_between(gather + r * (size_t)count, home.device, d_part, c.device, sizeof(g1_jac) * (size_t)count,
+                         c.stream));
+    CAP_HIP(hipEventCreateWithFlags(&done[r], hipEventDisableTiming));
+    CAP_HIP(hipEventRecord(done[r], c.stream));
+    return take_launch_error();
+  });
+  (void)hipEventDestroy(ready);
+  for (size_t r = 0; r < S; r++) {
+    if (!done[r]) continue;
+    if (rc == CAPGPU_OK && hipStreamWaitEvent(home.stream, done[r], 0) != hipSuccess) rc = CAPGPU_ERR_HIP;
+    (void)hipEventDestroy(done[r]);
+  }
+  if (rc) return rc;
+  g1_sum_ranks(gather, (uint32_t)S, (uint32_t)count, (uint32_t)count, d_out, home.stream);
+  return take_launch_error();
+}
+
+}  // namespace
+
 extern "C" {
 
-const char* capgpu_last_error(void) { return g_err; }
-const char* capgpu_version(void) { return "capgpu 0.1.0 (gfx950)"; }
+const char* capgpu_last_error(void) { return last_error(); }
+const char* capgpu_version(void) { return "capgpu 0.2.0 (gfx950)"; }
 
 int capgpu_init(const int* device_ids, int n_devices) {
-  Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
-  if (c.initialised) return CAPGPU_OK;
+  static std::mutex init_mu;
+  std::lock_guard<std::mutex> ilk(init_mu);
+  Runtime& R = rt();
+  if (R.initialised.load()) return CAPGPU_OK;
   int count = 0;
   hipError_t e = hipGetDeviceCount(&count);
   if (e != hipSuccess || count == 0) {
@@ -258,50 +536,149 @@ int capgpu_init(const int* device_ids, int n_devices) {
     (void)hipGetLastError();
     return CAPGPU_ERR_NO_DEVICE;
   }
-  int dev = (device_ids && n_devices > 0) ? device_ids[0] : 0;
-  if (dev < 0 || dev >= count) {
-    set_error("capgpu: device id %d out of range (0..%d)", dev, count - 1);
+  std::vector<int> ids;
+  if (device_ids && n_devices > 0) ids.assign(device_ids, device_ids + n_devices);
+  else ids.push_back(0);
+  // one context per listed device.  A device listed twice is refused unless CAPGPU_ALLOW_DUPLICATE_DEVICES=1 (tests
+  // drive the multi-device paths on one GPU that way); CAPGPU_CONTEXTS_PER_DEVICE=k gives every listed device k
+  // contexts, whose batches then overlap on the device (a batch's latency-bound launches and host transcript phases
+  // run under the other's issue-bound kernels).
+  const char* dup_env = getenv("CAPGPU_ALLOW_DUPLICATE_DEVICES");
+  const bool allow_dup = dup_env && atoi(dup_env) != 0;
+  for (size_t i = 0; i < ids.size(); i++) {
+    if (ids[i] < 0 || ids[i] >= count) {
+      set_error("capgpu: device id %d out of range (0..%d)", ids[i], count - 1);
+      return CAPGPU_ERR_INVALID_ARG;
+    }
+    for (size_t j = 0; j < i && !allow_dup; j++)
+      if (ids[j] == ids[i]) {
+        set_error("capgpu_init: device %d listed twice", ids[i]);
+        return CAPGPU_ERR_INVALID_ARG;
+      }
+  }
+  {
+    const char* pe = getenv("CAPGPU_CONTEXTS_PER_DEVICE");
+    const int per = pe ? std::min(std::max(atoi(pe), 1), 8) : 1;
+    std::vector<int> x;
+    for (int d : ids)
+      for (int k = 0; k < per; k++) x.push_back(d);
+    ids.swap(x);
+  }
+  if (ids.size() > 64) {
+    set_error("capgpu_init: %zu contexts requested, 64 at most", ids.size());
     return CAPGPU_ERR_INVALID_ARG;
   }
-  CAP_HIP(hipSetDevice(dev));
-  hipDeviceProp_t prop;
-  CAP_HIP(hipGetDeviceProperties(&prop, dev));
-  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
-    set_error("capgpu: device %d is %s; kernels are built for gfx950 (MI355X) only", dev, prop.gcnArchName);
-    return CAPGPU_ERR_NO_DEVICE;
+  std::vector<std::unique_ptr<Context>> made;
+  auto undo = [&] {
+    for (auto& c : made) {
+      (void)hipSetDevice(c->device);
+      ntt_free_small_tables(&c->small);
+      if (c->own_stream) hipStreamDestroy(c->own_stream);
+    }
+  };
+  for (size_t i = 0; i < ids.size(); i++) {
+    const int dev = ids[i];
+    hipDeviceProp_t prop;
+    hipError_t he = hipSetDevice(dev);
+    if (he == hipSuccess) he = hipGetDeviceProperties(&prop, dev);
+    if (he != hipSuccess) {
+      undo();
+      return hip_fail(he, "hipSetDevice / hipGetDeviceProperties");
+    }
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) {
+      set_error("capgpu: device %d is %s; kernels are built for gfx950 (MI355X) only", dev, prop.gcnArchName);
+      undo();
+      return CAPGPU_ERR_NO_DEVICE;
+    }
+    std::unique_ptr<Context> c(new Context);
+    c->slot = (int)i;
+    c->device = dev;
+    he = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
+    if (he != hipSuccess) {
+      undo();
+      return hip_fail(he, "hipStreamCreateWithFlags");
+    }
+    c->stream = c->own_stream;
+    made.push_back(std::move(c));
+    int rc = ntt_build_small_tables(&made.back()->small, made.back()->stream);
+    if (rc) {
+      undo();
+      return hip_fail((hipError_t)rc, "ntt_build_small_tables");
+    }
+    made.back()->initialised = true;
   }
-  c.device = dev;
-  CAP_HIP(hipStreamCreateWithFlags(&c.own_stream, hipStreamNonBlocking));
-  c.stream = c.own_stream;
-  int rc = ntt_build_small_tables(&c.small, c.stream);
-  if (rc) return hip_fail((hipError_t)rc, "ntt_build_small_tables");
-  c.initialised = true;
+  R.ctxs = std::move(made);
+  R.rr.store(0);
+  R.initialised.store(true, std::memory_order_release);
+  (void)hipSetDevice(R.ctxs[0]->device);
   return CAPGPU_OK;
 }
 
 void capgpu_shutdown(void) {
-  Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
-  if (!c.initialised) return;
+  Runtime& R = rt();
+  if (!R.initialised.load()) return;
   (void)capgpu_comm_destroy();
-  hipDeviceSynchronize();
-  c.keys.clear();
-  for (auto& kv : c.srs) msm_free_bases(&kv.second.bases);
-  c.srs.clear();
-  for (auto& kv : c.domains) ntt_free_domain(&kv.second);
-  c.domains.clear();
-  for (auto& kv : c.domains3) ntt3_free_domain(&kv.second);
-  c.domains3.clear();
-  ntt_free_small_tables(&c.small);
-  for (Scratch* s : {&c.ntt_scratch, &c.msm_ws, &c.stage_a, &c.stage_b}) {
-    if (s->p) hipFree(s->p);
-    s->p = nullptr;
-    s->cap = 0;
+  {
+    AllEntries all;
+    for (auto& cp : R.ctxs) {
+      Context& c = *cp;
+      (void)hipSetDevice(c.device);
+      (void)hipStreamSynchronize(c.stream);
+      if (c.copy_stream) (void)hipStreamSynchronize(c.copy_stream);
+    }
+    {
+      std::lock_guard<std::mutex> lk(R.mu);
+      R.srs.clear();
+      R.keys.clear();
+    }
+    for (auto& cp : R.ctxs) {
+      Context& c = *cp;
+      (void)hipSetDevice(c.device);
+      c.keys.clear();
+      c.srs.clear();
+      for (auto& kv : c.domains) ntt_free_domain(&kv.second);
+      c.domains.clear();
+      for (auto& kv : c.domains3) ntt3_free_domain(&kv.second);
+      c.domains3.clear();
+      ntt_free_small_tables(&c.small);
+      for (Scratch* s : {&c.ntt_scratch, &c.msm_ws, &c.stage_a, &c.stage_b, &c.prove_ws, &c.gather}) {
+        if (s->p) hipFree(s->p);
+        s->p = nullptr;
+        s->cap = 0;
+      }
+      c.pool.reset();
+      if (c.own_stream) hipStreamDestroy(c.own_stream);
+      if (c.copy_stream) hipStreamDestroy(c.copy_stream);
+      c.own_stream = c.stream = c.copy_stream = nullptr;
+      c.initialised = false;
+    }
+    R.initialised.store(false, std::memory_order_release);
   }
-  if (c.own_stream) hipStreamDestroy(c.own_stream);
-  if (c.copy_stream) hipStreamDestroy(c.copy_stream);
-  c.own_stream = c.stream = c.copy_stream = nullptr;
-  c.initialised = false;
+  tl_ctx = nullptr;
+  tl_bound = -1;
+  R.ctxs.clear();
+}
+
+int capgpu_device_count(int* count_out) {
+  if (!count_out) return CAPGPU_ERR_INVALID_ARG;
+  *count_out = rt().initialised.load() ? (int)num_contexts() : 0;
+  return CAPGPU_OK;
+}
+int capgpu_set_device(int slot) {
+  CAP_CHECK_INIT();
+  if (slot < -1 || slot >= (int)num_contexts()) {
+    set_error("capgpu_set_device: slot %d out of range (-1 .. %zu)", slot, num_contexts() - 1);
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  tl_bound = slot;
+  CAP_HIP(hipSetDevice(ctx().device));
+  return CAPGPU_OK;
+}
+int capgpu_get_device(int* slot_out, int* hip_device_out) {
+  CAP_CHECK_INIT();
+  if (slot_out) *slot_out = tl_bound;
+  if (hip_device_out) *hip_device_out = ctx().device;
+  return CAPGPU_OK;
 }
 
 int capgpu_device_info(char* name_out, int* cu_count_out, uint64_t* hbm_bytes_out) {
@@ -319,41 +696,41 @@ int capgpu_device_info(char* name_out, int* cu_count_out, uint64_t* hbm_bytes_ou
 int capgpu_malloc(void** dev_ptr_out, size_t bytes) {
   CAP_CHECK_INIT();
   if (!dev_ptr_out) return CAPGPU_ERR_INVALID_ARG;
-  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  Entry lk(ctx());
   CAP_HIP(hipMalloc(dev_ptr_out, bytes ? bytes : 1));
   return CAPGPU_OK;
 }
 int capgpu_free(void* dev_ptr) {
   CAP_CHECK_INIT();
-  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  Entry lk(ctx());
   CAP_HIP(hipStreamSynchronize(ctx().stream));
   CAP_HIP(hipFree(dev_ptr));
   return CAPGPU_OK;
 }
 int capgpu_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes) {
   CAP_CHECK_INIT();
-  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  Entry lk(ctx());
   CAP_HIP(hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx().stream));
   CAP_HIP(hipStreamSynchronize(ctx().stream));
   return CAPGPU_OK;
 }
 int capgpu_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes) {
   CAP_CHECK_INIT();
-  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  Entry lk(ctx());
   CAP_HIP(hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx().stream));
   CAP_HIP(hipStreamSynchronize(ctx().stream));
   return CAPGPU_OK;
 }
 int capgpu_sync(void) {
   CAP_CHECK_INIT();
-  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  Entry lk(ctx());
   CAP_HIP(hipStreamSynchronize(ctx().stream));
   return CAPGPU_OK;
 }
 int capgpu_set_stream(void* hip_stream) {
   CAP_CHECK_INIT();
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  Entry lk(c);
   CAP_HIP(hipStreamSynchronize(c.stream));
   c.stream = hip_stream ? (hipStream_t)hip_stream : c.own_stream;
   return CAPGPU_OK;
@@ -367,23 +744,55 @@ int capgpu_srs_upload(const void* bases, size_t n, size_t stride_bytes, int coor
     set_error("capgpu_srs_upload: bad argument (stride must be 64 or 72)");
     return CAPGPU_ERR_INVALID_ARG;
   }
-  Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
-  std::vector<g1_affine> packed(n ? n : 1);
   const unsigned char* src = (const unsigned char*)bases;
-  for (size_t i = 0; i < n; i++) {
-    memcpy(&packed[i], src + i * stride_bytes, 64);
-    if (stride_bytes == 72 && src[i * stride_bytes + 64]) memset(&packed[i], 0, 64);  // infinity flag
+  // packs [lo, lo + len) of the caller's array, uploads it to the current context and builds its window tables
+  auto upload_range = [&](size_t lo, size_t len, std::shared_ptr<SrsEntry>* out) -> int {
+    Context& c = ctx();
+    std::vector<g1_affine> packed(len ? len : 1);
+    for (size_t i = 0; i < len; i++) {
+      memcpy(&packed[i], src + (lo + i) * stride_bytes, 64);
+      if (stride_bytes == 72 && src[(lo + i) * stride_bytes + 64]) memset(&packed[i], 0, 64);  // infinity flag
+    }
+    DevTmp<g1_affine> d;
+    CAP_HIP(d.alloc(len));
+    CAP_HIP(hipMemcpyAsync(d, packed.data(), sizeof(g1_affine) * len, hipMemcpyHostToDevice, c.stream));
+    if (!coords_montgomery && len) {
+      size_t cnt = 2 * len;
+      launch("fq_to_mont_kernel", fq_to_mont_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c.stream,
+             reinterpret_cast<fe*>(d.p), cnt);
+    }
+    return make_srs_entry(d, len, lo, out);
+  };
+  if (should_shard(n)) {
+    AllEntries all;
+    const size_t S = num_contexts();
+    std::vector<std::shared_ptr<SrsEntry>> shards(S);
+    int rc = for_each_context([&](size_t r) -> int {
+      size_t lo, len;
+      shard_range(n, S, r, &lo, &len);
+      return upload_range(lo, len, &shards[r]);
+    });
+    if (rc) return rc;
+    *handle_out = register_shards(shards, n);
+    return CAPGPU_OK;
   }
-  DevTmp<g1_affine> d;
-  CAP_HIP(d.alloc(n));
-  CAP_HIP(hipMemcpyAsync(d, packed.data(), sizeof(g1_affine) * n, hipMemcpyHostToDevice, c.stream));
-  if (!coords_montgomery && n) {
-    size_t cnt = 2 * n;
-    launch("fq_to_mont_kernel", fq_to_mont_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, c.stream,
-           reinterpret_cast<fe*>(d.p), cnt);
+  Context& c = ctx();
+  Entry lk(c);
+  std::shared_ptr<SrsEntry> e;
+  int rc = upload_range(0, n, &e);
+  if (rc) return rc;
+  Runtime& R = rt();
+  const uint64_t h = R.next_handle.fetch_add(1);
+  {
+    std::lock_guard<std::mutex> rlk(R.mu);
+    SrsRecord rec;
+    rec.full = e;
+    rec.total_n = n;
+    R.srs[h] = rec;
   }
-  return register_srs(d, n, handle_out);
+  c.srs[h] = e;
+  *handle_out = h;
+  return take_launch_error();
 }
 
 static int srs_generate_common(int mode, const uint64_t a[4], const uint64_t b[4], size_t n, uint64_t* handle_out) {
@@ -392,30 +801,53 @@ static int srs_generate_common(int mode, const uint64_t a[4], const uint64_t b[4
     set_error("capgpu_srs_generate: bad argument");
     return CAPGPU_ERR_INVALID_ARG;
   }
+  const fe am = Fr::to_mont(fe_from_u64x4(a));
+  const fe bm = b ? Fr::to_mont(fe_from_u64x4(b)) : Fr::zero();
+  // points [lo, lo + len) of the sequence, generated on the current context
+  auto generate_range = [&](size_t lo, size_t len, g1_affine* d) -> int {
+    Context& c = ctx();
+    DevTmp<fe> d_tab, d_pw;
+    if (mode == 0) {
+      std::vector<fe> pw(64);
+      fe x = am;
+      for (int i = 0; i < 64; i++) {
+        pw[i] = x;
+        x = Fr::sqr(x);
+      }
+      CAP_HIP(d_pw.alloc(64));
+      CAP_HIP(d_tab.alloc(len));
+      CAP_HIP(hipMemcpyAsync(d_pw, pw.data(), sizeof(fe) * 64, hipMemcpyHostToDevice, c.stream));
+      launch("fr_powers_kernel", fr_powers_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c.stream, d_tab.p,
+             len, (const fe*)d_pw.p, lo);
+      CAP_HIP(hipStreamSynchronize(c.stream));
+    }
+    launch("srs_fixed_base_kernel", srs_fixed_base_kernel, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, c.stream,
+           d, len, mode, (const fe*)d_tab.p, am, bm, lo);
+    CAP_HIP(hipStreamSynchronize(c.stream));
+    return take_launch_error();
+  };
+  if (should_shard(n)) {
+    AllEntries all;
+    const size_t S = num_contexts();
+    std::vector<std::shared_ptr<SrsEntry>> shards(S);
+    int rc = for_each_context([&](size_t r) -> int {
+      size_t lo, len;
+      shard_range(n, S, r, &lo, &len);
+      DevTmp<g1_affine> d;
+      CAP_HIP(d.alloc(len));
+      int r2 = generate_range(lo, len, d);
+      return r2 ? r2 : make_srs_entry(d, len, lo, &shards[r]);
+    });
+    if (rc) return rc;
+    *handle_out = register_shards(shards, n);
+    return CAPGPU_OK;
+  }
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  Entry lk(c);
   DevTmp<g1_affine> d;
   CAP_HIP(d.alloc(n));
-  DevTmp<fe> d_tab, d_pw;
-  fe am = Fr::to_mont(fe_from_u64x4(a));
-  fe bm = b ? Fr::to_mont(fe_from_u64x4(b)) : Fr::zero();
-  if (mode == 0) {
-    std::vector<fe> pw(64);
-    fe x = am;
-    for (int i = 0; i < 64; i++) {
-      pw[i] = x;
-      x = Fr::sqr(x);
-    }
-    CAP_HIP(d_pw.alloc(64));
-    CAP_HIP(d_tab.alloc(n));
-    CAP_HIP(hipMemcpyAsync(d_pw, pw.data(), sizeof(fe) * 64, hipMemcpyHostToDevice, c.stream));
-    launch("fr_powers_kernel", fr_powers_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream, d_tab.p, n,
-           (const fe*)d_pw.p);
-    CAP_HIP(hipStreamSynchronize(c.stream));
-  }
-  launch("srs_fixed_base_kernel", srs_fixed_base_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, c.stream,
-         d.p, n, mode, (const fe*)d_tab.p, am, bm);
-  CAP_HIP(hipStreamSynchronize(c.stream));
+  int rc = generate_range(0, n, d);
+  if (rc) return rc;
   return register_srs(d, n, handle_out);
 }
 int capgpu_srs_generate(const uint64_t tau[4], size_t n, uint64_t* handle_out) {
@@ -428,30 +860,28 @@ int capgpu_srs_generate_affine_seq(const uint64_t a[4], const uint64_t b[4], siz
 
 int capgpu_srs_size(uint64_t handle, size_t* n_out) {
   CAP_CHECK_INIT();
-  Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
-  auto it = c.srs.find(handle);
-  if (it == c.srs.end() || !n_out) {
-    set_error("capgpu: unknown SRS handle %llu", (unsigned long long)handle);
-    return CAPGPU_ERR_BAD_HANDLE;
-  }
-  *n_out = it->second.bases.n;
+  SrsRecord rec;
+  int rc = srs_record(handle, &rec);
+  if (rc) return rc;
+  if (!n_out) return CAPGPU_ERR_INVALID_ARG;
+  *n_out = rec.total_n;
   return CAPGPU_OK;
 }
-int capgpu_srs_download(uint64_t handle, size_t offset, size_t n, void* out) {
+int capgpu_srs_shards(uint64_t handle, int* shards_out) {
   CAP_CHECK_INIT();
+  SrsRecord rec;
+  int rc = srs_record(handle, &rec);
+  if (rc) return rc;
+  if (shards_out) *shards_out = rec.sharded() ? (int)rec.shards.size() : 1;
+  return CAPGPU_OK;
+}
+
+// copies entries [off, off + n) of a resident table back as arkworks-form points (current context)
+static int download_range(const SrsEntry& e, size_t off, size_t n, g1_affine* pts) {
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
-  auto it = c.srs.find(handle);
-  if (it == c.srs.end()) {
-    set_error("capgpu: unknown SRS handle %llu", (unsigned long long)handle);
-    return CAPGPU_ERR_BAD_HANDLE;
-  }
-  if (offset + n > it->second.bases.n || !out) return CAPGPU_ERR_INVALID_ARG;
-  CAP_HIP(hipMemcpyAsync(out, it->second.bases.ext + offset, sizeof(g1_affine) * n, hipMemcpyDeviceToHost, c.stream));
+  CAP_HIP(hipMemcpyAsync(pts, e.bases.ext + off, sizeof(g1_affine) * n, hipMemcpyDeviceToHost, c.stream));
   CAP_HIP(hipStreamSynchronize(c.stream));
   // the resident table is in the internal Montgomery form (x * 2^261); hand back arkworks' form (x * 2^256)
-  g1_affine* pts = reinterpret_cast<g1_affine*>(out);
   for (size_t i = 0; i < n; i++) {
     if (G1::is_inf(pts[i])) continue;
     pts[i].x = Fq29::to_ext(Fq29::load(pts[i].x));
@@ -459,18 +889,53 @@ int capgpu_srs_download(uint64_t handle, size_t offset, size_t n, void* out) {
   }
   return CAPGPU_OK;
 }
+int capgpu_srs_download(uint64_t handle, size_t offset, size_t n, void* out) {
+  CAP_CHECK_INIT();
+  SrsRecord rec;
+  int rc = srs_record(handle, &rec);
+  if (rc) return rc;
+  if (offset + n > rec.total_n || !out) return CAPGPU_ERR_INVALID_ARG;
+  g1_affine* pts = reinterpret_cast<g1_affine*>(out);
+  if (rec.sharded()) {
+    for (size_t r = 0; r < rec.shards.size(); r++) {
+      const SrsEntry& sh = *rec.shards[r];
+      const size_t lo = std::max(offset, sh.range_lo), hi = std::min(offset + n, sh.range_lo + sh.bases.n);
+      if (lo >= hi) continue;
+      Context& c = *rt().ctxs[r];
+      ScopedCtx sc(c);
+      Entry lk(c);
+      if ((rc = download_range(sh, lo - sh.range_lo, hi - lo, pts + (lo - offset)))) return rc;
+    }
+    return CAPGPU_OK;
+  }
+  Context& c = ctx();
+  Entry lk(c);
+  const MsmBases* B = nullptr;
+  if ((rc = find_srs(handle, &B))) return rc;
+  return download_range(*find_srs_entry(handle), offset, n, pts);
+}
 int capgpu_srs_free(uint64_t handle) {
   CAP_CHECK_INIT();
-  Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
-  auto it = c.srs.find(handle);
-  if (it == c.srs.end()) {
-    set_error("capgpu: unknown SRS handle %llu", (unsigned long long)handle);
-    return CAPGPU_ERR_BAD_HANDLE;
+  Runtime& R = rt();
+  {
+    std::lock_guard<std::mutex> lk(R.mu);
+    auto it = R.srs.find(handle);
+    if (it == R.srs.end()) {
+      set_error("capgpu: unknown SRS handle %llu", (unsigned long long)handle);
+      return CAPGPU_ERR_BAD_HANDLE;
+    }
+    R.srs.erase(it);
   }
-  hipStreamSynchronize(c.stream);
-  msm_free_bases(&it->second.bases);
-  c.srs.erase(it);
+  // every context that holds the tables drains its stream before letting go of them
+  for (auto& cp : R.ctxs) {
+    Context& c = *cp;
+    ScopedCtx sc(c);
+    Entry lk(c);
+    auto it = c.srs.find(handle);
+    if (it == c.srs.end()) continue;
+    (void)hipStreamSynchronize(c.stream);
+    c.srs.erase(it);
+  }
   return CAPGPU_OK;
 }
 
@@ -478,23 +943,32 @@ int capgpu_srs_free(uint64_t handle) {
 int capgpu_msm_g1_dev(uint64_t srs_handle, size_t offset, const void* d_scalars, size_t scalar_stride, size_t n,
                       int count, int scalars_montgomery, void* d_out_xyz) {
   CAP_CHECK_INIT();
-  Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
-  auto it = c.srs.find(srs_handle);
-  if (it == c.srs.end()) {
-    set_error("capgpu: unknown SRS handle %llu", (unsigned long long)srs_handle);
-    return CAPGPU_ERR_BAD_HANDLE;
-  }
-  const MsmBases& B = it->second.bases;
-  if (count < 0 || offset + n > B.n || (!d_scalars && n) || !d_out_xyz) {
-    set_error("capgpu_msm_g1: bad argument (offset %zu + n %zu vs SRS size %zu)", offset, n, B.n);
+  SrsRecord rec;
+  int rc = srs_record(srs_handle, &rec);
+  if (rc) return rc;
+  if (count < 0 || offset + n > rec.total_n || (!d_scalars && n) || !d_out_xyz) {
+    set_error("capgpu_msm_g1: bad argument (offset %zu + n %zu vs SRS size %zu)", offset, n, rec.total_n);
     return CAPGPU_ERR_INVALID_ARG;
   }
   if (count == 0) return CAPGPU_OK;
-  size_t need = msm_workspace_bytes(B, n, (uint32_t)count);
-  int rc = scratch_reserve(c.msm_ws, need);
+  Context& c = ctx();
+  if (rec.sharded()) {
+    if (thread_entry_depth() > 0) {  // (would take the other contexts' locks out of order)
+      set_error("capgpu_msm_g1_dev: a sharded SRS cannot be used from inside another entry point");
+      return CAPGPU_ERR_INVALID_ARG;
+    }
+    AllEntries all;
+    ScopedCtx sc(c);
+    return msm_sharded(rec, c, offset, nullptr, (const fe*)d_scalars, scalar_stride, n, count, scalars_montgomery,
+                       (g1_jac*)d_out_xyz);
+  }
+  Entry lk(c);
+  const MsmBases* B = nullptr;
+  if ((rc = find_srs(srs_handle, &B))) return rc;
+  size_t need = msm_workspace_bytes(*B, n, (uint32_t)count);
+  rc = scratch_reserve(c.msm_ws, need);
   if (rc) return rc;
-  rc = msm_run(B, offset, (const fe*)d_scalars, scalar_stride, 1, 0, n, (uint32_t)count, scalars_montgomery,
+  rc = msm_run(*B, offset, (const fe*)d_scalars, scalar_stride, 1, 0, n, (uint32_t)count, scalars_montgomery,
                (g1_jac*)d_out_xyz, c.msm_ws.p, c.msm_ws.cap, c.stream);
   if (rc) return hip_fail((hipError_t)rc, "msm_run");
   return take_launch_error();
@@ -502,12 +976,22 @@ int capgpu_msm_g1_dev(uint64_t srs_handle, size_t offset, const void* d_scalars,
 
 int capgpu_msm_plan(uint64_t srs_handle, size_t n, int count, char* buf, size_t cap) {
   CAP_CHECK_INIT();
-  Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
-  const MsmBases* B = nullptr;
-  int rc = find_srs(srs_handle, &B);
+  SrsRecord rec;
+  int rc = srs_record(srs_handle, &rec);
   if (rc) return rc;
-  if (!buf || cap == 0 || count < 1 || n > B->n) return CAPGPU_ERR_INVALID_ARG;
+  if (!buf || cap == 0 || count < 1 || n > rec.total_n) return CAPGPU_ERR_INVALID_ARG;
+  if (rec.sharded()) {  // the plan of the largest shard's part, prefixed with the shard count
+    const SrsEntry& sh = *rec.shards[0];
+    int len = snprintf(buf, cap, "shards=%zu ", rec.shards.size());
+    if (len > 0 && (size_t)len < cap)
+      msm_plan_describe(sh.bases, std::min(sh.bases.n, (n + rec.shards.size() - 1) / rec.shards.size()), (uint32_t)count,
+                        buf + len, cap - len);
+    return CAPGPU_OK;
+  }
+  Context& c = ctx();
+  Entry lk(c);
+  const MsmBases* B = nullptr;
+  if ((rc = find_srs(srs_handle, &B))) return rc;
   msm_plan_describe(*B, n, (uint32_t)count, buf, cap);
   return CAPGPU_OK;
 }
@@ -516,8 +1000,35 @@ int capgpu_msm_g1_batch(uint64_t srs_handle, const size_t* offsets, const uint64
                         int count, uint64_t* out_xyz) {
   CAP_CHECK_INIT();
   if (count < 0 || (count && (!offsets || !scalars || !ns || !out_xyz))) return CAPGPU_ERR_INVALID_ARG;
-  Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  if (count == 0) return CAPGPU_OK;
+  SrsRecord rec;
+  int rc = srs_record(srs_handle, &rec);
+  if (rc) return rc;
+  if (rec.sharded()) {
+    Context& c = ctx();
+    if (thread_entry_depth() > 0) {
+      set_error("capgpu_msm_g1: a sharded SRS cannot be used from inside another entry point");
+      return CAPGPU_ERR_INVALID_ARG;
+    }
+    AllEntries all;
+    ScopedCtx sc(c);
+    if ((rc = scratch_reserve(c.stage_b, sizeof(g1_jac)))) return rc;
+    for (int g = 0; g < count; g++) {
+      if (offsets[g] + ns[g] > rec.total_n || (!scalars[g] && ns[g])) {
+        set_error("capgpu_msm_g1: bad argument (offset %zu + n %zu vs SRS size %zu)", offsets[g], ns[g], rec.total_n);
+        return CAPGPU_ERR_INVALID_ARG;
+      }
+      if ((rc = msm_sharded(rec, c, offsets[g], scalars[g], nullptr, ns[g], ns[g], 1, 0, (g1_jac*)c.stage_b.p)))
+        return rc;
+      CAP_HIP(hipMemcpyAsync(out_xyz + 12 * (size_t)g, c.stage_b.p, sizeof(g1_jac), hipMemcpyDeviceToHost, c.stream));
+      CAP_HIP(hipStreamSynchronize(c.stream));
+    }
+    return CAPGPU_OK;
+  }
+  // host buffers, logical handle: an unbound thread's call goes to whichever context is free
+  Context& c = pick_context();
+  ScopedCtx sc(c);
+  Entry lk(c);
   // equal (offset, n) entries run as one batched launch; otherwise one launch each
   bool uniform = true;
   for (int i = 1; i < count; i++) uniform = uniform && offsets[i] == offsets[0] && ns[i] == ns[0];
@@ -525,7 +1036,7 @@ int capgpu_msm_g1_batch(uint64_t srs_handle, const size_t* offsets, const uint64
   for (int g = 0; g < groups; g++) {
     int first = uniform ? 0 : g, cnt = uniform ? count : 1;
     size_t n = ns[first];
-    int rc = scratch_reserve(c.stage_a, sizeof(fe) * (n ? n : 1) * cnt + 96 * cnt);
+    rc = scratch_reserve(c.stage_a, sizeof(fe) * (n ? n : 1) * cnt + 96 * cnt);
     if (rc) return rc;
     fe* d_sc = (fe*)c.stage_a.p;
     void* d_out = (char*)c.stage_a.p + sizeof(fe) * (n ? n : 1) * cnt;
@@ -549,7 +1060,7 @@ int capgpu_g1_sum(const uint64_t* points_xyz, size_t n, uint64_t out_xyz[12]) {
   CAP_CHECK_INIT();
   if ((!points_xyz && n) || !out_xyz) return CAPGPU_ERR_INVALID_ARG;
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  Entry lk(c);
   int rc = scratch_reserve(c.stage_a, sizeof(g1_jac) * (n + 1));
   if (rc) return rc;
   g1_jac* d = (g1_jac*)c.stage_a.p;
@@ -557,7 +1068,7 @@ int capgpu_g1_sum(const uint64_t* points_xyz, size_t n, uint64_t out_xyz[12]) {
   launch("g1_sum_kernel", g1_sum_kernel, dim3(1), dim3(64), 0, c.stream, (const g1_jac*)(d + 1), n, d);
   CAP_HIP(hipMemcpyAsync(out_xyz, d, sizeof(g1_jac), hipMemcpyDeviceToHost, c.stream));
   CAP_HIP(hipStreamSynchronize(c.stream));
-  return CAPGPU_OK;
+  return take_launch_error();
 }
 
 // ---- NTT ------------------------------------------------------------------------------------------
@@ -570,7 +1081,7 @@ int capgpu_ntt_fr_dev(void* d_data, size_t stride_elems, int count, uint32_t log
   }
   if (count == 0) return CAPGPU_OK;
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  Entry lk(c);
   const NttDomain* dom = nullptr;
   int rc = get_domain(log_n, &dom);
   if (rc) return rc;
@@ -587,8 +1098,9 @@ int capgpu_ntt_fr_batch(uint64_t* const* data, int count, uint32_t log_n, int di
   CAP_CHECK_INIT();
   if (count < 0 || (count && !data) || log_n > 28) return CAPGPU_ERR_INVALID_ARG;
   if (count == 0) return CAPGPU_OK;
-  Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  Context& c = pick_context();
+  ScopedCtx sc(c);
+  Entry lk(c);
   size_t n = (size_t)1 << log_n;
   int rc = scratch_reserve(c.stage_b, sizeof(fe) * n * count);
   if (rc) return rc;
@@ -615,7 +1127,7 @@ int capgpu_ubench_mad_rate(double* lane_ops_per_s_out) {
   CAP_CHECK_INIT();
   if (!lane_ops_per_s_out) return CAPGPU_ERR_INVALID_ARG;
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  Entry lk(c);
   hipDeviceProp_t prop;
   CAP_HIP(hipGetDeviceProperties(&prop, c.device));
   const int blocks = prop.multiProcessorCount * 8, iters = 2000;  // 8 workgroups of 4 waves per CU: 8 waves per SIMD
@@ -643,20 +1155,37 @@ int capgpu_ubench_mad_rate(double* lane_ops_per_s_out) {
   return take_launch_error();
 }
 
+// the profiler is per context (contexts launch concurrently); the ABI reports the sums over all of them
 int capgpu_profile_enable(int on) {
-  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
-  profiler().on = on != 0;
+  for (auto& cp : rt().ctxs) {
+    Entry lk(*cp);
+    cp->prof.on = on != 0;
+  }
   return CAPGPU_OK;
 }
 int capgpu_profile_reset(void) {
-  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
-  profiler().reset();
+  for (auto& cp : rt().ctxs) {
+    ScopedCtx sc(*cp);
+    Entry lk(*cp);
+    cp->prof.reset();
+  }
   return CAPGPU_OK;
 }
+static std::map<std::string, Profiler::Stat> profile_totals() {
+  std::map<std::string, Profiler::Stat> tot;
+  for (auto& cp : rt().ctxs) {
+    ScopedCtx sc(*cp);
+    Entry lk(*cp);
+    for (const auto& kv : cp->prof.stats()) {
+      tot[kv.first].ms += kv.second.ms;
+      tot[kv.first].launches += kv.second.launches;
+    }
+  }
+  return tot;
+}
 int capgpu_profile_get(const char* name, double* total_ms_out, uint64_t* launches_out) {
-  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   if (!name) return CAPGPU_ERR_INVALID_ARG;
-  const auto& st = profiler().stats();
+  const auto st = profile_totals();
   auto it = st.find(name);
   double ms = 0;
   uint64_t cnt = 0;
@@ -669,11 +1198,10 @@ int capgpu_profile_get(const char* name, double* total_ms_out, uint64_t* launche
   return CAPGPU_OK;
 }
 int capgpu_profile_dump(char* buf, size_t cap) {
-  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   if (!buf || cap == 0) return CAPGPU_ERR_INVALID_ARG;
   size_t o = 0;
   buf[0] = 0;
-  for (const auto& kv : profiler().stats()) {
+  for (const auto& kv : profile_totals()) {
     int w = snprintf(buf + o, cap - o, "%s %.6f %llu\n", kv.first.c_str(), kv.second.ms,
                      (unsigned long long)kv.second.launches);
     if (w < 0 || (size_t)w >= cap - o) break;

@@ -1,19 +1,28 @@
-// Multi-GPU exchange step of the point-range-sharded MSM, inside the C ABI.
+// Multi-GPU exchange step of the point-range-sharded MSM, inside the C ABI, for jobs that run ONE
+// PROCESS PER GPU.  (A single process that drives several GPUs needs no communicator: capgpu_init binds them all and the
+// sharded MSM of capgpu.hip moves the partials with peer copies.)
 //
-// One process per GPU.  Rank g keeps the window table of its point range resident, receives the matching scalar
-// slice, and runs the whole Pippenger locally down to ONE point per MSM.  The single exchange step is an all-gather of
-// those 96-byte Jacobian points over RCCL (xGMI), enqueued on the library stream straight from device memory, followed
-// by G - 1 group additions on the device.  RCCL has no elliptic-curve reduction operator, so there is no all-reduce;
-// exchanging bucket arrays would move 2^c * 96 B per window for nothing.  The message is latency-bound (96 B x count
-// per rank): xGMI bandwidth plays no role.
+// Rank g keeps the window table of its point range resident, receives the matching scalar slice, and runs the whole
+// Pippenger locally down to ONE point per MSM.  The single exchange step is an all-gather of those 96-byte Jacobian
+// points over RCCL (xGMI), enqueued on the library stream straight from device memory, followed by G - 1 group
+// additions on the device.  RCCL has no elliptic-curve reduction operator, so there is no all-reduce; exchanging bucket
+// arrays would move 2^c * 96 B per window for nothing.  The message is latency-bound (96 B x count per rank): xGMI
+// bandwidth plays no role.
 //
-// A caller that is one process with many threads (the reference: rayon, src/utils/params_builder.rs:194-226) starts
-// one worker process per GPU and hands each its range; this file is what those workers call.
+// Failure handling: every rank's payload carries a status word behind its points.  A rank whose local step failed still
+// takes part in the all-gather (points at infinity, status = its error code), so nobody is left waiting, and every rank
+// returns an error afterwards.  A rank that never arrives is caught by a deadline (CAPGPU_COMM_TIMEOUT_MS, default
+// 60 s) on the communicator's creation and on the wait behind each exchange: the communicator is aborted and the call
+// fails instead of hanging with the context lock held.
 //
 // RCCL is loaded at capgpu_comm_init time (dlopen), so the library itself loads - and the single-GPU path runs - on
 // machines without it.  If the process already holds an RCCL (PyTorch ships one), that copy is used.
 #include <dlfcn.h>
+#include <rccl/rccl.h>  // types only: every function is looked up at run time
 #include <string.h>
+
+#include <chrono>
+#include <thread>
 
 #include "context.hpp"
 #include "curve29.hpp"
@@ -22,34 +31,42 @@
 namespace cap {
 namespace {
 
-// the slice of rccl.h this file needs (ABI-stable NCCL 2 signatures)
-typedef struct ncclComm* ncclComm_t;
-typedef struct {
-  char internal[128];
-} ncclUniqueId;
-typedef int ncclResult_t;
-constexpr int kNcclUint8 = 1;
-
 struct Rccl {
   void* lib = nullptr;
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitRankConfig)(ncclComm_t*, int, ncclUniqueId, int, ncclConfig_t*) = nullptr;  // optional
+  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;                             // optional
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                                                    // optional
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
-  ncclResult_t (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
 struct Comm {
   Rccl api;
   ncclComm_t comm = nullptr;
+  bool nonblocking = false;
+  bool loopback = false;  // test communicator: `world` ranks played one after the other on this device
   int rank = 0, world = 1;
-  g1_jac* d_gather = nullptr;  // world * count points
-  size_t gather_cap = 0;       // points
+  int slot = 0;               // the context the communicator belongs to
+  g1_jac* d_gather = nullptr;  // world * (count + 1) slots: every rank's points + its status slot
+  size_t gather_cap = 0;
+  g1_jac* d_send = nullptr;  // count + 1 slots
+  size_t send_cap = 0;
+  uint32_t* h_status = nullptr;  // pinned, `world` words
+  size_t status_cap = 0;
   bool shard_prover = false;
 };
 Comm& comm() {
   static Comm c;
   return c;
+}
+
+long timeout_ms() {
+  const char* e = getenv("CAPGPU_COMM_TIMEOUT_MS");
+  long x = e ? atol(e) : 60000;
+  return x > 0 ? x : 60000;
 }
 
 int load_rccl(Rccl& r) {
@@ -67,6 +84,9 @@ int load_rccl(Rccl& r) {
   }
   r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
   r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
+  r.CommInitRankConfig = (decltype(r.CommInitRankConfig))dlsym(h, "ncclCommInitRankConfig");
+  r.CommGetAsyncError = (decltype(r.CommGetAsyncError))dlsym(h, "ncclCommGetAsyncError");
+  r.CommAbort = (decltype(r.CommAbort))dlsym(h, "ncclCommAbort");
   r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
   r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
   r.GetErrorString = (decltype(r.GetErrorString))dlsym(h, "ncclGetErrorString");
@@ -80,17 +100,69 @@ int load_rccl(Rccl& r) {
 }
 int rccl_fail(ncclResult_t e, const char* what) {
   Comm& c = comm();
-  set_error("capgpu_comm: RCCL error %d (%s) in %s", e, c.api.GetErrorString ? c.api.GetErrorString(e) : "?", what);
+  set_error("capgpu_comm: RCCL error %d (%s) in %s", (int)e, c.api.GetErrorString ? c.api.GetErrorString(e) : "?", what);
   return CAPGPU_ERR_HIP;
 }
 
-// out[k] = sum over ranks r of all[r * count + k]   (one wavefront per MSM; lanes stride over the ranks)
-__global__ __launch_bounds__(64) void g1_sum_ranks_kernel(const g1_jac* __restrict__ all, uint32_t world, uint32_t count,
+// gives up the communicator after a deadline was missed: abort (never the collective ncclCommDestroy) and forget it
+void abandon_comm() {
+  Comm& c = comm();
+  if (c.comm) {
+    if (c.api.CommAbort) c.api.CommAbort(c.comm);
+    c.comm = nullptr;
+  }
+  c.rank = 0;
+  c.world = 1;
+  c.shard_prover = false;
+}
+
+// polls a non-blocking communicator until its pending operation has settled
+int wait_async(const char* what) {
+  Comm& c = comm();
+  if (!c.nonblocking || !c.api.CommGetAsyncError) return CAPGPU_OK;
+  const auto t0 = std::chrono::steady_clock::now();
+  for (;;) {
+    ncclResult_t st = ncclSuccess;
+    ncclResult_t e = c.api.CommGetAsyncError(c.comm, &st);
+    if (e != ncclSuccess) return rccl_fail(e, "ncclCommGetAsyncError");
+    if (st == ncclSuccess) return CAPGPU_OK;
+    if (st != ncclInProgress) return rccl_fail(st, what);
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms())) {
+      abandon_comm();
+      set_error("capgpu_comm: %s did not complete within %ld ms (a rank is missing?); communicator aborted", what,
+                timeout_ms());
+      return CAPGPU_ERR_COMM;
+    }
+    std::this_thread::sleep_for(std::chrono::microseconds(200));
+  }
+}
+
+// waits for the stream with a deadline instead of hipStreamSynchronize: a peer that never enters the collective must
+// not freeze this process with its context lock held
+int wait_stream(hipStream_t s, const char* what) {
+  const auto t0 = std::chrono::steady_clock::now();
+  for (int spin = 0;; spin++) {
+    hipError_t e = hipStreamQuery(s);
+    if (e == hipSuccess) return CAPGPU_OK;
+    if (e != hipErrorNotReady) return hip_fail(e, "hipStreamQuery");
+    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms())) {
+      abandon_comm();
+      set_error("capgpu_comm: %s did not complete within %ld ms (a rank is missing?); communicator aborted", what,
+                timeout_ms());
+      return CAPGPU_ERR_COMM;
+    }
+    if (spin < 2000) std::this_thread::yield();
+    else std::this_thread::sleep_for(std::chrono::microseconds(50));
+  }
+}
+
+// out[k] = sum over ranks r of all[r * stride + k]   (one wavefront per MSM; lanes stride over the ranks)
+__global__ __launch_bounds__(64) void g1_sum_ranks_kernel(const g1_jac* __restrict__ all, uint32_t world, uint32_t stride,
                                                           g1_jac* __restrict__ out) {
   const uint32_t k = blockIdx.x;
   g1x acc = G1L::inf();
   for (uint32_t r = threadIdx.x; r < world; r += 64) {
-    g1_jac p = all[(size_t)r * count + k];
+    g1_jac p = all[(size_t)r * stride + k];
     g1x q = G1L::inf();
     if (!Fq::is_zero(p.z)) {
       fl z = Fq29::from_ext(p.z);
@@ -117,33 +189,84 @@ __global__ __launch_bounds__(64) void g1_sum_ranks_kernel(const g1_jac* __restri
 
 }  // namespace
 
-bool comm_active() { return comm().comm != nullptr && comm().world > 1; }
-bool comm_shard_prover() { return comm().comm != nullptr && comm().shard_prover; }
+void g1_sum_ranks(const g1_jac* d_all, uint32_t world, uint32_t stride, uint32_t count, g1_jac* d_out, hipStream_t s) {
+  if (count == 0) return;
+  launch("g1_sum_ranks", g1_sum_ranks_kernel, dim3(count), dim3(64), 0, s, d_all, world, stride, d_out);
+}
+
+static bool comm_exists() { return comm().comm != nullptr || comm().loopback; }
+bool comm_active() { return comm_exists() && comm().world > 1; }
+bool comm_shard_prover() { return comm_exists() && comm().shard_prover && comm().slot == ctx().slot; }
+bool comm_loopback() { return comm().loopback; }
+void comm_loopback_rank(int r) {
+  if (comm().loopback && r >= 0 && r < comm().world) comm().rank = r;
+}
 int comm_rank() { return comm().rank; }
 int comm_world() { return comm().world; }
 
-// d_points: this rank's `count` partial results (device, written by work already enqueued on `s`).  On return (stream
-// order) d_points[k] holds the sum over all ranks of their k-th point, on every rank.
-int comm_allgather_sum(g1_jac* d_points, uint32_t count, hipStream_t s) {
+// d_points: this rank's `count` partial results (device, written by work already enqueued on `s`).  On return
+// d_points[k] holds the sum over all ranks of their k-th point, on every rank, and every rank knows whether any of them
+// failed.  (Loopback: the ranks 0 .. world - 2 only deposit their payload; the call of the last rank finishes the job.)
+int comm_allgather_sum(g1_jac* d_points, uint32_t count, hipStream_t s, int local_rc) {
   Comm& c = comm();
-  if (!c.comm) {
+  if (!comm_exists()) {
     set_error("capgpu_comm: no communicator (call capgpu_comm_init first)");
     return CAPGPU_ERR_NOT_INITIALISED;
   }
-  if (count == 0) return CAPGPU_OK;
-  const size_t need = (size_t)c.world * count;
-  if (need > c.gather_cap) {
+  if (c.slot != ctx().slot) {
+    set_error("capgpu_comm: the communicator belongs to context %d, this call runs on context %d", c.slot, ctx().slot);
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  const std::string local_msg = local_rc ? last_error() : "";
+  const size_t stride = (size_t)count + 1;  // points + status slot
+  if (stride > c.send_cap || (size_t)c.world * stride > c.gather_cap || (size_t)c.world > c.status_cap) {
     CAP_HIP(hipStreamSynchronize(s));
     if (c.d_gather) CAP_HIP(hipFree(c.d_gather));
-    c.d_gather = nullptr;
-    c.gather_cap = 0;
-    CAP_HIP(hipMalloc(&c.d_gather, sizeof(g1_jac) * need));
-    c.gather_cap = need;
+    if (c.d_send) CAP_HIP(hipFree(c.d_send));
+    if (c.h_status) CAP_HIP(hipHostFree(c.h_status));
+    c.d_gather = c.d_send = nullptr;
+    c.h_status = nullptr;
+    c.gather_cap = c.send_cap = c.status_cap = 0;
+    CAP_HIP(hipMalloc(&c.d_send, sizeof(g1_jac) * stride));
+    c.send_cap = stride;
+    CAP_HIP(hipMalloc(&c.d_gather, sizeof(g1_jac) * (size_t)c.world * stride));
+    c.gather_cap = (size_t)c.world * stride;
+    CAP_HIP(hipHostMalloc((void**)&c.h_status, sizeof(uint32_t) * (size_t)c.world, hipHostMallocDefault));
+    c.status_cap = (size_t)c.world;
   }
-  ncclResult_t e = c.api.AllGather(d_points, c.d_gather, sizeof(g1_jac) * count, kNcclUint8, c.comm, s);
-  if (e) return rccl_fail(e, "ncclAllGather");
-  launch("g1_sum_ranks", g1_sum_ranks_kernel, dim3(count), dim3(64), 0, s, (const g1_jac*)c.d_gather, (uint32_t)c.world,
-         count, d_points);
+  // payload: the points (infinity, Z = 0, when the local step failed) and the status word
+  if (local_rc) CAP_HIP(hipMemsetAsync(c.d_send, 0, sizeof(g1_jac) * stride, s));
+  else {
+    if (count) CAP_HIP(hipMemcpyAsync(c.d_send, d_points, sizeof(g1_jac) * count, hipMemcpyDeviceToDevice, s));
+    CAP_HIP(hipMemsetAsync(c.d_send + count, 0, sizeof(g1_jac), s));
+  }
+  if (local_rc) CAP_HIP(hipMemsetD32Async((hipDeviceptr_t)(c.d_send + count), (int)(uint32_t)local_rc, 1, s));
+  if (c.loopback) {
+    CAP_HIP(hipMemcpyAsync(c.d_gather + (size_t)c.rank * stride, c.d_send, sizeof(g1_jac) * stride,
+                           hipMemcpyDeviceToDevice, s));
+    if (c.rank != c.world - 1) return local_rc;
+  } else {
+    ncclResult_t e = c.api.AllGather(c.d_send, c.d_gather, sizeof(g1_jac) * stride, ncclUint8, c.comm, s);
+    if (e != ncclSuccess && e != ncclInProgress) return rccl_fail(e, "ncclAllGather");
+    int rc = wait_async("ncclAllGather");
+    if (rc) return rc;
+  }
+  g1_sum_ranks(c.d_gather, (uint32_t)c.world, (uint32_t)stride, count, d_points, s);
+  CAP_HIP(hipMemcpy2DAsync(c.h_status, sizeof(uint32_t), c.d_gather + count, sizeof(g1_jac) * stride, sizeof(uint32_t),
+                           (size_t)c.world, hipMemcpyDeviceToHost, s));
+  int rc = c.loopback ? (hipStreamSynchronize(s) == hipSuccess ? CAPGPU_OK : CAPGPU_ERR_HIP)
+                      : wait_stream(s, "the all-gather of MSM partials");
+  if (rc) return rc;
+  if (local_rc) {
+    set_error("%s", local_msg.c_str());
+    return local_rc;
+  }
+  for (int r = 0; r < c.world; r++)
+    if (c.h_status[r]) {
+      set_error("capgpu_comm: rank %d of %d failed its part of the sharded MSM (code %d)", r, c.world,
+                (int)c.h_status[r]);
+      return CAPGPU_ERR_COMM;
+    }
   return CAPGPU_OK;
 }
 
@@ -156,13 +279,14 @@ extern "C" {
 int capgpu_comm_unique_id(uint8_t id_out[128]) {
   CAP_CHECK_INIT();
   if (!id_out) return CAPGPU_ERR_INVALID_ARG;
-  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
+  Entry lk(ctx());
   Comm& c = comm();
   int rc = load_rccl(c.api);
   if (rc) return rc;
   ncclUniqueId id;
   ncclResult_t e = c.api.GetUniqueId(&id);
   if (e) return rccl_fail(e, "ncclGetUniqueId");
+  static_assert(sizeof(id.internal) == 128, "ncclUniqueId is 128 bytes");
   memcpy(id_out, id.internal, 128);
   return CAPGPU_OK;
 }
@@ -175,54 +299,130 @@ int capgpu_comm_init(int rank, int world, const uint8_t id[128]) {
   }
   Comm& c = comm();
   {
-    std::lock_guard<std::recursive_mutex> lk(ctx().mu);
-    if (c.comm) {
+    Entry lk(ctx());
+    if (comm_exists()) {
       set_error("capgpu_comm_init: a communicator already exists (capgpu_comm_destroy first)");
       return CAPGPU_ERR_INVALID_ARG;
     }
     int rc = load_rccl(c.api);
     if (rc) return rc;
   }
-  // ncclCommInitRank is collective and blocks until every rank has arrived: the process lock is NOT held across it,
-  // so a rank that never shows up cannot freeze the single-GPU entry points of this process (bench.py relies on it)
+  // Creating the communicator is collective: the context lock is NOT held across it, so a rank that never shows up
+  // cannot freeze the single-GPU entry points of this process.  Non-blocking creation with a deadline where the RCCL in
+  // the process offers it (CAPGPU_COMM_BLOCKING=1 forces the plain blocking call).
   ncclUniqueId uid;
   memcpy(uid.internal, id, 128);
   ncclComm_t nc = nullptr;
-  ncclResult_t e = c.api.CommInitRank(&nc, world, uid, rank);
-  if (e) return rccl_fail(e, "ncclCommInitRank");
-  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
-  if (c.comm) {  // a concurrent capgpu_comm_init won the race
-    c.api.CommDestroy(nc);
+  bool nonblocking = false;
+  const char* be = getenv("CAPGPU_COMM_BLOCKING");
+  if (!(be && atoi(be) != 0) && c.api.CommInitRankConfig && c.api.CommGetAsyncError && c.api.CommAbort) {
+    ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
+    cfg.blocking = 0;
+    ncclResult_t e = c.api.CommInitRankConfig(&nc, world, uid, rank, &cfg);
+    if (e == ncclSuccess || e == ncclInProgress) {
+      nonblocking = true;
+      const auto t0 = std::chrono::steady_clock::now();
+      for (;;) {
+        ncclResult_t st = ncclSuccess;
+        e = c.api.CommGetAsyncError(nc, &st);
+        if (e != ncclSuccess) st = e;
+        if (st == ncclSuccess) break;
+        if (st != ncclInProgress) {
+          c.api.CommAbort(nc);
+          return rccl_fail(st, "ncclCommInitRankConfig");
+        }
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms())) {
+          c.api.CommAbort(nc);
+          set_error("capgpu_comm_init: rank %d of %d: the other ranks did not arrive within %ld ms", rank, world,
+                    timeout_ms());
+          return CAPGPU_ERR_COMM;
+        }
+        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+      }
+    } else {
+      nc = nullptr;  // (a config this RCCL does not accept: fall back to the blocking call)
+    }
+  }
+  if (!nc) {
+    ncclResult_t e = c.api.CommInitRank(&nc, world, uid, rank);
+    if (e) return rccl_fail(e, "ncclCommInitRank");
+  }
+  Entry lk(ctx());
+  if (comm_exists()) {  // a concurrent capgpu_comm_init won the race
+    if (nonblocking && c.api.CommAbort) c.api.CommAbort(nc);
+    else c.api.CommDestroy(nc);
     set_error("capgpu_comm_init: a communicator already exists (capgpu_comm_destroy first)");
     return CAPGPU_ERR_INVALID_ARG;
   }
   c.comm = nc;
+  c.nonblocking = nonblocking;
+  c.loopback = false;
   c.rank = rank;
   c.world = world;
+  c.slot = ctx().slot;
+  return CAPGPU_OK;
+}
+
+int capgpu_comm_init_loopback(int world) {
+  CAP_CHECK_INIT();
+  if (world < 1 || world > 4096) {
+    set_error("capgpu_comm_init_loopback: bad world size %d", world);
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  Entry lk(ctx());
+  Comm& c = comm();
+  if (comm_exists()) {
+    set_error("capgpu_comm_init_loopback: a communicator already exists (capgpu_comm_destroy first)");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  c.comm = nullptr;
+  c.nonblocking = false;
+  c.loopback = true;
+  c.rank = 0;
+  c.world = world;
+  c.slot = ctx().slot;
+  return CAPGPU_OK;
+}
+int capgpu_comm_loopback_set_rank(int rank) {
+  CAP_CHECK_INIT();
+  Entry lk(ctx());
+  Comm& c = comm();
+  if (!c.loopback || rank < 0 || rank >= c.world) {
+    set_error("capgpu_comm_loopback_set_rank: no loopback communicator, or rank %d out of range", rank);
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  c.rank = rank;
   return CAPGPU_OK;
 }
 
 int capgpu_comm_destroy(void) {
   CAP_CHECK_INIT();
-  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
   Comm& c = comm();
-  if (!c.comm) return CAPGPU_OK;
-  (void)hipStreamSynchronize(ctx().stream);
-  c.api.CommDestroy(c.comm);
+  if (!comm_exists() && !c.d_gather) return CAPGPU_OK;
+  Context& owner = *rt().ctxs[(size_t)c.slot < num_contexts() ? c.slot : 0];
+  ScopedCtx sc(owner);
+  Entry lk(owner);
+  (void)hipStreamSynchronize(owner.stream);
+  if (c.comm) c.api.CommDestroy(c.comm);
   c.comm = nullptr;
+  c.loopback = false;
+  c.nonblocking = false;
   c.rank = 0;
   c.world = 1;
   c.shard_prover = false;
   if (c.d_gather) hipFree(c.d_gather);
-  c.d_gather = nullptr;
-  c.gather_cap = 0;
+  if (c.d_send) hipFree(c.d_send);
+  if (c.h_status) hipHostFree(c.h_status);
+  c.d_gather = c.d_send = nullptr;
+  c.h_status = nullptr;
+  c.gather_cap = c.send_cap = c.status_cap = 0;
   return CAPGPU_OK;
 }
 
 int capgpu_comm_info(int* rank_out, int* world_out) {
   Comm& c = comm();
-  if (rank_out) *rank_out = c.comm ? c.rank : 0;
-  if (world_out) *world_out = c.comm ? c.world : 0;
+  if (rank_out) *rank_out = comm_exists() ? c.rank : 0;
+  if (world_out) *world_out = comm_exists() ? c.world : 0;
   return CAPGPU_OK;
 }
 
@@ -230,14 +430,19 @@ int capgpu_msm_g1_sharded_dev(uint64_t srs_handle, size_t offset, const void* d_
                               size_t n_local, int count, int scalars_montgomery, void* d_out_xyz) {
   CAP_CHECK_INIT();
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
-  if (!comm().comm) {
+  Entry lk(c);
+  if (!comm_exists()) {
     set_error("capgpu_msm_g1_sharded: no communicator (call capgpu_comm_init first)");
     return CAPGPU_ERR_NOT_INITIALISED;
   }
+  if (count < 0 || !d_out_xyz) {
+    set_error("capgpu_msm_g1_sharded: bad argument");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  if (count == 0) return CAPGPU_OK;
+  // a local failure does not leave the other ranks waiting: this rank still enters the exchange, with its error code
   int rc = capgpu_msm_g1_dev(srs_handle, offset, d_scalars, scalar_stride, n_local, count, scalars_montgomery, d_out_xyz);
-  if (rc) return rc;
-  rc = comm_allgather_sum((g1_jac*)d_out_xyz, (uint32_t)count, c.stream);
+  rc = comm_allgather_sum((g1_jac*)d_out_xyz, (uint32_t)count, c.stream, rc);
   if (rc) return rc;
   return take_launch_error();
 }
@@ -247,7 +452,7 @@ int capgpu_msm_g1_sharded(uint64_t srs_handle, size_t offset, const uint64_t* sc
   CAP_CHECK_INIT();
   if ((!scalars && n_local) || !out_xyz) return CAPGPU_ERR_INVALID_ARG;
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  Entry lk(c);
   int rc = scratch_reserve(c.stage_a, sizeof(fe) * (n_local ? n_local : 1) + sizeof(g1_jac));
   if (rc) return rc;
   fe* d_sc = (fe*)c.stage_a.p;
@@ -262,8 +467,8 @@ int capgpu_msm_g1_sharded(uint64_t srs_handle, size_t offset, const uint64_t* sc
 
 int capgpu_plonk_shard_msm(int on) {
   CAP_CHECK_INIT();
-  std::lock_guard<std::recursive_mutex> lk(ctx().mu);
-  if (on && !comm().comm) {
+  Entry lk(ctx());
+  if (on && !comm_exists()) {
     set_error("capgpu_plonk_shard_msm: no communicator (call capgpu_comm_init first)");
     return CAPGPU_ERR_NOT_INITIALISED;
   }

@@ -1,8 +1,20 @@
-// Process-wide state of libcapgpu.so: the bound device, the library stream,
-// resident tables (NTT domains, SRS window tables, proving keys) and scratch.
+// State of libcapgpu.so.
+//
+// One process drives N GPUs (capgpu_init(device_ids, n)): the reference is ONE process whose rayon threads each call
+// prove() (src/utils/params_builder.rs:194-226), so the library - not the caller - spreads that work over the devices.
+//   Runtime   process-wide: the device contexts, the table of logical handles, the round-robin cursor.
+//   Context   one per bound device: stream, resident tables (NTT domains, SRS window tables, proving keys), scratch,
+//             host thread pool, launch profiler, and the lock that serialises work on that device.
+// Handles are LOGICAL: an SRS or a proving key is created on one context (its home) and replicated on the first use
+// on another one (tables are immutable after creation, so a replica is a peer copy - or, for a second context on the
+// same device, the same memory).  An SRS of >= 2^20 points is instead SHARDED by point range over the contexts at
+// upload (SURVEY 8e inside one process): MSMs on it run on all devices and meet in one exchange of 96-byte partials.
+// Lock order: context locks in ascending slot order, the registry lock (Runtime::mu) last and never held while a
+// context lock is being acquired.
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -10,6 +22,8 @@
 #include <vector>
 
 #include "../../include/capgpu.h"
+#include "host_pool.hpp"
+#include "launch.hpp"
 #include "msm.hpp"
 #include "ntt.hpp"
 
@@ -22,54 +36,149 @@ struct Scratch {
 
 struct SrsEntry {
   MsmBases bases;
+  int device = 0;       // HIP device the tables live on
+  bool is_shard = false;
+  size_t range_lo = 0;  // a shard of a sharded SRS: holds logical points [range_lo, range_lo + bases.n)
   // Parts of a loaded parameter blob the prover never reads but a store -> load round trip must not lose
   // (jf-plonk's `trim` indexes powers_of_gamma_g; ark-serialize bytes kept verbatim, validated at load):
-  std::vector<uint64_t> gamma_deg;  // BTreeMap keys of UniversalParams::powers_of_gamma_g (empty for a Vec)
+  std::vector<uint64_t> gamma_deg;  // BTreeMap keys of UniversalParams::powers_of_gamma_g
   std::vector<uint8_t> gamma_pts;   // 32 B compressed G1 each
   std::vector<uint8_t> neg_h;       // UniversalParams::neg_powers_of_h entries, 72 B each (u64 key + compressed G2)
+  // CommitKey::powers_of_gamma_g of a ProvingKey blob (a Vec<G1>, degrees 0, 1, ...): only capgpu_plonk_key_deserialize
+  // fills it, only capgpu_plonk_key_serialize reads it
+  std::vector<uint8_t> ck_gamma_pts;
+  SrsEntry() = default;
+  SrsEntry(const SrsEntry&) = delete;
+  SrsEntry& operator=(const SrsEntry&) = delete;
+  ~SrsEntry() { msm_free_bases(&bases); }
+};
+
+// a logical SRS handle: one full table (replicated on demand), or one shard per context
+struct SrsRecord {
+  std::shared_ptr<SrsEntry> full;                 // null when sharded
+  std::vector<std::shared_ptr<SrsEntry>> shards;  // [slot]; empty when not sharded
+  size_t total_n = 0;
+  bool sharded() const { return !shards.empty(); }
 };
 
 struct ProvingKey;  // plonk.hip
 
 struct Context {
   bool initialised = false;
-  int device = 0;
+  int slot = 0;    // index in Runtime::ctxs
+  int device = 0;  // HIP device id (two contexts may share a device: CAPGPU_CONTEXTS_PER_DEVICE)
   hipStream_t own_stream = nullptr;
   hipStream_t copy_stream = nullptr;  // H2D of host-resident witnesses (plonk.hip), created on first use
   hipStream_t stream = nullptr;  // the stream work is enqueued on (own_stream unless capgpu_set_stream)
   NttSmallTables small;
   std::map<uint32_t, NttDomain> domains;
   std::map<uint32_t, Ntt3Domain> domains3;  // N = 3 * 2^log_m (the prover's quotient domain)
-  std::map<uint64_t, SrsEntry> srs;
+  std::map<uint64_t, std::shared_ptr<SrsEntry>> srs;  // logical handle -> the table resident HERE (full or shard)
   std::map<uint64_t, std::shared_ptr<ProvingKey>> keys;
-  uint64_t next_handle = 1;
-  Scratch ntt_scratch, msm_ws, stage_a, stage_b;
+  Scratch ntt_scratch, msm_ws, stage_a, stage_b, prove_ws, gather;
+  std::unique_ptr<HostPool> pool;  // created on first use
+  Profiler prof;
+  LaunchError lerr;
+  int depth = 0;  // nesting of entry points on this context (Entry)
   std::recursive_mutex mu;
 };
 
+struct Runtime {
+  std::mutex mu;  // registry lock: the handle tables below
+  std::atomic<bool> initialised{false};
+  std::vector<std::unique_ptr<Context>> ctxs;
+  std::map<uint64_t, SrsRecord> srs;
+  std::map<uint64_t, std::shared_ptr<ProvingKey>> keys;  // home copies
+  std::atomic<uint64_t> next_handle{1};
+  std::atomic<uint32_t> rr{0};  // round-robin cursor of the dealers
+};
+Runtime& rt();
+
+// The context of the calling thread: the one a dispatcher put it on (ScopedCtx), else the one it bound with
+// capgpu_set_device, else context 0.  Before capgpu_init: an inert context (initialised == false).
 Context& ctx();
+int thread_bound_slot();  // -1: not bound (the library may deal this thread's host-buffer calls to any context)
+inline size_t num_contexts() { return rt().ctxs.size(); }
+
+// puts the calling thread on context c for a scope (and makes c's device the thread's HIP device)
+struct ScopedCtx {
+  Context* prev;
+  explicit ScopedCtx(Context& c);
+  ~ScopedCtx();
+  ScopedCtx(const ScopedCtx&) = delete;
+  ScopedCtx& operator=(const ScopedCtx&) = delete;
+};
+
+// Lock of an entry point on its context.  The outermost entry also clears the launch-error latch, so an error left
+// behind by a call that returned early is never reported by the next one (entry points call each other: the latch
+// survives the inner calls of one outer call).
+int& thread_entry_depth();  // context locks the calling thread holds through Entry
+struct Entry {
+  Context& c;
+  explicit Entry(Context& c_) : c(c_) {
+    c.mu.lock();
+    thread_entry_depth()++;
+    if (c.depth++ == 0) c.lerr = LaunchError{};
+  }
+  ~Entry() {
+    c.depth--;
+    thread_entry_depth()--;
+    c.mu.unlock();
+  }
+  Entry(const Entry&) = delete;
+  Entry& operator=(const Entry&) = delete;
+};
+// every context of the process, locked in slot order (sharded MSMs, shutdown); puts nothing on the thread
+struct AllEntries {
+  std::vector<std::unique_ptr<Entry>> held;
+  AllEntries() {
+    for (auto& c : rt().ctxs) held.emplace_back(new Entry(*c));
+  }
+};
+
 void set_error(const char* fmt, ...);
+const char* last_error();
 int hip_fail(hipError_t e, const char* what);  // records message, returns CAPGPU_ERR_HIP / _OOM
 int take_launch_error();                       // CAPGPU_OK, or CAPGPU_ERR_HIP naming the first kernel whose launch failed
 
-// grows (never shrinks) a scratch buffer; synchronises the stream before freeing the old one
+// grows (never shrinks) a scratch buffer of the current context; synchronises its stream before freeing the old one
 int scratch_reserve(Scratch& s, size_t bytes);
 // cached domain tables for 2^log_n
 int get_domain(uint32_t log_n, const NttDomain** out);
 int get_domain3(uint32_t log_m, const Ntt3Domain** out);
-// builds the window table of `n` device-resident affine bases (arkworks form, (0,0) = infinity) and registers it
+// builds the window table of `n` device-resident affine bases (arkworks form, (0,0) = infinity) on the current
+// context and registers it under a new logical handle
 int register_srs(g1_affine* d_bases, size_t n, uint64_t* handle_out);
+// the full SRS `h` resident on the current context (replicated from its home on first use); sharded handles are refused
 int find_srs(uint64_t h, const MsmBases** out);
-SrsEntry* find_srs_entry(uint64_t h);  // nullptr when unknown
+SrsEntry* find_srs_entry(uint64_t h);  // the current context's entry; nullptr when unknown there
+// a copy of the registry record (shared ownership of the tables); CAPGPU_ERR_BAD_HANDLE when unknown
+int srs_record(uint64_t h, SrsRecord* out);
+// proving keys: register a key created on the current context / find (replicate) one / drop everywhere
+uint64_t register_key(const std::shared_ptr<ProvingKey>& K);
+int lookup_key(uint64_t h, std::shared_ptr<ProvingKey>* out);
+int clone_key_to_current(const ProvingKey& src, int src_device, std::shared_ptr<ProvingKey>* out);  // plonk.hip
+// a context nobody is using right now (locked; the caller unlocks c->mu), else nullptr
+Context* try_acquire_context();
+// the context a host-buffer call of an unbound thread is dealt to: a free one if there is one, else round-robin
+Context& pick_context();
+// device-to-device copy between contexts (same device: plain copy), asynchronous on `s`
+hipError_t copy_between(void* dst, int dst_device, const void* src, int src_device, size_t bytes, hipStream_t s);
 
 // comm.hip: the RCCL communicator of a multi-process job (one process per GPU)
 bool comm_active();        // a communicator of more than one rank exists
 bool comm_shard_prover();  // the prover's commitment MSMs are sharded by point range over the ranks
+bool comm_loopback();      // test communicator: the ranks are played one after the other on this device
+void comm_loopback_rank(int r);
 int comm_rank();
 int comm_world();
 struct g1_jac;
-// all-gather of `count` points per rank on stream s + their per-index sums, in place (same result on every rank)
-int comm_allgather_sum(g1_jac* d_points, uint32_t count, hipStream_t s);
+// all-gather of `count` points per rank on stream s + their per-index sums, in place (same result on every rank).
+// local_rc: this rank's status so far; a rank that failed still takes part (with points at infinity) and EVERY rank
+// returns an error afterwards, so that no rank is left waiting in the collective.
+int comm_allgather_sum(g1_jac* d_points, uint32_t count, hipStream_t s, int local_rc = CAPGPU_OK);
+// out[k] = sum_r all[r * stride + k], k < count, on stream s (one wavefront per k)
+void g1_sum_ranks(const g1_jac* d_all, uint32_t world, uint32_t stride, uint32_t count, g1_jac* d_out, hipStream_t s);
 
 // Owning device pointer for temporaries of an entry point: freed on every return path (the OOM paths included).
 template <class T>
@@ -86,10 +195,10 @@ struct DevTmp {
 };
 
 // The HIP current device is per host thread; entry points may arrive on any thread (rayon workers in the reference),
-// so each one binds the library's device before it touches HIP.
+// so each one binds its context's device before it touches HIP.
 #define CAP_CHECK_INIT()                                                  \
   do {                                                                    \
-    if (!cap::ctx().initialised) {                                        \
+    if (!cap::rt().initialised.load(std::memory_order_acquire)) {         \
       cap::set_error("capgpu: not initialised (call capgpu_init first)"); \
       return CAPGPU_ERR_NOT_INITIALISED;                                  \
     }                                                                     \

@@ -16,6 +16,8 @@
 
 #include <math.h>
 #include <stdio.h>
+
+#include <atomic>
 #include <stdlib.h>
 
 namespace cap {
@@ -1158,13 +1160,14 @@ int msm_precompute(MsmBases* out, const g1_affine* d_bases, size_t n, uint32_t c
     launch("msm_precompute_kernel", msm_precompute_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, out->ext2,
            d_bases, n, kWideC, w2);
   }
-  return (int)hipGetLastError();
+  return 0;  // launch failures are latched by launch() and reported by take_launch_error()
 }
 
 void msm_free_bases(MsmBases* b) {
   if (b->ext) hipFree(b->ext);
   if (b->ext2) hipFree(b->ext2);
-  b->ext = b->ext2 = nullptr;
+  if (b->ext3) hipFree(b->ext3);
+  b->ext = b->ext2 = b->ext3 = nullptr;
   b->n = 0;
 }
 
@@ -1228,13 +1231,16 @@ int msm_run_slice(const MsmBases& bases, const Plan& pl, size_t offset, const fe
     const uint32_t bins = half >> pl.sub_bits;  // sort keys of the tile-local level (= buckets without a 2nd level)
     const uint32_t total_bins = bins * sb;
     size_t lds_bytes = sizeof(uint32_t) * (2 * (size_t)bins + (size_t)kDigitTile * W);
-    static bool attr_set = false;
-    if (!attr_set) {
+    // (function attributes are per device: a process may drive several)
+    static std::atomic<uint64_t> attr_set{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!(attr_set.load() >> (dev & 63) & 1)) {
       for (const void* f : {reinterpret_cast<const void*>(msm_digits_local<0>),
                             reinterpret_cast<const void*>(msm_digits_local<13>),
                             reinterpret_cast<const void*>(msm_digits_local<15>)})
         hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-      attr_set = true;
+      attr_set.fetch_or(1ull << (dev & 63));
     }
     auto digits_kernel = c == 13 ? msm_digits_local<13> : (c == 15 ? msm_digits_local<15> : msm_digits_local<0>);
     launch("msm_digits_local", digits_kernel, dim3(nblk * ((sb + 7) / 8) * 8), dim3(kDigitThreads), lds_bytes, stream,
@@ -1306,7 +1312,7 @@ int msm_run_slice(const MsmBases& bases, const Plan& pl, size_t offset, const fe
   }
   if (parts > 1)
     launch("msm_sum_parts", msm_sum_parts, dim3(batch), dim3(64), 0, stream, (const g1_xyzz*)part_pts, parts, out);
-  return (int)hipGetLastError();
+  return 0;  // launch failures are latched by launch() and reported by take_launch_error()
 }
 }  // namespace
 
@@ -1318,7 +1324,7 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
   if (offset + n > bases.n) return (int)hipErrorInvalidValue;
   if (n == 0) {
     launch("msm_fill_inf", msm_fill_inf, dim3((batch + 255) / 256), dim3(256), 0, stream, d_out, batch);
-    return (int)hipGetLastError();
+    return 0;  // launch failures are latched by launch() and reported by take_launch_error()
   }
   const Plan pl = choose_plan(bases, n, batch);
   uint32_t slice = batch_slice(pl, batch);

@@ -48,6 +48,10 @@ struct MsmBases {
   // (fewer than 4096 points, or c itself is already the wide window: tables of more than 2^18 points).
   uint32_t c2 = 0, windows2 = 0;
   g1_affine* ext2 = nullptr;
+  // Third table for long single MSMs (>= 2^20 points, see msm.hip "deep sort"): windows of 18-22 bits on ONE bucket set
+  // shared by all points - 12-15 digits per scalar instead of 17.  Null when not built.
+  uint32_t c3 = 0, windows3 = 0;
+  g1_affine* ext3 = nullptr;
 };
 
 struct MsmWorkspace {

@@ -571,7 +571,7 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
     size_t lds = sizeof(fl) << (log_len + log_c);
     launch("ntt_row_pass", ntt_row_pass, dim3((unsigned)tiles, count), dim3(kThreads), lds, stream, p);
   }
-  return (int)hipGetLastError();
+  return 0;  // launch failures are latched by launch() and reported by take_launch_error()
 }
 
 // ---- N = 3 * 2^k ------------------------------------------------------------------------------------------------
@@ -687,7 +687,7 @@ int ntt3_inverse(const Ntt3Domain& d3, const NttDomain& dom_m, const NttSmallTab
   if (rc) return rc;
   launch("ntt3_combine", ntt3_combine, dim3((unsigned)((M + kThreads - 1) / kThreads), count), dim3(kThreads), 0, stream,
          (const fe*)y, data, N, (size_t)0, 1u, M, (const fe*)d3.tw29_inv, d3.w3inv_29, (const fe*)d3.coset_inv_ext);
-  return (int)hipGetLastError();
+  return 0;  // launch failures are latched by launch() and reported by take_launch_error()
 }
 
 }  // namespace cap

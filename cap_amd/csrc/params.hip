@@ -231,7 +231,7 @@ int capgpu_g1_decompress(const uint8_t* in, size_t n, uint64_t* out_xy) {
   }
   if (n == 0) return CAPGPU_OK;
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  Entry lk(c);
   DevTmp<g1_affine> d;
   CAP_HIP(d.alloc(n));
   int rc = decompress_g1(in, n, d, c.stream);
@@ -251,7 +251,7 @@ int capgpu_g1_compress(const uint64_t* xy, size_t n, uint8_t* out) {
   }
   if (n == 0) return CAPGPU_OK;
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  Entry lk(c);
   DevTmp<g1_affine> d;
   CAP_HIP(d.alloc(n));
   hipError_t e = hipMemcpyAsync(d, xy, sizeof(g1_affine) * n, hipMemcpyHostToDevice, c.stream);
@@ -268,7 +268,7 @@ int capgpu_srs_deserialize(const uint8_t* bytes, size_t len, size_t max_degree, 
     return CAPGPU_ERR_INVALID_ARG;
   }
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  Entry lk(c);
   Reader rd(bytes, len);
   uint64_t n_g = 0, n_gamma = 0, n_neg = 0;
   if (!rd.count(32, &n_g)) goto truncated;
@@ -321,6 +321,19 @@ int capgpu_srs_deserialize(const uint8_t* bytes, size_t len, size_t max_degree, 
     // the hiding powers and the negative powers of h are not used by this (non-hiding) prover, but a reference-side
     // consumer of a re-stored file indexes them (jf-plonk `trim`): they stay with the handle, validated, verbatim
     if (SrsEntry* e = find_srs_entry(*handle_out)) {
+      if (keep < n_g) {
+        // a trimmed load keeps the hiding powers a setup of that degree would hold (degrees 0 .. max_degree + 1), so that
+        // a re-stored file is consistent
+        std::vector<uint64_t> deg2;
+        std::vector<uint8_t> pts2;
+        for (uint64_t i = 0; i < n_gamma; i++)
+          if (gamma_deg[i] <= (uint64_t)keep) {
+            deg2.push_back(gamma_deg[i]);
+            pts2.insert(pts2.end(), gamma.begin() + 32 * i, gamma.begin() + 32 * i + 32);
+          }
+        gamma_deg.swap(deg2);
+        gamma.swap(pts2);
+      }
       e->gamma_deg = std::move(gamma_deg);
       e->gamma_pts = std::move(gamma);
       e->neg_h = std::move(neg_h);
@@ -339,7 +352,7 @@ int capgpu_srs_serialize(uint64_t handle, const uint64_t h[16], const uint64_t b
                          size_t* len_out) {
   CAP_CHECK_INIT();
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  Entry lk(c);
   const MsmBases* B = nullptr;
   int rc = find_srs(handle, &B);
   if (rc) return rc;

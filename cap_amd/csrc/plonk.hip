@@ -55,99 +55,30 @@ struct ProvingKey {
   capgpu_verifying_key vk;
   std::vector<uint8_t> vk_bytes;
   bool recompute = false;
-  // workspace for a batch (grown on demand)
-  void* ws = nullptr;
-  size_t ws_bytes = 0;
+  int device = 0;  // HIP device the tables live on
+  // Immutable once published: contexts on the same device share the object, other devices get a peer copy
+  // (clone_key_to_current).  The batch workspace lives in the context (Context::prove_ws).
+  ProvingKey() = default;
+  ProvingKey(const ProvingKey&) = delete;
+  ProvingKey& operator=(const ProvingKey&) = delete;
   ~ProvingKey() {
-    for (void* p : {(void*)coef, (void*)sig_eval, (void*)pk_coset, (void*)inv_nx1, ws})
+    for (void* p : {(void*)coef, (void*)sig_eval, (void*)pk_coset, (void*)inv_nx1})
       if (p) hipFree(p);
   }
 };
 
 namespace {
 
-// The per-proof host work between rounds (Keccak transcript, a handful of field operations) is independent across
-// the proofs of a batch; the reference runs it under rayon (src/utils/params_builder.rs:194-226).  A serial loop
-// leaves the GPU idle for ~20 % of a 64-proof step.
-// A persistent pool (workers are created once and parked on a condition variable): spawning 31 threads per call cost
-// about a millisecond, seven times per step, with the GPU idle.
-class HostPool {
- public:
-  static HostPool& get() {
-    static HostPool p;
-    return p;
-  }
-  unsigned size() const { return nt_; }
-  // runs job(i) for i in [0, count); the caller takes part
-  void run(uint32_t count, const std::function<void(uint32_t)>& job) {
-    std::lock_guard<std::mutex> serial(run_mu_);  // one parallel region at a time
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      job_ = &job;
-      count_ = count;
-      next_.store(0, std::memory_order_relaxed);
-      pending_ = (unsigned)workers_.size();
-      epoch_++;
-    }
-    cv_.notify_all();
-    drain();
-    std::unique_lock<std::mutex> lk(mu_);
-    done_cv_.wait(lk, [&] { return pending_ == 0; });
-    job_ = nullptr;
-  }
-
- private:
-  HostPool() {
-    const char* e = getenv("CAPGPU_HOST_THREADS");
-    unsigned v = e ? (unsigned)atoi(e) : std::thread::hardware_concurrency();
-    nt_ = std::min(std::max(v, 1u), 32u);
-    for (unsigned t = 1; t < nt_; t++) workers_.emplace_back([this] { loop(); });
-  }
-  ~HostPool() {
-    {
-      std::lock_guard<std::mutex> lk(mu_);
-      stop_ = true;
-      epoch_++;
-    }
-    cv_.notify_all();
-    for (auto& w : workers_) w.join();
-  }
-  void drain() {
-    for (;;) {
-      uint32_t i = next_.fetch_add(1, std::memory_order_relaxed);
-      if (i >= count_) break;
-      (*job_)(i);
-    }
-  }
-  void loop() {
-    uint64_t seen = 0;
-    for (;;) {
-      {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_.wait(lk, [&] { return epoch_ != seen; });
-        seen = epoch_;
-        if (stop_) return;
-      }
-      drain();
-      std::lock_guard<std::mutex> lk(mu_);
-      if (--pending_ == 0) done_cv_.notify_one();
-    }
-  }
-  unsigned nt_ = 1;
-  std::vector<std::thread> workers_;
-  std::mutex mu_, run_mu_;
-  std::condition_variable cv_, done_cv_;
-  const std::function<void(uint32_t)>* job_ = nullptr;
-  uint32_t count_ = 0;
-  std::atomic<uint32_t> next_{0};
-  unsigned pending_ = 0;
-  uint64_t epoch_ = 0;
-  bool stop_ = false;
-};
+// The per-proof host work between rounds runs on the context's own pool (host_pool.hpp).
+HostPool& host_pool() {
+  Context& c = ctx();
+  if (!c.pool) c.pool.reset(new HostPool(HostPool::default_threads((unsigned)std::max<size_t>(num_contexts(), 1))));
+  return *c.pool;
+}
 
 template <class F>
 void parallel_for(uint32_t count, F&& fn) {
-  HostPool& pool = HostPool::get();
+  HostPool& pool = host_pool();
   if (pool.size() <= 1 || count <= 1) {
     for (uint32_t i = 0; i < count; i++) fn(i);
     return;
@@ -247,21 +178,27 @@ int run_ntt3_inv(hipStream_t s, uint32_t log_mm, fe* data, uint32_t count) {
 int run_msm(hipStream_t s, const MsmBases& B, const fe* scalars, size_t outer_stride, uint32_t inner,
             size_t inner_stride, size_t n, uint32_t batch, g1_jac* d_out) {
   Context& c = ctx();
+  auto local = [&](size_t lo, size_t len) -> int {
+    int rc = scratch_reserve(c.msm_ws, msm_workspace_bytes(B, len, batch));
+    if (rc) return rc;
+    rc = msm_run(B, lo, scalars + lo, outer_stride, inner, inner_stride, len, batch, 1, d_out, c.msm_ws.p, c.msm_ws.cap, s);
+    return rc ? hip_fail((hipError_t)rc, "msm_run") : CAPGPU_OK;
+  };
+  if (!comm_shard_prover()) return local(0, n);
   // Mode A of BASELINE config 4 (capgpu_plonk_shard_msm): every rank proves the same batch, each commitment MSM is cut
   // by point range over the ranks and finished by one all-gather of 96-byte partials + G - 1 additions.
-  // All ranks then hold the same commitments, derive the same challenges and stay in lock step.
-  size_t lo = 0, len = n;
-  if (comm_shard_prover()) {
-    const size_t world = (size_t)comm_world(), rank = (size_t)comm_rank();
+  // All ranks then hold the same commitments, derive the same challenges and stay in lock step.  A rank whose local
+  // part fails still enters the exchange (comm_allgather_sum), so every rank leaves with an error.  Under the loopback
+  // communicator this process plays the ranks one after the other.
+  const size_t world = (size_t)comm_world();
+  const bool loop = comm_loopback();
+  for (size_t rank = loop ? 0 : (size_t)comm_rank(), last = loop ? world - 1 : rank; rank <= last; rank++) {
+    if (loop) comm_loopback_rank((int)rank);
     const size_t base = n / world, rem = n % world;
-    lo = rank * base + std::min(rank, rem);
-    len = base + (rank < rem ? 1 : 0);
+    const size_t lo = rank * base + std::min(rank, rem), len = base + (rank < rem ? 1 : 0);
+    int rc = comm_allgather_sum(d_out, batch, s, local(lo, len));
+    if (rc) return rc;
   }
-  int rc = scratch_reserve(c.msm_ws, msm_workspace_bytes(B, len, batch));
-  if (rc) return rc;
-  rc = msm_run(B, lo, scalars + lo, outer_stride, inner, inner_stride, len, batch, 1, d_out, c.msm_ws.p, c.msm_ws.cap, s);
-  if (rc) return hip_fail((hipError_t)rc, "msm_run");
-  if (comm_shard_prover()) return comm_allgather_sum(d_out, batch, s);
   return CAPGPU_OK;
 }
 
@@ -360,16 +297,26 @@ uint32_t h2d_chunks(uint32_t P) {
 // domain share every MSM and NTT launch, only k_perm_numden / k_quotient and the descriptors of rounds 4-5 read key
 // data).  K is then keys[0] - it lends the domain-level tables and the workspace - and pub_inputs holds P rows of
 // `num_inputs` = the largest count among the keys, a key with fewer inputs using the first of its row.
-int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pub_inputs, size_t num_inputs,
+int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pub_inputs, size_t num_inputs,
                 const uint8_t* ext_msg, size_t ext_len, const uint64_t* blinders, capgpu_proof* proofs,
                 const uint8_t* const* msgs = nullptr, const size_t* msg_lens = nullptr,
-                const std::vector<ProvingKey*>* keys = nullptr, const uint64_t* const* h_wires = nullptr) {
+                const std::vector<const ProvingKey*>* keys = nullptr, const uint64_t* const* h_wires = nullptr) {
   // h_wires (optional): the wire columns are still in host memory - h_wires[p] points to the 5 n elements of proof p -
   // and d_wires is an empty device buffer for them.
   // Round 1 then runs in chunks of proofs - copy, interpolate, blind, commit - so that the copy of a chunk (pageable
   // memory: the call blocks the host, not the device) overlaps the commitments of the one before.
   Context& c = ctx();
   hipStream_t s = c.stream;
+  // host-resident witnesses are copied on the context's copy stream straight from the callers' buffers: no exit path -
+  // an error return in particular - may leave such a copy in flight (the caller frees or reuses its buffer, and the
+  // next call writes the same staging area)
+  struct CopyDrain {
+    Context& c;
+    bool armed;
+    ~CopyDrain() {
+      if (armed && c.copy_stream) (void)hipStreamSynchronize(c.copy_stream);
+    }
+  } drain{c, h_wires != nullptr};
   const size_t n = K.n, m = K.m, ps = K.ps;
   auto key_of = [&](uint32_t p) -> const ProvingKey& { return keys ? *(*keys)[p] : K; };
   if (keys) {
@@ -394,16 +341,8 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
   int rc = find_srs(K.srs_handle, &B);
   if (rc) return rc;
   // workspace
-  size_t need = carve(nullptr, K, P, num_inputs).total;
-  if (need > K.ws_bytes) {
-    CAP_HIP(hipStreamSynchronize(s));
-    if (K.ws) CAP_HIP(hipFree(K.ws));
-    K.ws = nullptr;
-    K.ws_bytes = 0;
-    CAP_HIP(hipMalloc(&K.ws, need));
-    K.ws_bytes = need;
-  }
-  BatchWs w = carve(K.ws, K, P, num_inputs);
+  if ((rc = scratch_reserve(c.prove_ws, carve(nullptr, K, P, num_inputs).total))) return rc;
+  BatchWs w = carve(c.prove_ws.p, K, P, num_inputs);
   const NttDomain* dom_n = nullptr;
   const Ntt3Domain* dom_q = nullptr;
   if ((rc = get_domain(K.log_n, &dom_n))) return rc;
@@ -484,6 +423,13 @@ int prove_batch(ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pu
     if (h_wires) {
       hipStream_t cs = chunks > 1 ? h2d_stream() : nullptr;
       if (!cs) cs = s;
+      if (cs != s && ck == 0) {  // the staging area may still be read by kernels of a call that returned early
+        hipEvent_t ev;
+        CAP_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        hipError_t e1 = hipEventRecord(ev, s), e2 = e1 == hipSuccess ? hipStreamWaitEvent(cs, ev, 0) : e1;
+        (void)hipEventDestroy(ev);
+        CAP_HIP(e2);
+      }
       // one copy per run of proofs that are contiguous in host memory (a plain batch: one per chunk)
       for (uint32_t p = p0; p < p1;) {
         uint32_t q = p + 1;
@@ -756,6 +702,7 @@ int key_init(ProvingKey& K, size_t n, size_t num_inputs, uint64_t srs_handle) {
   }
   K.num_inputs = num_inputs;
   K.srs_handle = srs_handle;
+  K.device = ctx().device;
   const char* env = getenv("CAPGPU_RECOMPUTE_PK_COSET");
   K.recompute = env && atoi(env) != 0;
   CAP_HIP(hipMalloc(&K.coef, sizeof(fe) * 18 * K.ps));
@@ -858,10 +805,14 @@ Coalescer& coalescer() {
   return c;
 }
 
-int lookup_key(uint64_t h, std::shared_ptr<ProvingKey>* out) {
-  Context& c = ctx();
-  auto it = c.keys.find(h);
-  if (it == c.keys.end()) {
+}  // namespace
+
+// the registry's (home) copy of a key, without replicating it
+static int home_key(uint64_t h, std::shared_ptr<ProvingKey>* out) {
+  Runtime& R = rt();
+  std::lock_guard<std::mutex> lk(R.mu);
+  auto it = R.keys.find(h);
+  if (it == R.keys.end()) {
     set_error("capgpu: unknown proving key handle %llu", (unsigned long long)h);
     return CAPGPU_ERR_BAD_HANDLE;
   }
@@ -869,7 +820,57 @@ int lookup_key(uint64_t h, std::shared_ptr<ProvingKey>* out) {
   return CAPGPU_OK;
 }
 
-}  // namespace
+int clone_key_to_current(const ProvingKey& src, int src_device, std::shared_ptr<ProvingKey>* out) {
+  Context& c = ctx();
+  auto K = std::make_shared<ProvingKey>();
+  K->n = src.n;
+  K->m = src.m;
+  K->ps = src.ps;
+  K->log_n = src.log_n;
+  K->log_m = src.log_m;
+  K->num_inputs = src.num_inputs;
+  K->srs_handle = src.srs_handle;
+  K->qc = src.qc;
+  K->qc29 = src.qc29;
+  K->vk = src.vk;
+  K->vk_bytes = src.vk_bytes;
+  K->recompute = src.recompute;
+  K->device = c.device;
+  auto dup = [&](fe** dst, const fe* from, size_t count) -> int {
+    if (!from) return CAPGPU_OK;
+    CAP_HIP(hipMalloc(dst, sizeof(fe) * count));
+    CAP_HIP(copy_between(*dst, c.device, from, src_device, sizeof(fe) * count, c.stream));
+    return CAPGPU_OK;
+  };
+  int rc;
+  if ((rc = dup(&K->coef, src.coef, 18 * src.ps))) return rc;
+  if ((rc = dup(&K->sig_eval, src.sig_eval, (size_t)NW * src.n))) return rc;
+  if ((rc = dup(&K->pk_coset, src.pk_coset, 18 * src.m))) return rc;
+  if ((rc = dup(&K->inv_nx1, src.inv_nx1, src.m))) return rc;
+  CAP_HIP(hipStreamSynchronize(c.stream));
+  *out = K;
+  return CAPGPU_OK;
+}
+
+// the key resident on the current context: replicated from its home on first use (same device: the same object)
+int lookup_key(uint64_t h, std::shared_ptr<ProvingKey>* out) {
+  Context& c = ctx();
+  auto it = c.keys.find(h);
+  if (it != c.keys.end()) {
+    *out = it->second;
+    return CAPGPU_OK;
+  }
+  std::shared_ptr<ProvingKey> home, rep;
+  int rc = home_key(h, &home);
+  if (rc) return rc;
+  if (home->device == c.device) rep = home;
+  else if ((rc = clone_key_to_current(*home, home->device, &rep))) return rc;
+  if ((rc = home_key(h, &home))) return rc;  // freed while it was being copied
+  c.keys[h] = rep;
+  *out = rep;
+  return CAPGPU_OK;
+}
+
 }  // namespace cap
 
 using namespace cap;
@@ -880,7 +881,7 @@ int capgpu_plonk_preprocess(uint64_t srs_handle, size_t n, size_t num_inputs, co
                             const uint64_t* sigma_evals, uint64_t* pk_handle_out, capgpu_verifying_key* vk_out) {
   CAP_CHECK_INIT();
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  Entry lk(c);
   // n >= 16: the five split-quotient commitments read 5 (n + 2) coefficients of the 6n-point quotient array
   if (!selectors || !sigma_evals || !pk_handle_out || n < 16 || (n & (n - 1)) || num_inputs >= n) {
     set_error("capgpu_plonk_preprocess: bad argument (n must be a power of two >= 16, num_inputs < n)");
@@ -917,9 +918,7 @@ int capgpu_plonk_preprocess(uint64_t srs_handle, size_t n, size_t num_inputs, co
   batch_to_affine(hj, ha);
   key_set_vk(*K, ha);
   if (vk_out) *vk_out = K->vk;
-  uint64_t h = c.next_handle++;
-  c.keys[h] = K;
-  *pk_handle_out = h;
+  *pk_handle_out = register_key(K);
   return take_launch_error();
 }
 
@@ -928,7 +927,7 @@ int capgpu_plonk_key_serialize(uint64_t pk_handle, const uint64_t gamma_g[8], co
                                const uint64_t beta_h[16], uint8_t* out, size_t cap, size_t* len_out) {
   CAP_CHECK_INIT();
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  Entry lk(c);
   if (!h || !beta_h || !len_out) {
     set_error("capgpu_plonk_key_serialize: bad argument");
     return CAPGPU_ERR_INVALID_ARG;
@@ -941,7 +940,8 @@ int capgpu_plonk_key_serialize(uint64_t pk_handle, const uint64_t gamma_g[8], co
   const size_t n = K->n, ps = K->ps, n_ck = n + 3;
   // upper bound: every polynomial at full length
   const SrsEntry* E0 = find_srs_entry(K->srs_handle);
-  const size_t bound = 2 * 8 + 18 * (8 + 32 * n) + 8 + 32 * n_ck + 8 + (E0 ? E0->gamma_pts.size() : 0) + 1024;
+  const size_t bound = 2 * 8 + 18 * (8 + 32 * n) + 8 + 32 * n_ck + 8 +
+                       (E0 ? std::max(E0->ck_gamma_pts.size(), (size_t)32 * n_ck) : 0) + 1024;
   if (!out) {
     *len_out = bound;
     return CAPGPU_OK;
@@ -970,11 +970,25 @@ int capgpu_plonk_key_serialize(uint64_t pk_handle, const uint64_t gamma_g[8], co
   w.u64(n_ck);
   w.put(ck.data(), ck.size());
   {
-    // CommitKey::powers_of_gamma_g (Vec<G1>): what the blob this key was loaded from held; none for a key made here
+    // CommitKey::powers_of_gamma_g (Vec<G1>, degrees 0 .. n_ck - 1 - what jf-plonk's trim emits).  A key loaded from a
+    // ProvingKey blob re-emits the blob's vector.  A key preprocessed under a loaded UniversalSrs takes the degrees
+    // 0 .. n_ck - 1 from that SRS's BTreeMap, in order - all of them or, when one is missing, none (a sparse map must
+    // not turn into a shorter vector with the degrees lost).  A synthetic SRS has no hiding powers: empty vector.
     const SrsEntry* E = find_srs_entry(K->srs_handle);
-    const size_t n_gamma = E ? E->gamma_pts.size() / 32 : 0;
-    w.u64(n_gamma);
-    if (n_gamma) w.put(E->gamma_pts.data(), 32 * n_gamma);
+    std::vector<uint8_t> gp;
+    if (E && !E->ck_gamma_pts.empty()) {
+      gp = E->ck_gamma_pts;
+    } else if (E && !E->gamma_deg.empty()) {
+      std::map<uint64_t, size_t> at;
+      for (size_t i = 0; i < E->gamma_deg.size(); i++) at[E->gamma_deg[i]] = i;
+      bool all = true;
+      for (uint64_t d = 0; d < n_ck && all; d++) all = at.count(d) != 0;
+      if (all)
+        for (uint64_t d = 0; d < n_ck; d++)
+          gp.insert(gp.end(), E->gamma_pts.begin() + 32 * at[d], E->gamma_pts.begin() + 32 * at[d] + 32);
+    }
+    w.u64(gp.size() / 32);
+    if (!gp.empty()) w.put(gp.data(), gp.size());
   }
   params::OpenKey ok;
   {
@@ -1002,7 +1016,7 @@ int capgpu_plonk_key_deserialize(const uint8_t* bytes, size_t len, uint64_t* srs
                                  size_t* consumed_out) {
   CAP_CHECK_INIT();
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  Entry lk(c);
   if (!bytes || !srs_handle_out || !pk_handle_out) {
     set_error("capgpu_plonk_key_deserialize: bad argument");
     return CAPGPU_ERR_INVALID_ARG;
@@ -1065,7 +1079,7 @@ int capgpu_plonk_key_deserialize(const uint8_t* bytes, size_t len, uint64_t* srs
     if (rc == CAPGPU_OK) rc = params::decompress_g1(ck, n_ck, d_ck, s);
     if (rc == CAPGPU_OK) rc = register_srs(d_ck, n_ck, &srs_handle);
     if (rc) return rc;
-    if (SrsEntry* E = find_srs_entry(srs_handle)) E->gamma_pts.assign(gamma, gamma + 32 * n_gamma);
+    if (SrsEntry* E = find_srs_entry(srs_handle)) E->ck_gamma_pts.assign(gamma, gamma + 32 * n_gamma);
   }
   auto K = std::make_shared<ProvingKey>();
   auto bail = [&](int code) {
@@ -1093,9 +1107,7 @@ int capgpu_plonk_key_deserialize(const uint8_t* bytes, size_t len, uint64_t* srs
   if (h_out) params::g2_to_words(ok.h, h_out);
   if (beta_h_out) params::g2_to_words(ok.beta_h, beta_h_out);
   if (consumed_out) *consumed_out = rd.pos;
-  uint64_t h = c.next_handle++;
-  c.keys[h] = K;
-  *pk_handle_out = h;
+  *pk_handle_out = register_key(K);
   *srs_handle_out = srs_handle;
   return CAPGPU_OK;
 }
@@ -1103,10 +1115,8 @@ int capgpu_plonk_key_deserialize(const uint8_t* bytes, size_t len, uint64_t* srs
 int capgpu_plonk_key_info(uint64_t pk_handle, size_t* domain_size_out, size_t* num_inputs_out,
                           uint64_t* srs_handle_out) {
   CAP_CHECK_INIT();
-  Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
   std::shared_ptr<ProvingKey> K;
-  int rc = lookup_key(pk_handle, &K);
+  int rc = home_key(pk_handle, &K);
   if (rc) return rc;
   if (domain_size_out) *domain_size_out = K->n;
   if (num_inputs_out) *num_inputs_out = K->num_inputs;
@@ -1116,15 +1126,26 @@ int capgpu_plonk_key_info(uint64_t pk_handle, size_t* domain_size_out, size_t* n
 
 int capgpu_plonk_free_key(uint64_t pk_handle) {
   CAP_CHECK_INIT();
-  Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
-  auto it = c.keys.find(pk_handle);
-  if (it == c.keys.end()) {
-    set_error("capgpu: unknown proving key handle %llu", (unsigned long long)pk_handle);
-    return CAPGPU_ERR_BAD_HANDLE;
+  Runtime& R = rt();
+  {
+    std::lock_guard<std::mutex> lk(R.mu);
+    auto it = R.keys.find(pk_handle);
+    if (it == R.keys.end()) {
+      set_error("capgpu: unknown proving key handle %llu", (unsigned long long)pk_handle);
+      return CAPGPU_ERR_BAD_HANDLE;
+    }
+    R.keys.erase(it);
   }
-  hipStreamSynchronize(c.stream);
-  c.keys.erase(it);
+  // every context that holds the key (or a replica) drains its stream before letting go of the tables
+  for (auto& cp : R.ctxs) {
+    Context& c = *cp;
+    ScopedCtx sc(c);
+    Entry lk(c);
+    auto it = c.keys.find(pk_handle);
+    if (it == c.keys.end()) continue;
+    (void)hipStreamSynchronize(c.stream);
+    c.keys.erase(it);
+  }
   return CAPGPU_OK;
 }
 
@@ -1133,7 +1154,7 @@ int capgpu_plonk_prove_batch_dev(uint64_t pk_handle, int count, const void* d_wi
                                  const uint64_t* blinders, capgpu_proof* proofs_out) {
   CAP_CHECK_INIT();
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  Entry lk(c);
   if (count < 0 || (count && (!d_wires || !blinders || !proofs_out || (num_inputs && !pub_inputs)))) {
     set_error("capgpu_plonk_prove: bad argument");
     return CAPGPU_ERR_INVALID_ARG;
@@ -1146,32 +1167,77 @@ int capgpu_plonk_prove_batch_dev(uint64_t pk_handle, int count, const void* d_wi
                      proofs_out);
 }
 
+// ---- dealing host-buffer batches over the device contexts -------------------------------------------------------
+// A batch that arrives with its witnesses in host memory names no device, so a process that drives several (capgpu_init
+// with more than one id, or CAPGPU_CONTEXTS_PER_DEVICE) cuts it into contiguous parts, one per context, each proved
+// from a thread of its own: proofs are independent, so the parts' proofs are bit for bit those of the undivided batch.
+// A thread that bound itself to a device (capgpu_set_device) keeps its batches there.
+static int deal_min() {  // proofs a part must hold at least (smaller batches stay on one context)
+  const char* e = getenv("CAPGPU_DEAL_MIN");
+  const int x = e ? atoi(e) : 8;
+  return x >= 1 ? x : 8;
+}
+static int deal(int count, const std::function<int(int first, int cnt)>& part) {
+  const size_t S = num_contexts();
+  const size_t parts = std::min<size_t>(S, (size_t)std::max(count / deal_min(), 1));
+  if (thread_bound_slot() >= 0 || S <= 1 || parts <= 1 || thread_entry_depth() > 0) {
+    Context& c = pick_context();
+    ScopedCtx sc(c);
+    return part(0, count);
+  }
+  std::vector<int> rcs(parts, CAPGPU_OK);
+  std::vector<std::string> errs(parts);
+  const uint32_t start = rt().rr.fetch_add((uint32_t)parts, std::memory_order_relaxed);
+  auto body = [&](size_t i) {
+    const int first = (int)((uint64_t)count * i / parts), last = (int)((uint64_t)count * (i + 1) / parts);
+    ScopedCtx sc(*rt().ctxs[(start + i) % S]);
+    rcs[i] = part(first, last - first);
+    if (rcs[i]) errs[i] = last_error();
+  };
+  std::vector<std::thread> th;
+  for (size_t i = 1; i < parts; i++) th.emplace_back(body, i);
+  body(0);
+  for (auto& t : th) t.join();
+  for (size_t i = 0; i < parts; i++)
+    if (rcs[i]) {
+      set_error("%s", errs[i].c_str());
+      return rcs[i];
+    }
+  return CAPGPU_OK;
+}
+
 int capgpu_plonk_prove_batch(uint64_t pk_handle, int count, const uint64_t* wires, const uint64_t* pub_inputs,
                              size_t num_inputs, const uint8_t* ext_msg, size_t ext_msg_len, const uint64_t* blinders,
                              capgpu_proof* proofs_out) {
   CAP_CHECK_INIT();
-  Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
   if (count < 0 || (count && !wires)) {
     set_error("capgpu_plonk_prove: bad argument");
     return CAPGPU_ERR_INVALID_ARG;
   }
   if (count == 0) return CAPGPU_OK;
-  std::shared_ptr<ProvingKey> K;
-  int rc = lookup_key(pk_handle, &K);
-  if (rc) return rc;
+  std::shared_ptr<ProvingKey> K0;
+  int rc0 = home_key(pk_handle, &K0);
+  if (rc0) return rc0;
   if (!blinders || !proofs_out || (num_inputs && !pub_inputs)) {
     set_error("capgpu_plonk_prove: bad argument");
     return CAPGPU_ERR_INVALID_ARG;
   }
-  size_t bytes = sizeof(fe) * (size_t)count * NW * K->n;
-  rc = scratch_reserve(c.stage_b, bytes);
-  if (rc) return rc;
-  // the columns are copied inside round 1, chunk by chunk, behind the commitments of the chunk before
-  std::vector<const uint64_t*> rows(count);
-  for (int i = 0; i < count; i++) rows[i] = wires + (size_t)4 * i * NW * K->n;
-  return prove_batch(*K, (uint32_t)count, (const fe*)c.stage_b.p, pub_inputs, num_inputs, ext_msg, ext_msg_len, blinders,
-                     proofs_out, nullptr, nullptr, nullptr, rows.data());
+  const size_t n = K0->n;
+  return deal(count, [&](int first, int cnt) -> int {
+    Context& c = ctx();
+    Entry lk(c);
+    std::shared_ptr<ProvingKey> K;
+    int rc = lookup_key(pk_handle, &K);
+    if (rc) return rc;
+    rc = scratch_reserve(c.stage_b, sizeof(fe) * (size_t)cnt * NW * n);
+    if (rc) return rc;
+    // the columns are copied inside round 1, chunk by chunk, behind the commitments of the chunk before
+    std::vector<const uint64_t*> rows(cnt);
+    for (int i = 0; i < cnt; i++) rows[i] = wires + (size_t)4 * (first + i) * NW * n;
+    return prove_batch(*K, (uint32_t)cnt, (const fe*)c.stage_b.p, pub_inputs ? pub_inputs + (size_t)4 * first * num_inputs : nullptr,
+                       num_inputs, ext_msg, ext_msg_len, blinders + (size_t)4 * 13 * first, proofs_out + first, nullptr,
+                       nullptr, nullptr, rows.data());
+  });
 }
 
 // Proofs of several proving keys in one device batch (see prove_batch): pk_handles[i] is the key of proof i.
@@ -1180,7 +1246,7 @@ int capgpu_plonk_prove_multi_dev(const uint64_t* pk_handles, int count, const vo
                                  const uint64_t* blinders, capgpu_proof* proofs_out) {
   CAP_CHECK_INIT();
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  Entry lk(c);
   if (count < 0 || (count && (!pk_handles || !d_wires || !blinders || !proofs_out || (num_inputs && !pub_inputs) ||
                               (ext_msgs && !ext_msg_lens)))) {
     set_error("capgpu_plonk_prove_multi: bad argument");
@@ -1188,7 +1254,7 @@ int capgpu_plonk_prove_multi_dev(const uint64_t* pk_handles, int count, const vo
   }
   if (count == 0) return CAPGPU_OK;
   std::vector<std::shared_ptr<ProvingKey>> hold(count);
-  std::vector<ProvingKey*> keys(count);
+  std::vector<const ProvingKey*> keys(count);
   for (int i = 0; i < count; i++) {
     int rc = lookup_key(pk_handles[i], &hold[i]);
     if (rc) return rc;
@@ -1202,46 +1268,79 @@ int capgpu_plonk_prove_multi(const uint64_t* pk_handles, int count, const uint64
                              size_t num_inputs, const uint8_t* const* ext_msgs, const size_t* ext_msg_lens,
                              const uint64_t* blinders, capgpu_proof* proofs_out) {
   CAP_CHECK_INIT();
-  Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
   if (count < 0 || (count && (!wires || !pk_handles))) {
     set_error("capgpu_plonk_prove_multi: bad argument");
     return CAPGPU_ERR_INVALID_ARG;
   }
   if (count == 0) return CAPGPU_OK;
-  std::shared_ptr<ProvingKey> K;
-  int rc = lookup_key(pk_handles[0], &K);
-  if (rc) return rc;
+  std::shared_ptr<ProvingKey> K0;
+  int rc0 = home_key(pk_handles[0], &K0);
+  if (rc0) return rc0;
   if (!blinders || !proofs_out || (num_inputs && !pub_inputs) || (ext_msgs && !ext_msg_lens)) {
     set_error("capgpu_plonk_prove_multi: bad argument");
     return CAPGPU_ERR_INVALID_ARG;
   }
-  std::vector<std::shared_ptr<ProvingKey>> hold(count);
-  std::vector<ProvingKey*> keys(count);
-  for (int i = 0; i < count; i++) {
-    if ((rc = lookup_key(pk_handles[i], &hold[i]))) return rc;
-    keys[i] = hold[i].get();
-  }
-  size_t bytes = sizeof(fe) * (size_t)count * NW * K->n;
-  rc = scratch_reserve(c.stage_b, bytes);
-  if (rc) return rc;
-  std::vector<const uint64_t*> rows(count);
-  for (int i = 0; i < count; i++) rows[i] = wires + (size_t)4 * i * NW * K->n;
-  return prove_batch(*keys[0], (uint32_t)count, (const fe*)c.stage_b.p, pub_inputs, num_inputs, nullptr, 0, blinders,
-                     proofs_out, ext_msgs, ext_msg_lens, &keys, rows.data());
+  const size_t n = K0->n;
+  return deal(count, [&](int first, int cnt) -> int {
+    Context& c = ctx();
+    Entry lk(c);
+    std::vector<std::shared_ptr<ProvingKey>> hold(cnt);
+    std::vector<const ProvingKey*> keys(cnt);
+    int rc;
+    for (int i = 0; i < cnt; i++) {
+      if ((rc = lookup_key(pk_handles[first + i], &hold[i]))) return rc;
+      keys[i] = hold[i].get();
+    }
+    // a part's rows carry `num_inputs` = the largest count among the keys of the WHOLE call; prove_batch wants the
+    // largest among its own keys: re-pack when the part's maximum is smaller
+    size_t ni = 0;
+    for (int i = 0; i < cnt; i++) ni = std::max(ni, keys[i]->num_inputs);
+    std::vector<uint64_t> pubs;
+    const uint64_t* pp = pub_inputs ? pub_inputs + (size_t)4 * first * num_inputs : nullptr;
+    if (ni != num_inputs) {
+      if (ni > num_inputs) {
+        set_error("capgpu_plonk_prove_multi: rows of %zu public inputs given, the keys need %zu", num_inputs, ni);
+        return CAPGPU_ERR_INVALID_ARG;
+      }
+      pubs.assign((size_t)4 * ni * cnt + 4, 0);
+      for (int i = 0; i < cnt; i++)
+        if (ni) memcpy(&pubs[(size_t)4 * ni * i], pp + (size_t)4 * num_inputs * i, 32 * ni);
+      pp = pubs.data();
+    }
+    if ((rc = scratch_reserve(c.stage_b, sizeof(fe) * (size_t)cnt * NW * n))) return rc;
+    std::vector<const uint64_t*> rows(cnt);
+    for (int i = 0; i < cnt; i++) rows[i] = wires + (size_t)4 * (first + i) * NW * n;
+    return prove_batch(*keys[0], (uint32_t)cnt, (const fe*)c.stage_b.p, pp, ni, nullptr, 0,
+                       blinders + (size_t)4 * 13 * first, proofs_out + first, ext_msgs ? ext_msgs + first : nullptr,
+                       ext_msg_lens ? ext_msg_lens + first : nullptr, &keys, rows.data());
+  });
 }
 
 // one gathered batch: device staging of every request's wires, per-proof messages and keys; a batch that fails because
-// ONE witness does not satisfy its circuit is re-run request by request so that only its owner sees the failure
+// ONE witness does not satisfy its circuit is re-run request by request so that only its owner sees the failure.
+// Runs on the calling thread's context (the leader took its lock).
 static void run_coalesced(std::vector<ProveReq*>& reqs) {
   Context& c = ctx();
-  std::lock_guard<std::recursive_mutex> lk(c.mu);
+  Entry lk(c);
   auto fail_all = [&](int rc) {
     for (ProveReq* r : reqs) {
       if (r->rc != CAPGPU_OK) continue;
       r->rc = rc;
       r->err = capgpu_last_error();
     }
+  };
+  // one request on this context (the recursive lock is held)
+  auto prove_one = [&](ProveReq* r) {
+    std::shared_ptr<ProvingKey> K;
+    int rc = lookup_key(r->pk, &K);
+    if (rc == CAPGPU_OK) rc = scratch_reserve(c.stage_b, sizeof(fe) * NW * K->n);
+    if (rc == CAPGPU_OK) {
+      const uint64_t* row = r->wires;
+      rc = prove_batch(*K, 1, (const fe*)c.stage_b.p, r->pubs, r->num_inputs, r->msg, r->msg_len, r->blinders, r->out,
+                       nullptr, nullptr, nullptr, &row);
+    }
+    r->rc = rc;
+    if (rc) r->err = capgpu_last_error();
   };
   std::vector<ProveReq*> good;
   std::vector<std::shared_ptr<ProvingKey>> hold;
@@ -1271,11 +1370,7 @@ static void run_coalesced(std::vector<ProveReq*>& reqs) {
   bool recompute = false;
   for (size_t i = 0; i < g; i++) recompute = recompute || hold[i]->recompute;
   if (mixed && recompute) {  // the reference-schedule test mode keeps one key per batch: prove these one by one
-    for (size_t i = 0; i < g; i++) {
-      good[i]->rc = capgpu_plonk_prove_batch(good[i]->pk, 1, good[i]->wires, good[i]->pubs, good[i]->num_inputs,
-                                             good[i]->msg, good[i]->msg_len, good[i]->blinders, good[i]->out);
-      if (good[i]->rc) good[i]->err = capgpu_last_error();
-    }
+    for (size_t i = 0; i < g; i++) prove_one(good[i]);
     coalescer().batches += g;
     coalescer().proofs += g;
     return;
@@ -1287,7 +1382,7 @@ static void run_coalesced(std::vector<ProveReq*>& reqs) {
   std::vector<const uint8_t*> msgs(g);
   std::vector<size_t> lens(g);
   std::vector<capgpu_proof> out(g);
-  std::vector<ProvingKey*> keys(g);
+  std::vector<const ProvingKey*> keys(g);
   std::vector<const uint64_t*> rows(g);  // every caller's own buffer: copied inside round 1, chunk by chunk
   for (size_t i = 0; i < g; i++) {
     rows[i] = good[i]->wires;
@@ -1303,11 +1398,7 @@ static void run_coalesced(std::vector<ProveReq*>& reqs) {
   if (rc == CAPGPU_OK) {
     for (size_t i = 0; i < g; i++) *good[i]->out = out[i];
   } else if (rc == CAPGPU_ERR_PROOF && g > 1) {
-    for (size_t i = 0; i < g; i++) {  // find the owner(s) of the unsatisfied witness
-      good[i]->rc = capgpu_plonk_prove_batch(good[i]->pk, 1, good[i]->wires, good[i]->pubs, good[i]->num_inputs,
-                                             good[i]->msg, good[i]->msg_len, good[i]->blinders, good[i]->out);
-      if (good[i]->rc) good[i]->err = capgpu_last_error();
-    }
+    for (size_t i = 0; i < g; i++) prove_one(good[i]);  // find the owner(s) of the unsatisfied witness
   } else {
     for (ProveReq* r : good) {
       r->rc = rc;
@@ -1335,8 +1426,7 @@ int capgpu_plonk_prove(uint64_t pk_handle, const uint64_t* wires, const uint64_t
   {
     auto it = co.group_of.find(pk_handle);
     if (it == co.group_of.end()) {
-      // first call for this key: its domain size and SRS make the group (the lookup takes the process lock, which a
-      // running batch holds - once per key)
+      // first call for this key: its domain size and SRS make the group
       lk.unlock();
       size_t kn = 0;
       uint64_t ksrs = 0;
@@ -1359,7 +1449,7 @@ int capgpu_plonk_prove(uint64_t pk_handle, const uint64_t* wires, const uint64_t
       co.cv.wait_for(lk, std::chrono::milliseconds(1), [&] { return req.done; });
       continue;
     }
-    // this thread leads the group's next batch: collect for the window, and for as long as the device is busy
+    // this thread leads the group's next batch: collect for the window, and for as long as every device is busy
     co.leader[group] = true;
     if (!waited_window) {
       // the window restarts while calls keep arriving (threads released by the previous batch come back one by one),
@@ -1372,15 +1462,30 @@ int capgpu_plonk_prove(uint64_t pk_handle, const uint64_t* wires, const uint64_t
       }
       waited_window = true;
     }
-    Context& c = ctx();
-    while (!c.mu.try_lock()) co.cv.wait_for(lk, std::chrono::microseconds(100));  // later arrivals join meanwhile
+    // a free device context: any of the process's (several batches are then in flight, one per context), or the one
+    // this thread bound itself to.  Later arrivals join the queue meanwhile.
+    Context* c = nullptr;
+    for (;;) {
+      const int bound = thread_bound_slot();
+      if (bound >= 0) {
+        Context* b = rt().ctxs[(size_t)bound].get();
+        if (b->mu.try_lock()) c = b;
+      } else {
+        c = try_acquire_context();
+      }
+      if (c) break;
+      co.cv.wait_for(lk, std::chrono::microseconds(100));
+    }
     const size_t take = std::min<size_t>(q.size(), co.max_batch);
     std::vector<ProveReq*> reqs(q.begin(), q.begin() + take);
     q.erase(q.begin(), q.begin() + take);
     co.leader[group] = false;
     lk.unlock();
-    run_coalesced(reqs);  // re-enters the (recursive) process lock this thread holds
-    c.mu.unlock();
+    {
+      ScopedCtx sc(*c);
+      run_coalesced(reqs);  // re-enters the (recursive) context lock this thread holds
+    }
+    c->mu.unlock();
     lk.lock();
     for (ProveReq* r : reqs) r->done = true;
     co.cv.notify_all();

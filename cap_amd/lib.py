@@ -17,6 +17,7 @@ CAPGPU_OK = 0
 ERR_NAMES = {
     -1: "CAPGPU_ERR_INVALID_ARG", -2: "CAPGPU_ERR_NO_DEVICE", -3: "CAPGPU_ERR_HIP", -4: "CAPGPU_ERR_BAD_HANDLE",
     -5: "CAPGPU_ERR_OOM", -6: "CAPGPU_ERR_NOT_INITIALISED", -7: "CAPGPU_ERR_PROOF", -8: "CAPGPU_ERR_SERIALIZATION",
+    -9: "CAPGPU_ERR_COMM",
 }
 
 u64p = ctypes.POINTER(ctypes.c_uint64)
@@ -76,13 +77,38 @@ def check(rc: int):
         raise CapGpuError(rc, load().capgpu_last_error().decode())
 
 
-def init(device: int | None = None):
+def init(device: int | None = None, devices=None):
+    """One device (`device`; default LOCAL_RANK, the process-per-GPU launch) or, with `devices`, the list of HIP device
+    ids this ONE process drives (capgpu_init(device_ids, n): one context per id)."""
     L = load()
-    if device is None:
-        device = int(os.environ.get("LOCAL_RANK", "0"))
-    ids = (ctypes.c_int * 1)(device)
-    check(L.capgpu_init(ids, 1))
+    if devices is None:
+        if device is None:
+            device = int(os.environ.get("LOCAL_RANK", "0"))
+        devices = [device]
+    ids = (ctypes.c_int * len(devices))(*devices)
+    check(L.capgpu_init(ids, len(devices)))
     return L
+
+
+def shutdown():
+    load().capgpu_shutdown()
+
+
+def device_count() -> int:
+    n = ctypes.c_int(0)
+    check(load().capgpu_device_count(ctypes.byref(n)))
+    return n.value
+
+
+def set_device(slot: int):
+    """bind the calling thread to context `slot` (-1: unbind)"""
+    check(load().capgpu_set_device(int(slot)))
+
+
+def get_device():
+    s, d = ctypes.c_int(0), ctypes.c_int(0)
+    check(load().capgpu_get_device(ctypes.byref(s), ctypes.byref(d)))
+    return s.value, d.value
 
 
 def _p(a: np.ndarray):
@@ -165,6 +191,12 @@ def srs_free(handle: int):
     check(load().capgpu_srs_free(ctypes.c_uint64(handle)))
 
 
+def srs_shards(handle: int) -> int:
+    n = ctypes.c_int(0)
+    check(load().capgpu_srs_shards(ctypes.c_uint64(handle), ctypes.byref(n)))
+    return n.value
+
+
 def srs_size(handle: int) -> int:
     n = ctypes.c_size_t(0)
     check(load().capgpu_srs_size(ctypes.c_uint64(handle), ctypes.byref(n)))
@@ -209,6 +241,8 @@ def msm_plan(handle: int, n: int, count: int = 1) -> dict:
     check(load().capgpu_msm_plan(ctypes.c_uint64(handle), ctypes.c_size_t(n), count, buf, ctypes.c_size_t(256)))
     out = {}
     for kv in buf.value.decode().split():
+        if "=" not in kv:
+            continue
         k, v = kv.split("=")
         out[k] = int(v) if v.isdigit() else v
     return out
@@ -224,6 +258,15 @@ def comm_unique_id() -> bytes:
 def comm_init(rank: int, world: int, unique_id: bytes):
     assert len(unique_id) == 128
     check(load().capgpu_comm_init(rank, world, (ctypes.c_uint8 * 128).from_buffer_copy(unique_id)))
+
+
+def comm_init_loopback(world: int):
+    """test communicator: this process plays `world` ranks one after the other (capgpu.h)"""
+    check(load().capgpu_comm_init_loopback(int(world)))
+
+
+def comm_loopback_set_rank(rank: int):
+    check(load().capgpu_comm_loopback_set_rank(int(rank)))
 
 
 def comm_destroy():

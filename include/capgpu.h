@@ -35,7 +35,11 @@
  *     from capgpu_malloc and enqueue on the library stream (capgpu_sync waits).
  *   - Thread safety: entry points may be called from any thread (rayon workers
  *     in the reference, src/utils/params_builder.rs:194-226); calls serialise
- *     on an internal lock per process (one process drives one GPU).  Concurrent
+ *     on an internal lock per DEVICE CONTEXT.  One process drives as many GPUs
+ *     as capgpu_init binds (see "devices" below): handles are process-wide,
+ *     resident tables are replicated to a device on first use there, and
+ *     host-buffer calls of threads that did not bind themselves to a device
+ *     are dealt over the devices by the library.  Concurrent
  *     capgpu_plonk_prove calls can be gathered into device batches instead of
  *     queueing up: capgpu_plonk_set_coalescing.
  *   - There is no CPU fallback: without a usable gfx950 device capgpu_init
@@ -62,15 +66,39 @@ extern "C" {
 #define CAPGPU_ERR_PROOF (-7) /* prover-side failure: wrong quotient degree (unsatisfied circuit), bad sizes */
 #define CAPGPU_ERR_SERIALIZATION (-8) /* malformed parameter blob: ark_serialize::SerializationError, which the
                                          reference maps to TxnApiError::DeserializationError (src/errors.rs:81-85) */
+#define CAPGPU_ERR_COMM (-9) /* multi-process exchange: a peer rank failed its part, or did not arrive in time */
 
 #define CAPGPU_NUM_WIRE_TYPES 5
 #define CAPGPU_NUM_SELECTORS 13
 
 /* ---- lifecycle ------------------------------------------------------------------------- */
-/* Binds this process to ONE GPU: device_ids[0] (NULL selects HIP device 0).  Further ids are ignored - a process
- * drives one device; N GPUs are N processes (see "multi-GPU" below), which is also what keeps the per-process lock
- * from serialising work that could run on different devices.  Idempotent. */
+/* Binds this process to the n_devices GPUs listed in device_ids (NULL / 0 selects HIP device 0): one device context
+ * - stream, resident tables, scratch, lock - per id, numbered 0 .. n_devices - 1 in the order given ("slots").  The
+ * reference is ONE process whose rayon threads each call prove() (src/utils/params_builder.rs:194-226); with several
+ * devices bound, the library itself spreads such calls:
+ *   - handles (SRS, proving keys) are process-wide; the tables behind them are copied to a device the first time it
+ *     needs them (peer copy over xGMI);
+ *   - capgpu_plonk_prove_batch / _prove_multi cut a host-resident batch into one part per device, proved concurrently;
+ *     coalesced capgpu_plonk_prove calls (capgpu_plonk_set_coalescing) form one batch per free device; single
+ *     host-buffer MSM / NTT calls go to a free device;
+ *   - an SRS of >= 2^20 points (CAPGPU_SHARD_MIN_POINTS) is SHARDED by point range over the devices when it is
+ *     uploaded or generated: every capgpu_msm_g1* call on it runs on all devices at once, each on the points it holds,
+ *     and one exchange of the 96-byte partials (peer copies) plus n_devices - 1 additions gives the result;
+ *   - *_dev entry points and capgpu_malloc work on the device of the calling thread: slot 0, or the slot the thread
+ *     chose with capgpu_set_device.
+ * A device may be listed once (CAPGPU_ERR_INVALID_ARG otherwise; CAPGPU_ALLOW_DUPLICATE_DEVICES=1 lifts this for tests
+ * that drive the multi-device paths on one GPU).  CAPGPU_CONTEXTS_PER_DEVICE=k gives every listed device k contexts,
+ * whose batches overlap on that device.  One process per GPU (torchrun) keeps working: each process binds one device
+ * and the ranks meet through capgpu_comm_* ("multi-GPU" below).  Idempotent: a second call is a no-op. */
 int capgpu_init(const int* device_ids, int n_devices);
+/* number of device contexts bound by capgpu_init (0 before it) */
+int capgpu_device_count(int* count_out);
+/* Binds the CALLING THREAD to context `slot` (0 .. count - 1): its *_dev calls, capgpu_malloc / memcpy / sync and its
+ * host-buffer calls then all run there.  slot = -1 (the default of every thread) unbinds: device-pointer calls use slot
+ * 0, host-buffer calls are dealt by the library. */
+int capgpu_set_device(int slot);
+/* the calling thread's binding (-1: none) and the HIP device id its device-pointer calls use */
+int capgpu_get_device(int* slot_out, int* hip_device_out);
 void capgpu_shutdown(void);
 const char* capgpu_last_error(void);
 const char* capgpu_version(void);
@@ -100,6 +128,8 @@ int capgpu_srs_generate(const uint64_t tau[4], size_t n, uint64_t* handle_out);
 /* bases[i] = [a + i*b] G (canonical Fr integers) - synthetic bases for the 2^24 scaling config */
 int capgpu_srs_generate_affine_seq(const uint64_t a[4], const uint64_t b[4], size_t n, uint64_t* handle_out);
 int capgpu_srs_size(uint64_t handle, size_t* n_out);
+/* point-range shards the SRS is held in: 1, or the device count for a sharded SRS (capgpu_init) */
+int capgpu_srs_shards(uint64_t handle, int* shards_out);
 /* copies bases [offset, offset+n) back as packed 64-byte Montgomery affine points */
 int capgpu_srs_download(uint64_t handle, size_t offset, size_t n, void* out);
 int capgpu_srs_free(uint64_t handle);
@@ -137,13 +167,24 @@ int capgpu_g1_sum(const uint64_t* points_xyz, size_t n, uint64_t out_xyz[12]);
  *
  * capgpu_comm_unique_id: called by ONE rank; the 128 bytes (an ncclUniqueId) travel to the other ranks by whatever
  * channel the job has (MPI, a socket, torch.distributed - bench.py broadcasts them).  capgpu_comm_init is collective:
- * it returns once all `world` ranks have called it.  RCCL is loaded at that moment (dlopen of librccl.so.1; a copy
- * already in the process is reused), so single-GPU users need no RCCL at all. */
+ * it returns once all `world` ranks have called it - or fails with CAPGPU_ERR_COMM when they have not arrived within
+ * CAPGPU_COMM_TIMEOUT_MS (default 60000).  RCCL is loaded at that moment (dlopen of librccl.so.1; a copy
+ * already in the process is reused), so single-GPU users need no RCCL at all.
+ * Failures are agreed on: a rank whose local MSM fails still enters the exchange (its status travels with the
+ * partials) and every rank returns an error; a rank that never enters it is caught by the same deadline, the
+ * communicator is aborted and the call returns CAPGPU_ERR_COMM instead of hanging. */
 int capgpu_comm_unique_id(uint8_t id_out[128]);
 int capgpu_comm_init(int rank, int world, const uint8_t id[128]);
 int capgpu_comm_destroy(void);
 /* rank / world of the communicator; world == 0 when there is none */
 int capgpu_comm_info(int* rank_out, int* world_out);
+/* Test communicator: a world of `world` ranks that THIS process plays one after the other on its device, through the
+ * same payload layout, gather buffer and summation kernel as the RCCL path (the all-gather itself becomes a copy into
+ * the rank's slot).  capgpu_msm_g1_sharded_dev is then called once per rank (capgpu_comm_loopback_set_rank before each;
+ * the call of the last rank leaves the sum), and with capgpu_plonk_shard_msm(1) the prover plays all ranks of every
+ * commitment MSM itself.  Lets a 1-GPU box execute the N > 1 code paths. */
+int capgpu_comm_init_loopback(int world);
+int capgpu_comm_loopback_set_rank(int rank);
 /* out (on every rank) = sum over ranks of sum_i scalars_r[i] * bases_r[offset + i]: `count` MSMs in one launch, their
  * partials exchanged in ONE all-gather of count * 96 bytes per rank.  Arguments as capgpu_msm_g1_dev (n_local = this
  * rank's points; may differ between ranks, count may not). */

@@ -1,0 +1,298 @@
+"""One process, N GPUs (capgpu_init(device_ids, n), cap_amd/csrc/context.hpp) - on the ONE GPU a test box has.
+
+The reference is one process whose rayon threads each call prove() (src/utils/params_builder.rs:194-226), so the library
+itself spreads work over the devices it was given.  With CAPGPU_ALLOW_DUPLICATE_DEVICES=1 device 0 may be bound twice:
+two contexts - two streams, two sets of resident tables, two locks - that run exactly the code two GPUs would, except
+that a replica on the "other device" is the same memory.  Checked here:
+  * batches with host-resident witnesses are dealt over the contexts, the proofs bit-identical to the one-context run
+    (the full-size 64-proof mix of BASELINE config 4 included);
+  * handles are process-wide: a key / SRS made on one context works on the other;
+  * an SRS above the sharding threshold is cut by point range over the contexts and every MSM form on it (host, batch,
+    device-resident, sub-ranges across the cut) equals the unsharded result and the known answer;
+  * coalesced single-proof calls are served by both contexts.
+"""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from cap_amd import bench_utils as bu
+from oracle import bn254 as bn
+from oracle import capref as cr
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+A_SEQ, B_SEQ = 0x1234567890ABCDEF1234567890ABCDEF % bn.R, 0xFEDCBA0987654321FEDCBA % bn.R
+
+
+@pytest.fixture(scope="module")
+def cg2(cg):
+    """the library re-initialised with device 0 bound twice; restored to the session's single context afterwards"""
+    cg.shutdown()
+    os.environ["CAPGPU_ALLOW_DUPLICATE_DEVICES"] = "1"
+    os.environ["CAPGPU_SHARD_MIN_POINTS"] = "4096"
+    try:
+        cg.init(devices=[0, 0])
+        assert cg.device_count() == 2
+        yield cg
+    finally:
+        cg.shutdown()
+        del os.environ["CAPGPU_ALLOW_DUPLICATE_DEVICES"]
+        del os.environ["CAPGPU_SHARD_MIN_POINTS"]
+        cg.init(0)
+        assert cg.device_count() == 1
+
+
+def test_a_device_may_be_listed_once(cg):
+    """(runs on the session's context: a second capgpu_init is a no-op, so the refusal is checked after a shutdown)"""
+    cg.shutdown()
+    try:
+        with pytest.raises(cg.CapGpuError) as e:
+            cg.init(devices=[0, 0])
+        assert e.value.code == -1 and "twice" in str(e.value)
+        with pytest.raises(cg.CapGpuError) as e:
+            cg.init(devices=[0, 99])
+        assert e.value.code == -1
+        assert cg.device_count() == 0
+    finally:
+        cg.init(0)
+    assert cg.device_count() == 1
+    with pytest.raises(cg.CapGpuError):
+        cg.set_device(1)
+    cg.set_device(0)
+    assert cg.get_device() == (0, 0)
+    cg.set_device(-1)
+
+
+def _witnesses(sc, count, seed):
+    ws, ps, bls = [], [], []
+    for p in range(count):
+        w, pubs = sc.witness(seed + p)
+        ws.append(sc.wires_mont(w))
+        ps.append(bu.to_mont_array(pubs))
+        bls.append(bu.to_mont_array(bu.blinders(seed + 1000 + p)))
+    return np.stack(ws), np.stack(ps), np.stack(bls)
+
+
+def test_host_batches_are_dealt_over_the_contexts(cg2, tau):
+    cg = cg2
+    sc = bu.synthetic_circuit(10, 4, seed=21)
+    h = cg.srs_generate(tau, sc.n + 3)
+    pkh, vk = cg.plonk_preprocess(h, sc.n, 4, sc.selectors_mont(), sc.sigma_mont())
+    ws, ps, bls = _witnesses(sc, 37, 300)
+    cg.set_device(0)                                   # a bound thread keeps its batch on its context
+    cg.profile_reset()
+    one = cg.plonk_prove_batch(pkh, ws, ps, bls, b"deal", 37)
+    cg.set_device(-1)
+    cg.profile_enable(True)
+    cg.profile_reset()
+    two = cg.plonk_prove_batch(pkh, ws, ps, bls, b"deal", 37)     # unbound: parts of 18 and 19 proofs
+    st = cg.profile_stats()
+    cg.profile_enable(False)
+    assert [bytes(p) for p in one] == [bytes(p) for p in two]
+    assert st["k_quotient"][1] == 2, st["k_quotient"]             # one quotient launch per part: both contexts worked
+    # ... and against the CPU restatement
+    key = cr.PlonkKey(cg.srs_download(h, 0, sc.n + 3), sc.n, 4, sc.selectors_mont(), sc.sigma_mont())
+    for i in (0, 18, 36):
+        rc, comms, evals = key.prove(ws[i], ps[i], bls[i], b"deal")
+        assert rc == 0 and H.proof_points(two[i]) == H.cref_proof_points(comms, evals)
+    # a batch too small to cut stays whole
+    cg.profile_enable(True)
+    cg.profile_reset()
+    small = cg.plonk_prove_batch(pkh, ws[:9], ps[:9], bls[:9], b"deal", 9)
+    assert cg.profile_stats()["k_quotient"][1] == 1
+    cg.profile_enable(False)
+    assert [bytes(p) for p in small] == [bytes(p) for p in one[:9]]
+    # an unsatisfied witness in one part fails the call with that part's error
+    bad = ws.copy()
+    bad[30, 0, 5, 0] ^= 1
+    with pytest.raises(cg.CapGpuError) as e:
+        cg.plonk_prove_batch(pkh, bad, ps, bls, b"deal", 37)
+    assert e.value.code == -7
+    cg.plonk_free_key(pkh)
+    cg.srs_free(h)
+
+
+def test_handles_are_process_wide(cg2, tau):
+    """an SRS and a key made by a thread on context 0 serve a thread bound to context 1 (replicated on first use)"""
+    cg = cg2
+    sc = bu.synthetic_circuit(8, 3, seed=5)
+    cg.set_device(0)
+    h = cg.srs_generate(tau, 3000)
+    pkh, vk = cg.plonk_preprocess(h, sc.n, 3, sc.selectors_mont(), sc.sigma_mont())
+    ws, ps, bls = _witnesses(sc, 2, 11)
+    k = cr.random_field(9, 1, 3000, False)
+    want_msm = cr.g1_to_affine(cg.msm_g1(h, k))
+    want = cg.plonk_prove_batch(pkh, ws, ps, bls, None, 2)
+    out = {}
+
+    def other():
+        try:
+            cg.set_device(1)
+            assert cg.get_device()[0] == 1
+            out["msm"] = cr.g1_to_affine(cg.msm_g1(h, k))
+            d = cg.DevBuf.from_numpy(k)                             # device memory of context 1
+            out["msm_dev"] = cr.g1_to_affine(cg.msm_g1_dev(h, d, 3000).to_numpy())
+            out["proofs"] = cg.plonk_prove_batch(pkh, ws, ps, bls, None, 2)
+            out["srs"] = cg.srs_download(h, 5, 10)
+            d.free()
+        except Exception as ex:                                      # noqa: BLE001
+            out["error"] = ex
+
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert "error" not in out, out.get("error")
+    assert np.array_equal(out["msm"], want_msm) and np.array_equal(out["msm_dev"], want_msm)
+    assert [bytes(p) for p in out["proofs"]] == [bytes(p) for p in want]
+    assert np.array_equal(out["srs"], cg.srs_download(h, 5, 10))
+    cg.set_device(-1)
+    cg.plonk_free_key(pkh)
+    with pytest.raises(cg.CapGpuError) as e:                       # gone on every context
+        cg.plonk_prove_batch(pkh, ws, ps, bls, None, 2)
+    assert e.value.code == -4
+    cg.srs_free(h)
+    with pytest.raises(cg.CapGpuError) as e:
+        cg.msm_g1(h, k)
+    assert e.value.code == -4
+
+
+def test_a_large_srs_is_sharded_by_point_range(cg2, tau):
+    cg = cg2
+    n = 10001                                                       # above the (lowered) threshold, odd: ragged shards
+    h = cg.srs_generate_affine_seq(A_SEQ, B_SEQ, n)
+    assert cg.srs_shards(h) == 2 and cg.srs_size(h) == n
+    assert cg.msm_plan(h, n, 1)["shards"] == 2
+    sc = bu.random_canonical_scalars(91, n)
+    sc[0] = 0
+    sc[1] = cr.int_to_limbs(1)
+    sc[5000] = cr.int_to_limbs(bn.R - 1)
+
+    def expect(s, lo=0):
+        s0, s1 = bu.weighted_scalar_sums(s, lo)
+        return bn.g1_mul(bn.G1_GEN, (A_SEQ * s0 + B_SEQ * s1) % bn.R)
+
+    def aff(j):
+        return cr.affine_to_ints(cr.g1_to_affine(j))
+
+    assert aff(cg.msm_g1(h, sc)) == expect(sc)
+    # sub-ranges: inside shard 0, inside shard 1, across the cut, empty
+    for off, m in ((0, 4000), (6000, 4001), (4990, 25), (3000, 5500), (777, 0)):
+        assert aff(cg.msm_g1(h, sc[off:off + m], offset=off)) == expect(sc[off:off + m], off), (off, m)
+    # several MSMs of unequal ranges in one call
+    got = cg.msm_g1_batch(h, [sc[:6000], sc[4000:9000], sc[9000:]], offsets=[0, 4000, 9000])
+    assert [aff(g) for g in got] == [expect(sc[:6000]), expect(sc[4000:9000], 4000), expect(sc[9000:], 9000)]
+    # device-resident scalars (Montgomery form, three arrays, a stride): the slices travel to the shards' devices
+    scs = np.stack([bu.random_canonical_scalars(92 + i, 7000) for i in range(3)])
+    d = cg.DevBuf.from_numpy(cr.vec_to_mont(1, scs.reshape(-1, 4)))
+    out = cg.msm_g1_dev(h, d, 6500, count=3, stride=7000, montgomery=True, offset=2000).to_numpy().reshape(3, 12)
+    for i in range(3):
+        assert aff(out[i]) == expect(scs[i, :6500], 2000), i
+    d.free()
+    # the sharded table is the unsharded one, cut
+    os.environ["CAPGPU_SHARD_MIN_POINTS"] = "100000"
+    h1 = cg.srs_generate_affine_seq(A_SEQ, B_SEQ, n)
+    os.environ["CAPGPU_SHARD_MIN_POINTS"] = "4096"
+    assert cg.srs_shards(h1) == 1
+    assert np.array_equal(cg.srs_download(h, 4990, 30), cg.srs_download(h1, 4990, 30))
+    assert np.array_equal(cr.g1_to_affine(cg.msm_g1(h1, sc)), cr.g1_to_affine(cg.msm_g1(h, sc)))
+    # powers of tau, uploaded from host memory (the other way an SRS arrives)
+    host = cg.srs_download(h1, 0, n)
+    h2 = cg.srs_upload(host)
+    assert cg.srs_shards(h2) == 2
+    assert aff(cg.msm_g1(h2, sc)) == expect(sc)
+    ht = cg.srs_generate(tau, 5000)
+    assert cg.srs_shards(ht) == 2
+    f = bu.random_canonical_scalars(95, 5000)
+    ftau = bn.from_mont(cr.poly_eval_fr(cr.vec_to_mont(1, f), bn.to_mont(tau, bn.R)), bn.R)
+    assert aff(cg.msm_g1(ht, f)) == bn.g1_mul(bn.G1_GEN, ftau)
+    # a sharded SRS commits no proving key: refused, not mis-served
+    circ = bu.synthetic_circuit(6, 2, seed=1)
+    with pytest.raises(cg.CapGpuError) as e:
+        cg.plonk_preprocess(ht, circ.n, 2, circ.selectors_mont(), circ.sigma_mont())
+    assert e.value.code == -1 and "sharded" in str(e.value)
+    for x in (h, h1, h2, ht):
+        cg.srs_free(x)
+
+
+def test_coalesced_calls_use_every_context(cg2, tau):
+    cg = cg2
+    sc = bu.synthetic_circuit(9, 3, seed=8)
+    h = cg.srs_generate(tau, sc.n + 3)
+    pkh, vk = cg.plonk_preprocess(h, sc.n, 3, sc.selectors_mont(), sc.sigma_mont())
+    T = 24
+    ws, ps, bls = _witnesses(sc, T, 40)
+    want = cg.plonk_prove_batch(pkh, ws, ps, bls, b"c", T)
+    got, errs = [None] * T, []
+    cg.plonk_set_coalescing(300, 6)                                  # small batches: both contexts get some
+    b0, p0 = cg.plonk_coalescing_stats()
+
+    def worker(i):
+        try:
+            got[i] = cg.plonk_prove(pkh, ws[i], ps[i], bls[i], b"c")
+        except Exception as ex:                                      # noqa: BLE001
+            errs.append(ex)
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(T)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    cg.plonk_set_coalescing(0, 0)
+    assert not errs, errs
+    assert [bytes(p) for p in got] == [bytes(p) for p in want]
+    b1, p1 = cg.plonk_coalescing_stats()
+    assert p1 - p0 == T and 4 <= b1 - b0 < T
+    cg.plonk_free_key(pkh)
+    cg.srs_free(h)
+
+
+def test_mixed_batch_of_64_full_size_split_over_two_contexts(cg2, tau):
+    """BASELINE config 4 at full size: 32 transfer 2x3 + 19 freeze 3 (n = 2^15, one mixed-key device batch) and 13 mint
+    (n = 2^14), dealt over two contexts - every proof the bytes of the one-context run."""
+    cg = cg2
+    mix = [("transfer_2x3", 32), ("mint", 13), ("freeze_3", 19)]
+    n_max = 1 << max(bu.NOTE_SHAPES[k][0] for k, _ in mix)
+    os.environ["CAPGPU_SHARD_MIN_POINTS"] = str(1 << 20)            # (the module lowers it; a commit key is never cut)
+    h = cg.srs_generate(tau, n_max + 3)
+    os.environ["CAPGPU_SHARD_MIN_POINTS"] = "4096"
+    assert cg.srs_shards(h) == 1
+    groups = []
+    for gi, (kind, count) in enumerate(mix):
+        sc = bu.note_circuit(kind, seed=40 + gi)
+        pkh, vk = cg.plonk_preprocess(h, sc.n, sc.num_inputs, sc.selectors_mont(), sc.sigma_mont())
+        wit = [sc.witness(500 + 10 * gi + i) for i in range(3)]
+        wires = np.stack([sc.wires_mont(wit[i % 3][0]) for i in range(count)])
+        pubs = np.stack([bu.to_mont_array(wit[i % 3][1]) for i in range(count)])
+        blind = np.stack([bu.to_mont_array(bu.blinders(900 + 100 * gi + i)) for i in range(count)])
+        msg = None if kind == "mint" else b"txn-memo-ver-key"
+        groups.append((pkh, wires, pubs, blind, msg, count, sc.n))
+    same = [g for g in groups if g[6] == n_max]
+    mint = [g for g in groups if g[6] != n_max][0]
+    max_in = max(g[2].shape[1] for g in same)
+    rows = np.concatenate([np.pad(g[2], ((0, 0), (0, max_in - g[2].shape[1]), (0, 0))) for g in same])
+    handles = [g[0] for g in same for _ in range(g[5])]
+    wires = np.concatenate([g[1] for g in same])
+    blind = np.concatenate([g[3] for g in same])
+    msgs = [g[4] for g in same for _ in range(g[5])]
+
+    def run():
+        a = cg.plonk_prove_multi(handles, wires, rows, blind, msgs)
+        b = cg.plonk_prove_batch(mint[0], mint[1], mint[2], mint[3], mint[4], mint[5])
+        return [bytes(p) for p in a + b]
+
+    cg.set_device(0)
+    one = run()
+    cg.set_device(-1)
+    cg.profile_enable(True)
+    cg.profile_reset()
+    two = run()
+    launches = cg.profile_stats()["k_quotient"][1]
+    cg.profile_enable(False)
+    assert launches == 4                                             # each of the two calls ran as two parts
+    assert one == two and len(set(one)) == 64
+    for g in groups:
+        cg.plonk_free_key(g[0])
+    cg.srs_free(h)
