@@ -12,16 +12,20 @@
 // Failure handling: every rank's payload carries a status word behind its points.  A rank whose local step failed still
 // takes part in the all-gather (points at infinity, status = its error code), so nobody is left waiting, and every rank
 // returns an error afterwards.  A rank that never arrives is caught by a deadline (CAPGPU_COMM_TIMEOUT_MS, default
-// 60 s) on the communicator's creation and on the wait behind each exchange: the communicator is aborted and the call
-// fails instead of hanging with the context lock held.
+// 60 s): on the communicator's creation (which runs on a helper thread, RCCL blocks inside it) and on the wait behind
+// each exchange (the communicator is aborted) - the call fails instead of hanging with the context lock held.
 //
 // RCCL is loaded at capgpu_comm_init time (dlopen), so the library itself loads - and the single-GPU path runs - on
 // machines without it.  If the process already holds an RCCL (PyTorch ships one), that copy is used.
 #include <dlfcn.h>
 #include <rccl/rccl.h>  // types only: every function is looked up at run time
+#include <stdio.h>
 #include <string.h>
 
 #include <chrono>
+#include <condition_variable>
+#include <memory>
+#include <mutex>
 #include <thread>
 
 #include "context.hpp"
@@ -35,9 +39,7 @@ struct Rccl {
   void* lib = nullptr;
   ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
   ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
-  ncclResult_t (*CommInitRankConfig)(ncclComm_t*, int, ncclUniqueId, int, ncclConfig_t*) = nullptr;  // optional
-  ncclResult_t (*CommGetAsyncError)(ncclComm_t, ncclResult_t*) = nullptr;                             // optional
-  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;                                                    // optional
+  ncclResult_t (*CommAbort)(ncclComm_t) = nullptr;  // optional
   ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
   ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
   const char* (*GetErrorString)(ncclResult_t) = nullptr;
@@ -46,7 +48,6 @@ struct Rccl {
 struct Comm {
   Rccl api;
   ncclComm_t comm = nullptr;
-  bool nonblocking = false;
   bool loopback = false;  // test communicator: `world` ranks played one after the other on this device
   int rank = 0, world = 1;
   int slot = 0;               // the context the communicator belongs to
@@ -62,6 +63,19 @@ Comm& comm() {
   static Comm c;
   return c;
 }
+
+bool comm_debug() {
+  const char* e = getenv("CAPGPU_COMM_DEBUG");
+  return e && atoi(e) != 0;
+}
+#define COMM_DBG(...)                                 \
+  do {                                                \
+    if (comm_debug()) {                               \
+      fprintf(stderr, "[capgpu_comm] " __VA_ARGS__);  \
+      fputc('\n', stderr);                            \
+      fflush(stderr);                                 \
+    }                                                 \
+  } while (0)
 
 long timeout_ms() {
   const char* e = getenv("CAPGPU_COMM_TIMEOUT_MS");
@@ -84,8 +98,6 @@ int load_rccl(Rccl& r) {
   }
   r.GetUniqueId = (decltype(r.GetUniqueId))dlsym(h, "ncclGetUniqueId");
   r.CommInitRank = (decltype(r.CommInitRank))dlsym(h, "ncclCommInitRank");
-  r.CommInitRankConfig = (decltype(r.CommInitRankConfig))dlsym(h, "ncclCommInitRankConfig");
-  r.CommGetAsyncError = (decltype(r.CommGetAsyncError))dlsym(h, "ncclCommGetAsyncError");
   r.CommAbort = (decltype(r.CommAbort))dlsym(h, "ncclCommAbort");
   r.CommDestroy = (decltype(r.CommDestroy))dlsym(h, "ncclCommDestroy");
   r.AllGather = (decltype(r.AllGather))dlsym(h, "ncclAllGather");
@@ -114,27 +126,6 @@ void abandon_comm() {
   c.rank = 0;
   c.world = 1;
   c.shard_prover = false;
-}
-
-// polls a non-blocking communicator until its pending operation has settled
-int wait_async(const char* what) {
-  Comm& c = comm();
-  if (!c.nonblocking || !c.api.CommGetAsyncError) return CAPGPU_OK;
-  const auto t0 = std::chrono::steady_clock::now();
-  for (;;) {
-    ncclResult_t st = ncclSuccess;
-    ncclResult_t e = c.api.CommGetAsyncError(c.comm, &st);
-    if (e != ncclSuccess) return rccl_fail(e, "ncclCommGetAsyncError");
-    if (st == ncclSuccess) return CAPGPU_OK;
-    if (st != ncclInProgress) return rccl_fail(st, what);
-    if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms())) {
-      abandon_comm();
-      set_error("capgpu_comm: %s did not complete within %ld ms (a rank is missing?); communicator aborted", what,
-                timeout_ms());
-      return CAPGPU_ERR_COMM;
-    }
-    std::this_thread::sleep_for(std::chrono::microseconds(200));
-  }
 }
 
 // waits for the stream with a deadline instead of hipStreamSynchronize: a peer that never enters the collective must
@@ -247,9 +238,7 @@ int comm_allgather_sum(g1_jac* d_points, uint32_t count, hipStream_t s, int loca
     if (c.rank != c.world - 1) return local_rc;
   } else {
     ncclResult_t e = c.api.AllGather(c.d_send, c.d_gather, sizeof(g1_jac) * stride, ncclUint8, c.comm, s);
-    if (e != ncclSuccess && e != ncclInProgress) return rccl_fail(e, "ncclAllGather");
-    int rc = wait_async("ncclAllGather");
-    if (rc) return rc;
+    if (e != ncclSuccess) return rccl_fail(e, "ncclAllGather");
   }
   g1_sum_ranks(c.d_gather, (uint32_t)c.world, (uint32_t)stride, count, d_points, s);
   CAP_HIP(hipMemcpy2DAsync(c.h_status, sizeof(uint32_t), c.d_gather + count, sizeof(g1_jac) * stride, sizeof(uint32_t),
@@ -307,55 +296,60 @@ int capgpu_comm_init(int rank, int world, const uint8_t id[128]) {
     int rc = load_rccl(c.api);
     if (rc) return rc;
   }
-  // Creating the communicator is collective: the context lock is NOT held across it, so a rank that never shows up
-  // cannot freeze the single-GPU entry points of this process.  Non-blocking creation with a deadline where the RCCL in
-  // the process offers it (CAPGPU_COMM_BLOCKING=1 forces the plain blocking call).
-  ncclUniqueId uid;
-  memcpy(uid.internal, id, 128);
-  ncclComm_t nc = nullptr;
-  bool nonblocking = false;
-  const char* be = getenv("CAPGPU_COMM_BLOCKING");
-  if (!(be && atoi(be) != 0) && c.api.CommInitRankConfig && c.api.CommGetAsyncError && c.api.CommAbort) {
-    ncclConfig_t cfg = NCCL_CONFIG_INITIALIZER;
-    cfg.blocking = 0;
-    ncclResult_t e = c.api.CommInitRankConfig(&nc, world, uid, rank, &cfg);
-    if (e == ncclSuccess || e == ncclInProgress) {
-      nonblocking = true;
-      const auto t0 = std::chrono::steady_clock::now();
-      for (;;) {
-        ncclResult_t st = ncclSuccess;
-        e = c.api.CommGetAsyncError(nc, &st);
-        if (e != ncclSuccess) st = e;
-        if (st == ncclSuccess) break;
-        if (st != ncclInProgress) {
-          c.api.CommAbort(nc);
-          return rccl_fail(st, "ncclCommInitRankConfig");
-        }
-        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(timeout_ms())) {
-          c.api.CommAbort(nc);
-          set_error("capgpu_comm_init: rank %d of %d: the other ranks did not arrive within %ld ms", rank, world,
-                    timeout_ms());
-          return CAPGPU_ERR_COMM;
-        }
-        std::this_thread::sleep_for(std::chrono::milliseconds(1));
+  // Creating the communicator is collective and RCCL blocks inside it until every rank has arrived (its non-blocking
+  // mode blocks in the bootstrap all the same - probed on this image, tools/gpu_comm_timeout_probe.py).  So the call
+  // runs on a helper thread and this one waits for it with a deadline, the context lock NOT held: a rank that never
+  // shows up costs the helper thread (it stays parked inside RCCL; should the world complete later it destroys the
+  // communicator it got), not the process - every other entry point keeps working.
+  struct Pending {
+    std::mutex mu;
+    std::condition_variable cv;
+    bool finished = false, abandoned = false;
+    ncclResult_t result = ncclSuccess;
+    ncclComm_t nc = nullptr;
+  };
+  auto pend = std::make_shared<Pending>();
+  {
+    const int device = ctx().device;
+    ncclUniqueId uid;
+    memcpy(uid.internal, id, 128);
+    const Rccl api = c.api;
+    std::thread([pend, api, uid, world, rank, device] {
+      (void)hipSetDevice(device);
+      ncclComm_t nc = nullptr;
+      COMM_DBG("ncclCommInitRank rank %d of %d", rank, world);
+      ncclResult_t e = api.CommInitRank(&nc, world, uid, rank);
+      COMM_DBG("... returned %d", (int)e);
+      std::lock_guard<std::mutex> lk(pend->mu);
+      pend->result = e;
+      pend->nc = nc;
+      pend->finished = true;
+      if (pend->abandoned && e == ncclSuccess && nc) {
+        if (api.CommAbort) api.CommAbort(nc);
+        else api.CommDestroy(nc);
       }
-    } else {
-      nc = nullptr;  // (a config this RCCL does not accept: fall back to the blocking call)
-    }
+      pend->cv.notify_all();
+    }).detach();
   }
-  if (!nc) {
-    ncclResult_t e = c.api.CommInitRank(&nc, world, uid, rank);
-    if (e) return rccl_fail(e, "ncclCommInitRank");
+  ncclComm_t nc = nullptr;
+  {
+    std::unique_lock<std::mutex> plk(pend->mu);
+    if (!pend->cv.wait_for(plk, std::chrono::milliseconds(timeout_ms()), [&] { return pend->finished; })) {
+      pend->abandoned = true;
+      set_error("capgpu_comm_init: rank %d of %d: the other ranks did not arrive within %ld ms", rank, world,
+                timeout_ms());
+      return CAPGPU_ERR_COMM;
+    }
+    if (pend->result != ncclSuccess) return rccl_fail(pend->result, "ncclCommInitRank");
+    nc = pend->nc;
   }
   Entry lk(ctx());
   if (comm_exists()) {  // a concurrent capgpu_comm_init won the race
-    if (nonblocking && c.api.CommAbort) c.api.CommAbort(nc);
-    else c.api.CommDestroy(nc);
+    c.api.CommDestroy(nc);
     set_error("capgpu_comm_init: a communicator already exists (capgpu_comm_destroy first)");
     return CAPGPU_ERR_INVALID_ARG;
   }
   c.comm = nc;
-  c.nonblocking = nonblocking;
   c.loopback = false;
   c.rank = rank;
   c.world = world;
@@ -376,7 +370,6 @@ int capgpu_comm_init_loopback(int world) {
     return CAPGPU_ERR_INVALID_ARG;
   }
   c.comm = nullptr;
-  c.nonblocking = false;
   c.loopback = true;
   c.rank = 0;
   c.world = world;
@@ -406,7 +399,6 @@ int capgpu_comm_destroy(void) {
   if (c.comm) c.api.CommDestroy(c.comm);
   c.comm = nullptr;
   c.loopback = false;
-  c.nonblocking = false;
   c.rank = 0;
   c.world = 1;
   c.shard_prover = false;

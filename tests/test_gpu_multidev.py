@@ -291,7 +291,7 @@ def test_mixed_batch_of_64_full_size_split_over_two_contexts(cg2, tau):
     two = run()
     launches = cg.profile_stats()["k_quotient"][1]
     cg.profile_enable(False)
-    assert launches == 4                                             # each of the two calls ran as two parts
+    assert launches == 3                  # the 51-proof batch ran as two parts, the 13 mints (< 2 x 8) stayed whole
     assert one == two and len(set(one)) == 64
     for g in groups:
         cg.plonk_free_key(g[0])
