@@ -30,7 +30,8 @@ constexpr int kDigitThreads = 1024;       // one scalar per thread: 16 waves hid
 // A bucket's list is cut into work items of at most item_len entries (one msm_accumulate thread each).  item_len
 // is chosen per launch: long items (one per bucket at the prover's sizes) when the batch alone fills the chip,
 // short ones when a single MSM has to be spread over all CUs.
-constexpr uint32_t kMinItemLen = 32, kMaxItemLen = 256;
+constexpr uint32_t kMinItemLen = 32, kMaxItemLen = 512;
+constexpr uint32_t kBatchItemCap = 256;  // cap of the batched plans (the deep plan takes the full kMaxItemLen)
 
 // Two schedules of the same field arithmetic (field29.hpp).  G1L (column-wise products, 204 instructions per
 // multiplication) is for everything that runs more than a handful of waves.  G1S (row-wise, 220 instructions, 18
@@ -144,7 +145,9 @@ __device__ __forceinline__ uint32_t tile_entry_index(uint32_t v, uint32_t tile, 
 
 // Sub-MSM `sb` of a launch = (MSM b = sb / parts, part = sb % parts): scalars [part * n_sub, part * n_sub + len) of MSM
 // b, where len = min(n_sub, n - part * n_sub).
-template <uint32_t CT>  // CT = 13 / 15: window size known at compile time; 0: taken from the argument c
+// DEEP (the three-level sort of long single MSMs, below): up to 14 low key bits ride at bit 14 of the entry (the window
+// field is then 4 bits: at most 16 windows).
+template <uint32_t CT, bool DEEP = false>  // CT: window size known at compile time; 0: taken from the argument c
 __global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __restrict__ scalars, size_t outer_stride,
                                                              uint32_t inner, size_t inner_stride, size_t n_total,
                                                              size_t n_sub, uint32_t parts,
@@ -166,7 +169,8 @@ __global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __re
   // batch entry write interleaved 4-byte cells of the same table lines ([bucket][tile] layout), so they are all sent
   // to one XCD, where the partial writes merge in that L2 instead of leaving eight L2s as masked partial lines.
   const uint32_t xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-  const uint32_t b = (slot / nblk) * 8 + xcd, blk = slot % nblk;
+  // (a launch of ONE entry has nothing to spread: its grid is just the tiles)
+  const uint32_t b = batch == 1 ? 0 : (slot / nblk) * 8 + xcd, blk = batch == 1 ? blockIdx.x : slot % nblk;
   if (b >= batch) return;
   for (uint32_t j = threadIdx.x; j < half; j += kDigitThreads) hist[j] = 0;
   __syncthreads();
@@ -177,7 +181,8 @@ __global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __re
   static_assert(kDigitTile == kDigitThreads, "one scalar per thread: it stays in registers between the passes");
   const size_t i = (size_t)blk * kDigitTile + threadIdx.x;
   // CT != 0: the digits are extracted once, with compile-time limb indices, and live in registers across both passes
-  constexpr uint32_t NWIN = CT ? (256 + CT - 1) / CT + (256 % CT == 0 ? 1 : 0) : 1;
+  constexpr uint32_t CTD = CT ? CT : 1;  // (keeps the CT == 0 instantiation free of divisions by zero)
+  constexpr uint32_t NWIN = CT ? (256 + CTD - 1) / CTD + (256 % CTD == 0 ? 1 : 0) : 1;
   uint32_t dg[NWIN];
   fe k;
   if (i < n) {
@@ -237,7 +242,7 @@ __global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __re
       const uint32_t mag = d & 0x7FFFFFFFu;
       if (mag) {
         uint32_t pos = atomicAdd(&hist[(mag - 1) >> sub_bits], 1u);
-        buf[pos] = (w << 10) | threadIdx.x | (((mag - 1) & sub_mask) << 24) | (d & 0x80000000u);
+        buf[pos] = (w << 10) | threadIdx.x | (((mag - 1) & sub_mask) << (DEEP ? 14 : 24)) | (d & 0x80000000u);
       }
     };
     if constexpr (CT != 0) {
@@ -419,6 +424,215 @@ __global__ __launch_bounds__(kThreads) CAP_L2_WAVES void msm_sort_level2(const u
   for (uint32_t p = kL2Stage + threadIdx.x; p < cnt; p += kThreads) place(fetch(p));
   __syncthreads();
   for (uint32_t p = threadIdx.x; p < staged; p += kThreads) dst[p] = stage[p];
+}
+
+// ---- K4 for long single MSMs: three-level ("deep") sort ---------------------------------------------------------
+// A single MSM of 2^20 .. 2^24 points wants ONE bucket set with windows of c = log2(n) - 2 bits: 12-15 digits per scalar
+// instead of the 17 of the c = 15 table, and a bucket reduction that is noise against n * W / 2^(c-1) ~ 100 additions
+// per bucket.  Its W n entries must then be sorted by a key of K = c - 1 = 17 .. 21 bits.  Three counting sorts in LDS:
+//   L1  msm_digits_local<CT, DEEP>: a tile of 1024 scalars by the top `top` bits of the bucket (<= 128 super-bins; runs
+//       of ~100-500 entries per tile and super-bin)
+//   L2  msm_deep_sort<0>: workgroup (super-bin S, group g of G tiles) gathers the tiles' runs for S (~12-16 K entries)
+//       and sorts them by the next `mid` bits; it writes them back to the range the runs occupy in the S-major order,
+//       with one row of the [S][mid][group] count table
+//   L3  msm_deep_sort<1>: workgroup (S, mid) gathers its run from every group - the ~12 K entries of 32-128 buckets -
+//       sorts by the low 5-7 bits and emits the final bucket lists (table index | sign), bucket counts and offsets.
+// Entries stay 4 bytes throughout because position carries the rest: a tile entry is (t, w, low key bits); L2 adds the
+// tile's number within its group (7 bits), L3 knows the group from the run it reads.
+//   after L1:  t 0-9 | w 10-13 | the key's mid + low bits 14-27 | sign 31
+//   after L2:  t 0-9 | w 10-13 | the key's low bits (5-7 of them) from 14 | tile in group 21-27 | sign 31
+// Everything downstream sees the 2^K buckets as 2^(K-14) batch entries of 16384 buckets (msm_accumulate, the running-sum
+// or bit-plane reductions), whose (sum, weighted sum) pairs one more msm_reduce_final folds with the entry offsets.
+constexpr uint32_t kDeepThreads = 1024;   // 16 waves share a 64 KiB stage: two workgroups per CU fill its wave slots
+constexpr uint32_t kDeepStage = 16384;    // entries staged in LDS between the passes (a bin beyond it: see level 2 sort)
+constexpr uint32_t kDeepMaxRuns = 512;    // runs a workgroup gathers (tiles per group <= 128; groups per MSM <= 512)
+// buckets per downstream batch entry.  (4096 - a quarter of the msm_reduce_final chain - was measured: the reduction
+// 0.67 -> 0.43 ms, but msm_accumulate 16.3 -> 17.4 ms at 2^24 points: its items are length-sorted per entry.)
+constexpr uint32_t kDeepEntryBucketsDefault = 16384;
+uint32_t deep_entry_buckets() {
+  const char* e = getenv("CAPGPU_MSM_DEEP_ENTRY");
+  const int x = e ? atoi(e) : 0;
+  return x == 4096 || x == 8192 || x == 16384 ? (uint32_t)x : kDeepEntryBucketsDefault;
+}
+// Entries per work item of the deep plan: about four items per bucket, 64 or 128 entries.  Measured at 2^24 points
+// (416 entries per bucket; msm_accumulate + msm_combine + msm_sort_items): items of 512 -> 16.4 ms, 256 -> 15.9, 128 -> 15.6,
+// 64 -> 15.7; at 2^22 (104 per bucket): 512 -> 4.34, 128 -> 4.34, 64 -> 4.26.  Shorter items mean more, shorter waves:
+// the launch's tail is shorter and the chip's 3 waves per SIMD are kept full for longer.
+uint32_t deep_item_len(size_t avg_bucket) {
+  const char* e = getenv("CAPGPU_MSM_DEEP_ITEM");
+  const int x = e ? atoi(e) : 0;
+  if (x >= 32 && x <= 512) return (uint32_t)x;
+  return avg_bucket / 4 > 64 ? 128u : 64u;
+}
+#define kDeepEntryBuckets deep_entry_buckets()
+// buckets per running-sum segment of the deep plan: its 2^16 .. 2^21 buckets must spread over the chip as short chains
+// (16: 32 dependent additions per thread, 1024 segments per entry for the one-wave finish)
+constexpr uint32_t kDeepSegLen = 16;
+// buckets per reduction entry (256 segments: 4 per lane of the entry's msm_reduce_final wave; the last launch then folds
+// 2^(K-12) <= 512 (sum, weighted sum) pairs)
+constexpr uint32_t kDeepReduceBuckets = 4096;
+
+template <int FINAL>
+__global__ __launch_bounds__(kDeepThreads) void msm_deep_sort(const uint32_t* __restrict__ src,
+                                                             const uint32_t* __restrict__ run_cnt,
+                                                             const uint32_t* __restrict__ run_loc,
+                                                             const uint32_t* __restrict__ off2,
+                                                             const uint32_t* __restrict__ off3, uint32_t nblk,
+                                                             uint32_t G, uint32_t groups, uint32_t M, uint32_t low,
+                                                             uint32_t tile_words, size_t srs_n, size_t base_index,
+                                                             uint32_t* __restrict__ dst, uint32_t* __restrict__ cnt_out,
+                                                             uint32_t* __restrict__ loc_out) {
+  // FINAL: the key is (bucket within the bin, window pair) - up to 128 x 8 counters - so that every bucket's list comes
+  // out ordered by window: the lanes of msm_accumulate then walk the W n x 64 B table (14 GB at 2^24 points) two
+  // windows, ~2 GB, at a time instead of gathering across all of it.  (8 KiB of counters + the 64 KiB stage: two
+  // workgroups still fit a CU.)
+  constexpr uint32_t kKeys = FINAL ? 1024 : 128;
+  __shared__ uint32_t hist[kKeys];
+  __shared__ uint32_t start[kKeys];
+  __shared__ uint32_t run_pre[kDeepMaxRuns + 1];  // run lengths, then their inclusive prefix (run_pre[0] = 0)
+  __shared__ uint32_t run_src[kDeepMaxRuns];
+  __shared__ uint32_t stage[kDeepStage];
+  const uint32_t S = blockIdx.y, tid = threadIdx.x;
+  uint32_t R, nkeys, out_base;
+  if (FINAL == 0) {
+    const uint32_t t0 = blockIdx.x * G;
+    R = nblk - t0 < G ? nblk - t0 : G;
+    nkeys = M;
+    for (uint32_t r = tid; r < R; r += kDeepThreads) {
+      const size_t row = (size_t)S * nblk + t0 + r;
+      run_src[r] = (t0 + r) * tile_words + run_loc[row];
+      run_pre[r + 1] = run_cnt[row];
+    }
+    out_base = off2[(size_t)S * nblk + t0];
+  } else {
+    R = groups;
+    nkeys = 8u << low;
+    for (uint32_t g = tid; g < R; g += kDeepThreads) {
+      const size_t row = ((size_t)S * M + blockIdx.x) * groups + g;
+      run_src[g] = off2[(size_t)S * nblk + (size_t)g * G] + run_loc[row];
+      run_pre[g + 1] = run_cnt[row];
+    }
+    out_base = off3[((size_t)S * M + blockIdx.x) * groups];
+  }
+  for (uint32_t j = tid; j < kKeys; j += kDeepThreads) hist[j] = 0;
+  __syncthreads();
+  if (tid < 64) {  // inclusive prefix of the run lengths by one wave
+    const uint32_t per = (R + 63) / 64, j0 = tid * per;
+    uint32_t run = 0;
+    for (uint32_t t = 0; t < per && j0 + t < R; t++) run += run_pre[j0 + t + 1];
+    uint32_t inc = run;
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t o = __shfl_up(inc, d);
+      if ((int)tid >= d) inc += o;
+    }
+    uint32_t pre = inc - run;
+    for (uint32_t t = 0; t < per && j0 + t < R; t++) {
+      pre += run_pre[j0 + t + 1];
+      run_pre[j0 + t + 1] = pre;
+    }
+    if (tid == 0) run_pre[0] = 0;
+  }
+  __syncthreads();
+  const uint32_t cnt = run_pre[R];
+  // p-th entry of the gathered runs -> (entry for the next level, its sort key)
+  auto find_run = [&](uint32_t p) -> uint32_t {
+    uint32_t lo = 0, hi = R;
+    while (hi - lo > 1) {
+      const uint32_t mid = (lo + hi) >> 1;
+      if (run_pre[mid] <= p) lo = mid;
+      else hi = mid;
+    }
+    return lo;
+  };
+  auto fetch_in = [&](uint32_t p, uint32_t lo, uint32_t& key) -> uint32_t {  // entry p, known to lie in run lo
+    const uint32_t v = src[run_src[lo] + (p - run_pre[lo])];
+    if (FINAL == 0) {
+      key = (v >> (14 + low)) & (M - 1);
+      // the mid bits are spent; the entry keeps its low key bits and now names its tile within the group
+      return (v & (0x80003FFFu | (((1u << low) - 1) << 14))) | (lo << 21);
+    }
+    key = (((v >> 14) & ((1u << low) - 1)) << 3) | ((v >> 11) & 7u);
+    const size_t tile = (size_t)lo * G + ((v >> 21) & 127u);
+    return (uint32_t)((size_t)((v >> 10) & 15u) * srs_n + base_index + tile * kDigitTile + (v & 1023u)) |
+           (v & 0x80000000u);
+  };
+  auto fetch = [&](uint32_t p, uint32_t& key) -> uint32_t { return fetch_in(p, find_run(p), key); };
+  constexpr int kPer = kDeepStage / kDeepThreads;
+  const uint32_t staged = cnt < kDeepStage ? cnt : kDeepStage;
+  uint32_t ev[kPer], keys[kPer / 2];  // 16-bit keys, two per register
+#pragma unroll
+  for (int i = 0; i < kPer / 2; i++) keys[i] = 0;
+  // a thread takes kPer CONSECUTIVE entries: one search for the run of the first, then a walk (the binary search per
+  // entry - 8 dependent LDS reads - was most of this kernel's time); a lane reads a 64-byte piece of a run
+  {
+    uint32_t run = tid * kPer < staged ? find_run(tid * kPer) : 0;
+#pragma unroll
+    for (int i = 0; i < kPer; i++) {
+      const uint32_t p = tid * kPer + i;
+      if (p < staged) {
+        while (run + 1 < R && run_pre[run + 1] <= p) run++;
+        uint32_t k;
+        ev[i] = fetch_in(p, run, k);
+        keys[i >> 1] |= k << (16 * (i & 1));
+        atomicAdd(&hist[k], 1u);
+      }
+    }
+  }
+  for (uint32_t p = kDeepStage + tid; p < cnt; p += kDeepThreads) {  // an oversized bin (skewed scalars): counted now,
+    uint32_t k;                                                       // fetched again for the placement
+    (void)fetch(p, k);
+    atomicAdd(&hist[k], 1u);
+  }
+  __syncthreads();
+  if (tid < 64) {  // exclusive scan of the counters by one wave (kKeys / 64 consecutive ones per lane)
+    constexpr uint32_t per = kKeys / 64;
+    uint32_t run = 0;
+#pragma unroll 4
+    for (uint32_t t = 0; t < per; t++) run += hist[tid * per + t];
+    uint32_t inc = run;
+    for (int d = 1; d < 64; d <<= 1) {
+      uint32_t o = __shfl_up(inc, d);
+      if ((int)tid >= d) inc += o;
+    }
+    uint32_t pre = inc - run;
+#pragma unroll 4
+    for (uint32_t t = 0; t < per; t++) {
+      start[tid * per + t] = pre;
+      pre += hist[tid * per + t];
+    }
+  }
+  __syncthreads();
+  if (FINAL == 0) {
+    if (tid < nkeys) {
+      const size_t row = ((size_t)S * M + tid) * groups + blockIdx.x;
+      cnt_out[row] = hist[tid];
+      loc_out[row] = start[tid];
+    }
+  } else if (tid < (1u << low)) {  // a bucket = its 8 consecutive (bucket, window pair) keys
+    const size_t gb = (((size_t)S * M + blockIdx.x) << low) + tid;
+    const uint32_t k0 = tid << 3;
+    cnt_out[gb] = (k0 + 8 < nkeys ? start[k0 + 8] : cnt) - start[k0];
+    loc_out[gb] = out_base + start[k0];
+  }
+  __syncthreads();  // start[] now serves as the placement cursor
+  uint32_t* out = dst + out_base;
+#pragma unroll
+  for (int i = 0; i < kPer; i++) {
+    if (tid * kPer + i < staged) {
+      const uint32_t pos = atomicAdd(&start[(keys[i >> 1] >> (16 * (i & 1))) & 0xFFFFu], 1u);
+      if (pos < kDeepStage) stage[pos] = ev[i];
+      else out[pos] = ev[i];
+    }
+  }
+  for (uint32_t p = kDeepStage + tid; p < cnt; p += kDeepThreads) {
+    uint32_t k;
+    const uint32_t e = fetch(p, k);
+    const uint32_t pos = atomicAdd(&start[k], 1u);
+    if (pos < kDeepStage) stage[pos] = e;
+    else out[pos] = e;
+  }
+  __syncthreads();
+  for (uint32_t p = tid; p < staged; p += kDeepThreads) out[p] = stage[p];
 }
 
 // ---- K4: exclusive scan, one workgroup per batch entry ------------------------------------------
@@ -775,9 +989,12 @@ __device__ g1x mul_small(const g1x& p, uint32_t k) {
 // out (one Jacobian point per MSM) or, when the MSMs of the launch are parts of longer ones, out_part (XYZZ, summed by
 // msm_sum_parts)
 // (312 VGPRs, one wave per SIMD; forcing two - 256 VGPRs, 343 spilled - was measured: 1.56 -> 1.46 ms per step, not adopted)
+// out_pair (deep plan): the entry's buckets are a slice of one larger bucket set, so the plain sum of its buckets is
+// wanted beside the weighted one: out_pair[2 b] = sum_j B_j, out_pair[2 b + 1] = sum_j (j + 1) B_j - the (S, T) pair of
+// a segment one level up, folded by one more launch of this kernel.
 __global__ __launch_bounds__(64) void msm_reduce_final(const g1_xyzz* __restrict__ seg_pts, uint32_t seg_len,
                                                        uint32_t nseg, g1_jac* __restrict__ out,
-                                                       g1_xyzz* __restrict__ out_part) {
+                                                       g1_xyzz* __restrict__ out_part, g1_xyzz* __restrict__ out_pair) {
   const uint32_t b = blockIdx.x, lane = threadIdx.x;
   const uint32_t q = (nseg + 63) / 64;
   const uint32_t s_lo = lane * q;
@@ -797,14 +1014,21 @@ __global__ __launch_bounds__(64) void msm_reduce_final(const g1_xyzz* __restrict
     g1x o = shfl_down_pt(suf, d);
     if (lane + d < 64) add_tree<G1S>(suf, o);
   }
+  const g1x all = suf;  // lane 0: the sum of every segment
   if (lane == 0) suf = G1S::inf();
   // per lane: A + seg_len * (T + q * suf); their sum over the wave is the result
   g1x r = G1S::add(T, mul_small<G1S>(suf, q));
   r = G1S::add(mul_small<G1S>(r, seg_len), A);
   r = wave_sum<G1S>(r);
   if (lane == 0) {
-    if (out_part) out_part[b] = G1S::store(r);
-    else out[b] = G1S::to_jac_ext(r);
+    if (out_pair) {
+      out_pair[2 * (size_t)b] = G1S::store(all);
+      out_pair[2 * (size_t)b + 1] = G1S::store(r);
+    } else if (out_part) {
+      out_part[b] = G1S::store(r);
+    } else {
+      out[b] = G1S::to_jac_ext(r);
+    }
   }
 }
 
@@ -856,8 +1080,9 @@ __global__ __launch_bounds__(kThreads) void msm_combine(const g1_xyzz* __restric
 // + 6 shuffle + 2 cross-wave.  (512 threads - a chain of 4 + 6 + 3 - were measured slower, 0.93 against 0.79 ms over a
 // single proof's four launches: two waves of this code on a SIMD run at little more than the speed of one.)
 constexpr int kReduceThreads = 256;
+// planes = c, or c + 1: plane c is then the plain sum of the chunk's buckets (deep plan, see msm_reduce_final)
 __global__ __launch_bounds__(kReduceThreads) void msm_reduce_bits(const g1_xyzz* __restrict__ buckets, uint32_t half,
-                                                                  uint32_t c, uint32_t chunks,
+                                                                  uint32_t c, uint32_t planes, uint32_t chunks,
                                                                   g1_xyzz* __restrict__ partial) {
   constexpr int kWaves = kReduceThreads / 64;
   __shared__ g1_xyzz sh[kWaves];
@@ -867,11 +1092,19 @@ __global__ __launch_bounds__(kReduceThreads) void msm_reduce_bits(const g1_xyzz*
   // enumerate only the weights v = j + 1 in [1, half] that have `bit` set: v = idx with a 1 inserted at `bit`
   // (every lane does useful work; a predicate on j would leave half the lanes idle for the low bits); the chunk owns
   // the indices [chunk * per_chunk, (chunk + 1) * per_chunk) of the half / 2 such weights
-  const uint32_t per_chunk = (half / 2 + chunks - 1) / chunks;
-  for (uint32_t q = threadIdx.x; q < per_chunk; q += kReduceThreads) {
-    const uint32_t idx = chunk * per_chunk + q;
-    const uint32_t v = ((idx >> bit) << (bit + 1)) | (1u << bit) | (idx & ((1u << bit) - 1));
-    if (idx < half / 2 && v <= half) add_tree<G1L>(acc, G1L::load(bk[v - 1]));  // (the top plane holds v = half only)
+  if (bit >= c) {
+    const uint32_t per_all = (half + chunks - 1) / chunks;
+    for (uint32_t q = threadIdx.x; q < per_all; q += kReduceThreads) {
+      const uint32_t j = chunk * per_all + q;
+      if (j < half) add_tree<G1L>(acc, G1L::load(bk[j]));
+    }
+  } else {
+    const uint32_t per_chunk = (half / 2 + chunks - 1) / chunks;
+    for (uint32_t q = threadIdx.x; q < per_chunk; q += kReduceThreads) {
+      const uint32_t idx = chunk * per_chunk + q;
+      const uint32_t v = ((idx >> bit) << (bit + 1)) | (1u << bit) | (idx & ((1u << bit) - 1));
+      if (idx < half / 2 && v <= half) add_tree<G1L>(acc, G1L::load(bk[v - 1]));  // (the top plane holds v = half only)
+    }
   }
   const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   for (int d = 32; d >= 1; d >>= 1) {
@@ -886,7 +1119,7 @@ __global__ __launch_bounds__(kReduceThreads) void msm_reduce_bits(const g1_xyzz*
       g1x o = shfl_down_pt(r, d);
       if (lane < (uint32_t)d) add_tree<G1L>(r, o);
     }
-    if (lane == 0) partial[((size_t)b * c + bit) * chunks + chunk] = G1L::store(r);
+    if (lane == 0) partial[((size_t)b * planes + bit) * chunks + chunk] = G1L::store(r);
   }
 }
 
@@ -895,12 +1128,13 @@ __global__ __launch_bounds__(kReduceThreads) void msm_reduce_bits(const g1_xyzz*
 // 16-lane shuffle tree folds the chunks of each plane (planes never straddle a wave: four of them per wave), then the
 // first wave has T_bit in lane `bit`, doubles it `bit` times and adds the planes up.  c <= 16, chunks <= 16.
 __global__ __launch_bounds__(256) void msm_reduce_bits_final(const g1_xyzz* __restrict__ partial, uint32_t c,
-                                                        uint32_t chunks, g1_jac* __restrict__ out,
-                                                        g1_xyzz* __restrict__ out_part) {
+                                                        uint32_t nplanes, uint32_t chunks, g1_jac* __restrict__ out,
+                                                        g1_xyzz* __restrict__ out_part,
+                                                        g1_xyzz* __restrict__ out_pair) {
   __shared__ g1_xyzz planes[16];
   const uint32_t b = blockIdx.x, t = threadIdx.x, bit = t >> 4, k = t & 15;
   g1x acc = G1S::inf();
-  if (bit < c && k < chunks) acc = G1S::load(partial[((size_t)b * c + bit) * chunks + k]);
+  if (bit < nplanes && k < chunks) acc = G1S::load(partial[((size_t)b * nplanes + bit) * chunks + k]);
   for (int d = 8; d >= 1; d >>= 1) {
     g1x o = shfl_down_pt(acc, d);
     if (k < (uint32_t)d && k + d < chunks) add_tree<G1S>(acc, o);
@@ -919,8 +1153,14 @@ __global__ __launch_bounds__(256) void msm_reduce_bits_final(const g1_xyzz* __re
     if (lane < (uint32_t)d) add_tree<G1S>(acc, o);  // see wave_sum
   }
   if (lane == 0) {
-    if (out_part) out_part[b] = G1S::store(acc);
-    else out[b] = G1S::to_jac_ext(acc);
+    if (out_pair) {
+      out_pair[2 * (size_t)b] = planes[c];  // the plain-sum plane
+      out_pair[2 * (size_t)b + 1] = G1S::store(acc);
+    } else if (out_part) {
+      out_part[b] = G1S::store(acc);
+    } else {
+      out[b] = G1S::to_jac_ext(acc);
+    }
   }
 }
 
@@ -977,7 +1217,62 @@ struct Plan {
   const g1_affine* ext;
   uint32_t parts;
   size_t n_sub;
+  // deep plan (one long MSM on one bucket set of 2^(c-1) buckets, three-level sort): key bits = top + mid + low,
+  // tiles are gathered in groups of G
+  bool deep = false;
+  uint32_t top = 0, mid = 0, low = 0, G = 0, groups = 0;
 };
+// The third table's window size for an SRS of n points.  Not every c is usable: the top window holds only
+// 254 - c (W - 1) bits, and when those are few, all n of its digits fall into a handful of buckets (c = 18: 2 bits - four
+// buckets of n / 4 entries each; c = 19: 7 bits; c = 21: 2; c = 22: 12).  c = 17 (16 of 17 bits, W = 15) and c = 20 (14 of
+// 20, W = 13) have nearly full top windows, like the c = 15 table (14 of 15).
+uint32_t deep_c(size_t n) {
+  if (const char* e = getenv("CAPGPU_MSM_DEEP_C")) {
+    const int x = atoi(e);
+    if (x >= 17 && x <= 22) return (uint32_t)x;  // (c = 16 has 17 windows: one more than the entry's window field holds)
+  }
+  return n < ((size_t)3 << 19) ? 17u : 20u;  // 1.5 M points: 13 digits + 2^19 buckets overtake 15 digits + 2^16 buckets
+}
+bool deep_enabled() {
+  const char* e = getenv("CAPGPU_MSM_DEEP");
+  return !e || atoi(e) != 0;
+}
+size_t deep_min_points() {  // shortest MSM that takes the deep plan
+  const char* e = getenv("CAPGPU_MSM_DEEP_MIN");
+  // measured (tools/gpu_msm_deep_ab.py): 2^20 points 2.83 ms deep against 2.55 ms as 128 sub-MSMs, 2^21 3.6 against 4.0
+  const long long x = e ? atoll(e) : (3ll << 19);
+  return (size_t)(x >= 4096 ? x : 4096);
+}
+size_t deep_min_density() {  // average entries per bucket below which a launch leaves the deep plan (tests: 0)
+  const char* e = getenv("CAPGPU_MSM_DEEP_DENSITY");
+  const long long x = e ? atoll(e) : 8;
+  return (size_t)(x >= 0 ? x : 8);
+}
+// fills the deep fields for an MSM of n points on the table (c, windows); false when the shape does not fit the sort
+bool deep_shape(Plan& pl, size_t n) {
+  const uint32_t K = pl.c - 1;
+  if (K < 14 || pl.windows > 16) return false;
+  // buckets per level-3 bin = 2^low: as many as keep an average bin inside the LDS stage
+  const size_t avg_bucket = std::max<size_t>(((size_t)pl.windows * n) >> K, 1);
+  pl.low = 7;
+  while (pl.low > 4 && (avg_bucket << pl.low) > 14000) pl.low--;
+  const uint32_t rest = K - pl.low;
+  pl.top = (rest + 1) / 2;
+  pl.mid = rest - pl.top;
+  if (pl.top > 7 || pl.mid > 7 || pl.mid + pl.low > 14) return false;
+  const size_t nblk = (n + kDigitTile - 1) / kDigitTile;
+  const size_t run1 = std::max<size_t>(((size_t)kDigitTile * pl.windows) >> pl.top, 1);
+  uint32_t G = 1;
+  while (G < 128 && (size_t)(2 * G) * run1 <= 14336) G *= 2;  // a group's gathered runs must fit the 16384-entry stage
+  pl.G = G;
+  pl.groups = (uint32_t)((nblk + G - 1) / G);
+  if (pl.groups > kDeepMaxRuns) return false;
+  pl.sub_bits = K - pl.top;
+  pl.deep = true;
+  pl.parts = 1;
+  pl.n_sub = n;
+  return true;
+}
 size_t split_target() {  // sub-MSMs a long MSM is cut into at least (when it has the points for it)
   static const size_t v = [] {
     const char* e = getenv("CAPGPU_MSM_SPLIT");
@@ -988,6 +1283,13 @@ size_t split_target() {  // sub-MSMs a long MSM is cut into at least (when it ha
 }
 Plan choose_plan(const MsmBases& bases, size_t n, uint32_t batch) {
   Plan pl{bases.c, bases.windows, 0, bases.ext, 1, n};
+  // one long MSM: the deep plan, as long as its buckets hold >= 8 entries on average (a short range of a long table
+  // would pay for 2^(c-1) bucket reductions it has no entries for)
+  if (bases.ext3 && batch == 1 && deep_enabled() && n >= deep_min_points() &&
+      n * bases.windows3 >= (deep_min_density() << (bases.c3 - 1))) {
+    Plan dp{bases.c3, bases.windows3, 0, bases.ext3, 1, n};
+    if (deep_shape(dp, n)) return dp;
+  }
   const bool primary_wide = bases.c >= 14;  // tables of more than 2^18 points hold the wide windows only
   if (primary_wide) {
     pl.sub_bits = pick_sub_bits(n, pl.c, pl.windows);
@@ -1032,13 +1334,13 @@ bool use_segment_reduce(uint32_t half, uint32_t batch) {
 uint32_t choose_item_len(size_t entries, size_t buckets) {
   static const size_t cap = [] {
     const char* e = getenv("CAPGPU_MSM_ITEM_MAX");
-    int x = e ? atoi(e) : (int)kMaxItemLen;
-    return (size_t)(x >= 8 && x <= (int)kMaxItemLen ? x : (int)kMaxItemLen);
+    int x = e ? atoi(e) : (int)kBatchItemCap;
+    return (size_t)(x >= 8 && x <= (int)kMaxItemLen ? x : (int)kBatchItemCap);
   }();
   static const size_t floor_len = [] {
     const char* e = getenv("CAPGPU_MSM_ITEM_MIN");
     int x = e ? atoi(e) : (int)kMinItemLen;
-    return (size_t)(x >= 4 && x <= (int)kMaxItemLen ? x : (int)kMinItemLen);
+    return (size_t)(x >= 4 && x <= (int)kBatchItemCap ? x : (int)kMinItemLen);
   }();
   // Small launches (a single proof's MSMs, single MSMs up to 2^18 points): one wave per SIMD already saturates it
   // (tools/ubench_lonewave.hip), and a SIMD that gets two waves takes twice as long - so the launch should be ONE wave
@@ -1098,9 +1400,56 @@ WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t sb, uint32_t
   L.total = o;
   return L;
 }
+// workspace of the deep plan (one MSM of n points)
+struct DeepLayout {
+  size_t counts, offsets, chunks /* = sorted, once level 2 has read the chunks */, mid_buf, table, off2, tloc, table2, off3,
+      tloc2, seg_tot, buckets, partial, pairs, item_off, item_base, totals, item_bucket, item_sub, item_pts, max_items, nblk,
+      entries, total;
+  uint32_t sbp, item_len;
+};
+DeepLayout deep_layout(const Plan& pl, size_t n) {
+  DeepLayout L{};
+  const uint32_t K = pl.c - 1;
+  const size_t nb = (size_t)1 << K;
+  L.sbp = (uint32_t)(nb / kDeepEntryBuckets);
+  L.nblk = (n + kDigitTile - 1) / kDigitTile;
+  L.entries = (size_t)kDigitTile * pl.windows * L.nblk;  // capacity of the tile chunks >= W n
+  L.item_len = deep_item_len(std::max<size_t>(((size_t)pl.windows * n) >> K, 1));
+  L.max_items = (size_t)pl.windows * n / L.item_len + nb;
+  const size_t rows1 = ((size_t)1 << pl.top) * L.nblk, rows2 = ((size_t)1 << (pl.top + pl.mid)) * pl.groups;
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    const size_t at = o;
+    o = align_up(o + bytes, 256);
+    return at;
+  };
+  L.counts = take(4 * nb);
+  L.offsets = take(4 * nb);
+  L.chunks = take(4 * L.entries);
+  L.mid_buf = take(4 * L.entries);
+  L.table = take(4 * rows1);
+  L.off2 = take(4 * rows1);
+  L.tloc = take(4 * rows1);
+  L.table2 = take(4 * rows2);
+  L.off3 = take(4 * rows2);
+  L.tloc2 = take(4 * rows2);
+  L.seg_tot = take(4 * ((std::max(rows1, rows2) + kScanSeg - 1) / kScanSeg + 1));
+  L.buckets = take(sizeof(g1_xyzz) * nb);
+  L.partial = take(sizeof(g1_xyzz) * (size_t)L.sbp * 2 * (kDeepEntryBuckets / kDeepSegLen));  // (S, T) per segment
+  L.pairs = take(sizeof(g1_xyzz) * 2 * (nb / kDeepReduceBuckets));
+  L.item_off = take(4 * nb);
+  L.item_base = take(4 * ((size_t)L.sbp + 1));
+  L.totals = take(4 * (size_t)L.sbp);
+  L.item_bucket = take(4 * L.max_items);
+  L.item_sub = take(4 * L.max_items);
+  L.item_pts = take(sizeof(g1_xyzz) * L.max_items);
+  L.total = o;
+  return L;
+}
 // MSMs of a launch that go through the kernels together: the [key][tile] tables must stay below 2^28 rows and every
 // per-launch counter within 32 bits; larger batches are run in slices
 uint32_t batch_slice(const Plan& pl, uint32_t batch) {
+  if (pl.deep) return 1;
   const size_t bins = ((size_t)1 << (pl.c - 1)) >> pl.sub_bits;
   const size_t nblk = (pl.n_sub + kDigitTile - 1) / kDigitTile;
   const size_t per_msm_rows = bins * std::max<size_t>(nblk, 1) * pl.parts;
@@ -1160,6 +1509,23 @@ int msm_precompute(MsmBases* out, const g1_affine* d_bases, size_t n, uint32_t c
     launch("msm_precompute_kernel", msm_precompute_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, out->ext2,
            d_bases, n, kWideC, w2);
   }
+  // the deep-window table for long single MSMs (tables of more than 2^18 points)
+  if (!getenv("CAPGPU_MSM_C") && deep_enabled() && n > ((size_t)1 << 18) && n >= deep_min_points()) {
+    const uint32_t c3 = deep_c(n), w3 = msm_num_windows(c3);
+    Plan probe{c3, w3, 0, nullptr, 1, n};
+    if ((size_t)w3 * n < ((size_t)1 << 31) && deep_shape(probe, n)) {
+      e = hipMalloc(&out->ext3, sizeof(g1_affine) * n * w3);
+      if (e != hipSuccess) {
+        (void)hipStreamSynchronize(stream);
+        msm_free_bases(out);
+        return (int)e;
+      }
+      out->c3 = c3;
+      out->windows3 = w3;
+      launch("msm_precompute_kernel", msm_precompute_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, out->ext3,
+             d_bases, n, c3, w3);
+    }
+  }
   return 0;  // launch failures are latched by launch() and reported by take_launch_error()
 }
 
@@ -1174,12 +1540,19 @@ void msm_free_bases(MsmBases* b) {
 size_t msm_workspace_bytes(const MsmBases& bases, size_t n, uint32_t batch) {
   if (n == 0 || batch == 0) return 256;
   Plan pl = choose_plan(bases, n, batch);
+  if (pl.deep) return deep_layout(pl, n).total;
   const uint32_t slice = batch_slice(pl, batch);
   return ws_layout(pl.c, pl.windows, pl.n_sub, slice * pl.parts, pl.sub_bits, pl.parts > 1).total;
 }
 
 const char* msm_plan_describe(const MsmBases& bases, size_t n, uint32_t batch, char* buf, size_t cap) {
   Plan pl = choose_plan(bases, n, batch);
+  if (pl.deep) {
+    snprintf(buf, cap,
+             "c=%u windows=%u sort=deep parts=1 n_sub=%zu slice=1 top=%u mid=%u low=%u group_tiles=%u groups=%u entries=%u",
+             pl.c, pl.windows, n, pl.top, pl.mid, pl.low, pl.G, pl.groups, (1u << (pl.c - 1)) / kDeepEntryBuckets);
+    return buf;
+  }
   int len = snprintf(buf, cap, "c=%u windows=%u sort=%s parts=%u n_sub=%zu slice=%u", pl.c, pl.windows,
                      pl.sub_bits ? "two-level" : "one-level", pl.parts, pl.n_sub, batch_slice(pl, batch));
   if (pl.sub_bits && len > 0 && (size_t)len < cap) snprintf(buf + len, cap - len, " bin_buckets=%u", 1u << pl.sub_bits);
@@ -1187,6 +1560,158 @@ const char* msm_plan_describe(const MsmBases& bases, size_t n, uint32_t batch, c
 }
 
 namespace {
+// K5 + K6 over `sb` batch entries of `half` buckets each: work items, accumulation, bucket reduction.  One result per
+// entry goes to out (Jacobian), out_part (XYZZ: parts of a longer MSM) or out_pair (XYZZ (sum, weighted sum): entries
+// that are slices of one bucket set).
+struct Tail {
+  const g1_affine* ext;
+  uint32_t *counts, *offsets, *sorted, *item_off, *item_base, *totals, *item_bucket, *item_sub;
+  g1_xyzz *item_pts, *buckets, *partial;
+  size_t per, max_items, entries;
+  uint32_t half, sb, item_len, planes /* bit planes of the log-depth reduction: log2(half) + 1 */;
+  uint32_t seg_len = 0;  // != 0: running-sum reduction with segments of this many buckets, whatever the launch size
+  // != 0 (with seg_len): the reduction sees the bucket array as entries of this many buckets - smaller than `half`, which
+  // sizes the length-sorted item lists - so that the one-wave finish of an entry is a short chain
+  uint32_t reduce_half = 0;
+};
+void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, hipStream_t stream) {
+  const uint32_t half = t.half, sb = t.sb, item_len = t.item_len;
+  const uint32_t seg_len = t.seg_len ? t.seg_len : reduce_seg_len(half);
+  const bool segments = t.seg_len != 0 || use_segment_reduce(half, sb);
+  const uint32_t total_buckets = half * sb;
+  launch("msm_scan_items", msm_scan<1>, dim3(sb), dim3(1024), 0, stream, (const uint32_t*)t.counts, t.item_off, half,
+         t.totals, item_len);
+  launch("msm_item_bases", msm_item_bases, dim3(1), dim3(1024), 0, stream, (const uint32_t*)t.totals, sb, t.item_base);
+  launch("msm_sort_items", msm_sort_items, dim3(sb), dim3(1024), 0, stream, (const uint32_t*)t.counts,
+         (const uint32_t*)t.item_base, half, item_len, t.item_bucket, t.item_sub);
+  if (t.max_items > 0) {
+    launch("msm_accumulate", msm_accumulate, dim3((unsigned)((t.max_items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
+           stream, t.ext, (const uint32_t*)t.sorted, (const uint32_t*)t.counts, (const uint32_t*)t.offsets,
+           (const uint32_t*)t.item_off, (const uint32_t*)t.item_base, (const uint32_t*)t.item_bucket,
+           (const uint32_t*)t.item_sub, t.per, half, sb, item_len, t.item_pts, t.buckets);
+  }
+  if (segments) {
+    launch("msm_combine", msm_combine, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0, stream,
+           (const g1_xyzz*)t.item_pts, (const uint32_t*)t.counts, (const uint32_t*)t.item_off,
+           (const uint32_t*)t.item_base, half, total_buckets, item_len, t.buckets);
+    const uint32_t rhalf = t.reduce_half ? t.reduce_half : half, rsb = total_buckets / rhalf;
+    const uint32_t rnseg = (rhalf + seg_len - 1) / seg_len;
+    launch("msm_reduce_segments", msm_reduce_segments, dim3((rnseg * rsb + kThreads - 1) / kThreads), dim3(kThreads), 0,
+           stream, (const g1_xyzz*)t.buckets, rhalf, seg_len, rnseg, rsb, t.partial);
+    launch("msm_reduce_final", msm_reduce_final, dim3(rsb), dim3(64), 0, stream, (const g1_xyzz*)t.partial, seg_len, rnseg,
+           out, out_part, out_pair);
+  } else {
+    // G lanes per bucket: the smallest power of two that holds a bucket's items with some room for the spread of the
+    // bucket sizes (a bucket with more items than lanes loops), so that the shuffle tree is no deeper than needed
+    const size_t avg_items = (t.entries / total_buckets + item_len - 1) / item_len;
+    const size_t want = avg_items * 3 / 2;
+    const uint32_t G = want <= 8 ? 8u : (want <= 16 ? 16u : (want <= 32 ? 32u : 64u));
+    auto kern = G == 8 ? msm_combine_wave<8>
+                       : (G == 16 ? msm_combine_wave<16> : (G == 32 ? msm_combine_wave<32> : msm_combine_wave<64>));
+    launch("msm_combine", kern, dim3((unsigned)(((size_t)total_buckets * G + kThreads - 1) / kThreads)), dim3(kThreads),
+           0, stream, (const g1_xyzz*)t.item_pts, (const uint32_t*)t.counts, (const uint32_t*)t.item_off,
+           (const uint32_t*)t.item_base, half, total_buckets, item_len, t.buckets);
+    const uint32_t nplanes = t.planes + (out_pair ? 1u : 0u);
+    const uint32_t chunks = reduce_chunks(half, nplanes, sb);
+    launch("msm_reduce_bits", msm_reduce_bits, dim3(chunks, nplanes, sb), dim3(kReduceThreads), 0, stream,
+           (const g1_xyzz*)t.buckets, half, t.planes, nplanes, chunks, t.partial);
+    launch("msm_reduce_bits_final", msm_reduce_bits_final, dim3(sb), dim3(256), 0, stream, (const g1_xyzz*)t.partial,
+           t.planes, nplanes, chunks, out, out_part, out_pair);
+  }
+}
+
+// one long MSM on the deep-window table (choose_plan): three-level sort, then the common tail over 2^(K-14) batch
+// entries of 16384 buckets, then one more msm_reduce_final over the entries' (sum, weighted sum) pairs
+int msm_run_deep(const MsmBases& bases, const Plan& pl, size_t offset, const fe* d_scalars, size_t n, int montgomery,
+                 g1_jac* d_out, void* ws, size_t ws_bytes, hipStream_t stream) {
+  const DeepLayout L = deep_layout(pl, n);
+  if (ws_bytes < L.total) return (int)hipErrorInvalidValue;
+  char* base = reinterpret_cast<char*>(ws);
+  auto u32 = [&](size_t off) { return reinterpret_cast<uint32_t*>(base + off); };
+  auto pts = [&](size_t off) { return reinterpret_cast<g1_xyzz*>(base + off); };
+  const uint32_t c = pl.c, W = pl.windows, K = c - 1, nblk = (uint32_t)L.nblk;
+  const uint32_t S1 = 1u << pl.top, M = 1u << pl.mid;
+  const uint32_t tile_words = kDigitTile * W;
+  uint32_t *table = u32(L.table), *off2 = u32(L.off2), *tloc = u32(L.tloc), *chunks = u32(L.chunks);
+  uint32_t *table2 = u32(L.table2), *off3 = u32(L.off3), *tloc2 = u32(L.tloc2), *mid_buf = u32(L.mid_buf);
+  uint32_t *counts = u32(L.counts), *offsets = u32(L.offsets), *seg_tot = u32(L.seg_tot);
+  uint32_t* sorted = chunks;  // level 3 writes where level 1 wrote: the tile chunks are dead once level 2 has read them
+  auto scan = [&](const uint32_t* in, uint32_t* out, size_t nbs) {
+    const uint32_t nb = (uint32_t)nbs;
+    if (nb <= 4 * kScanSeg) {
+      launch("msm_scan", msm_scan<0>, dim3(1), dim3(1024), 0, stream, in, out, nb, (uint32_t*)nullptr, 0u);
+      return;
+    }
+    const uint32_t ns = (nb + kScanSeg - 1) / kScanSeg;
+    launch("msm_scan_seg", msm_scan_seg, dim3(ns, 1), dim3(1024), 0, stream, in, out, nb, ns, seg_tot);
+    launch("msm_scan_tot", msm_scan_tot, dim3(1), dim3(1024), 0, stream, seg_tot, ns);
+    launch("msm_scan_add", msm_scan_add, dim3(ns, 1), dim3(1024), 0, stream, out, nb, ns, (const uint32_t*)seg_tot);
+  };
+  // level 1: tiles sorted by the top key bits
+  {
+    static std::atomic<uint64_t> attr_set{0};
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    if (!(attr_set.load() >> (dev & 63) & 1)) {
+      for (const void* f : {reinterpret_cast<const void*>(msm_digits_local<17, true>),
+                            reinterpret_cast<const void*>(msm_digits_local<18, true>),
+                            reinterpret_cast<const void*>(msm_digits_local<19, true>),
+                            reinterpret_cast<const void*>(msm_digits_local<20, true>),
+                            reinterpret_cast<const void*>(msm_digits_local<21, true>),
+                            reinterpret_cast<const void*>(msm_digits_local<22, true>)})
+        hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
+      attr_set.fetch_or(1ull << (dev & 63));
+    }
+    auto kern = c == 17   ? msm_digits_local<17, true>
+                : c == 18 ? msm_digits_local<18, true>
+                : c == 19 ? msm_digits_local<19, true>
+                : c == 20 ? msm_digits_local<20, true>
+                : c == 21 ? msm_digits_local<21, true>
+                          : msm_digits_local<22, true>;
+    const size_t lds_bytes = sizeof(uint32_t) * (2 * (size_t)S1 + (size_t)kDigitTile * W);
+    launch("msm_digits_local", kern, dim3(nblk), dim3(kDigitThreads), lds_bytes, stream, d_scalars, (size_t)0, 1u,
+           (size_t)0, n, n, 1u, montgomery, c, W, nblk, 1u, pl.sub_bits, table, tloc, chunks);
+  }
+  scan(table, off2, (size_t)S1 * nblk);
+  // level 2: (super-bin, group of tiles) sorted by the middle key bits, written back in super-bin-major order
+  launch("msm_deep_sort_mid", msm_deep_sort<0>, dim3(pl.groups, S1), dim3(kDeepThreads), 0, stream, (const uint32_t*)chunks,
+         (const uint32_t*)table, (const uint32_t*)tloc, (const uint32_t*)off2, (const uint32_t*)nullptr, nblk, pl.G,
+         pl.groups, M, pl.low, tile_words, bases.n, offset, mid_buf, table2, tloc2);
+  scan(table2, off3, (size_t)S1 * M * pl.groups);
+  // level 3: (super-bin, mid-bin) = 128 buckets sorted by the low key bits -> bucket lists, counts, offsets
+  launch("msm_deep_sort_low", msm_deep_sort<1>, dim3(M, S1), dim3(kDeepThreads), 0, stream, (const uint32_t*)mid_buf,
+         (const uint32_t*)table2, (const uint32_t*)tloc2, (const uint32_t*)off2, (const uint32_t*)off3, nblk, pl.G,
+         pl.groups, M, pl.low, tile_words, bases.n, offset, sorted, counts, offsets);
+  Tail t{};
+  t.ext = pl.ext;
+  t.counts = counts;
+  t.offsets = offsets;
+  t.sorted = sorted;
+  t.item_off = u32(L.item_off);
+  t.item_base = u32(L.item_base);
+  t.totals = u32(L.totals);
+  t.item_bucket = u32(L.item_bucket);
+  t.item_sub = u32(L.item_sub);
+  t.item_pts = pts(L.item_pts);
+  t.buckets = pts(L.buckets);
+  t.partial = pts(L.partial);
+  t.per = 0;  // offsets[] are positions in the one sorted array
+  t.max_items = L.max_items;
+  t.entries = (size_t)W * n;
+  t.half = kDeepEntryBuckets;
+  t.sb = L.sbp;
+  t.item_len = L.item_len;
+  t.planes = 15;  // (unused: the deep plan reduces by running sums)
+  t.seg_len = kDeepSegLen;
+  t.reduce_half = kDeepReduceBuckets;
+  g1_xyzz* pairs = pts(L.pairs);
+  run_tail(t, nullptr, nullptr, pairs, stream);
+  // reduction entry e holds buckets e * 4096 ..: total = sum_e T_e + 4096 * sum_e e * S_e
+  launch("msm_reduce_final", msm_reduce_final, dim3(1), dim3(64), 0, stream, (const g1_xyzz*)pairs, kDeepReduceBuckets,
+         (uint32_t)(((size_t)1 << K) / kDeepReduceBuckets), d_out, (g1_xyzz*)nullptr, (g1_xyzz*)nullptr);
+  return 0;
+}
+
 // one slice of a launch: `batch` MSMs, all kernels
 int msm_run_slice(const MsmBases& bases, const Plan& pl, size_t offset, const fe* d_scalars, size_t outer_stride,
                   uint32_t inner, size_t inner_stride, size_t n, uint32_t first, uint32_t batch, int montgomery,
@@ -1204,8 +1729,6 @@ int msm_run_slice(const MsmBases& bases, const Plan& pl, size_t offset, const fe
   g1_xyzz* partial = reinterpret_cast<g1_xyzz*>(base + L.partial);
   g1_xyzz* part_pts = parts > 1 ? reinterpret_cast<g1_xyzz*>(base + L.part_pts) : nullptr;
   const size_t per = (size_t)W * n_sub;
-  const uint32_t seg_len = reduce_seg_len(half), nseg = (half + seg_len - 1) / seg_len;
-  const uint32_t total_buckets = half * sb;
   // the scalars of MSM `first + b`: the addressing of msm_run with the slice's first MSM folded into the pointer
   // (slices start at multiples of `inner` or the launch has inner == 1 / a single slice)
   const fe* sc0 = d_scalars + (size_t)(first / inner) * outer_stride + (size_t)(first % inner) * inner_stride;
@@ -1243,7 +1766,8 @@ int msm_run_slice(const MsmBases& bases, const Plan& pl, size_t offset, const fe
       attr_set.fetch_or(1ull << (dev & 63));
     }
     auto digits_kernel = c == 13 ? msm_digits_local<13> : (c == 15 ? msm_digits_local<15> : msm_digits_local<0>);
-    launch("msm_digits_local", digits_kernel, dim3(nblk * ((sb + 7) / 8) * 8), dim3(kDigitThreads), lds_bytes, stream,
+    launch("msm_digits_local", digits_kernel, dim3(sb == 1 ? nblk : nblk * ((sb + 7) / 8) * 8), dim3(kDigitThreads),
+           lds_bytes, stream,
            sc0, outer_stride, inner, inner_stride, n, n_sub, parts, montgomery, c, W, nblk, sb, pl.sub_bits, table, tloc,
            chunk_buf);
     scan_counts(table, off2, bins * nblk);
@@ -1261,57 +1785,29 @@ int msm_run_slice(const MsmBases& bases, const Plan& pl, size_t offset, const fe
              per, bins, nblk, W, rows, bases.n, offset, n_sub, parts, sorted);
     }
   }
-  uint32_t* item_off = reinterpret_cast<uint32_t*>(base + L.item_off);
-  uint32_t* item_base = reinterpret_cast<uint32_t*>(base + L.item_base);
-  uint32_t* totals = reinterpret_cast<uint32_t*>(base + L.totals);
-  uint32_t* item_bucket = reinterpret_cast<uint32_t*>(base + L.item_bucket);
-  g1_xyzz* item_pts = reinterpret_cast<g1_xyzz*>(base + L.item_pts);
-  uint32_t* item_sub = reinterpret_cast<uint32_t*>(base + L.item_sub);
-  const uint32_t item_len = choose_item_len(per * sb, (size_t)half * sb);
-  launch("msm_scan_items", msm_scan<1>, dim3(sb), dim3(1024), 0, stream, (const uint32_t*)counts, item_off, half,
-         totals, item_len);
-  launch("msm_item_bases", msm_item_bases, dim3(1), dim3(1024), 0, stream, (const uint32_t*)totals, sb, item_base);
-  launch("msm_sort_items", msm_sort_items, dim3(sb), dim3(1024), 0, stream, (const uint32_t*)counts,
-         (const uint32_t*)item_base, half, item_len, item_bucket, item_sub);
-  if (L.max_items > 0) {
-    launch("msm_accumulate", msm_accumulate, dim3((unsigned)((L.max_items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-           stream, pl.ext, (const uint32_t*)sorted, (const uint32_t*)counts, (const uint32_t*)offsets,
-           (const uint32_t*)item_off, (const uint32_t*)item_base, (const uint32_t*)item_bucket,
-           (const uint32_t*)item_sub, per, half, sb, item_len, item_pts,
-           reinterpret_cast<g1_xyzz*>(base + L.buckets));
-  }
-  g1_xyzz* buckets = reinterpret_cast<g1_xyzz*>(base + L.buckets);
-  g1_jac* out = d_out + first;
-  if (use_segment_reduce(half, sb))
-    launch("msm_combine", msm_combine, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0, stream,
-           (const g1_xyzz*)item_pts, (const uint32_t*)counts, (const uint32_t*)item_off, (const uint32_t*)item_base, half,
-           total_buckets, item_len, buckets);
-  else {
-    // G lanes per bucket: the smallest power of two that holds a bucket's items with some room for the spread of the
-    // bucket sizes (a bucket with more items than lanes loops), so that the shuffle tree is no deeper than needed
-    const size_t avg_items = (per * sb / total_buckets + item_len - 1) / item_len;
-    const size_t want = avg_items * 3 / 2;
-    const uint32_t G = want <= 8 ? 8u : (want <= 16 ? 16u : (want <= 32 ? 32u : 64u));
-    auto kern = G == 8 ? msm_combine_wave<8>
-                       : (G == 16 ? msm_combine_wave<16> : (G == 32 ? msm_combine_wave<32> : msm_combine_wave<64>));
-    launch("msm_combine", kern, dim3((unsigned)(((size_t)total_buckets * G + kThreads - 1) / kThreads)), dim3(kThreads),
-           0, stream, (const g1_xyzz*)item_pts, (const uint32_t*)counts, (const uint32_t*)item_off,
-           (const uint32_t*)item_base, half, total_buckets, item_len, buckets);
-  }
-  if (use_segment_reduce(half, sb)) {
-    launch("msm_reduce_segments", msm_reduce_segments, dim3((nseg * sb + kThreads - 1) / kThreads), dim3(kThreads), 0,
-           stream, (const g1_xyzz*)buckets, half, seg_len, nseg, sb, partial);
-    launch("msm_reduce_final", msm_reduce_final, dim3(sb), dim3(64), 0, stream, (const g1_xyzz*)partial, seg_len, nseg,
-           out, part_pts);
-  } else {
-    const uint32_t chunks = reduce_chunks(half, c, sb);
-    launch("msm_reduce_bits", msm_reduce_bits, dim3(chunks, c, sb), dim3(kReduceThreads), 0, stream, (const g1_xyzz*)buckets,
-           half, c, chunks, partial);
-    launch("msm_reduce_bits_final", msm_reduce_bits_final, dim3(sb), dim3(256), 0, stream, (const g1_xyzz*)partial, c,
-           chunks, out, part_pts);
-  }
+  Tail t{};
+  t.ext = pl.ext;
+  t.counts = counts;
+  t.offsets = offsets;
+  t.sorted = sorted;
+  t.item_off = reinterpret_cast<uint32_t*>(base + L.item_off);
+  t.item_base = reinterpret_cast<uint32_t*>(base + L.item_base);
+  t.totals = reinterpret_cast<uint32_t*>(base + L.totals);
+  t.item_bucket = reinterpret_cast<uint32_t*>(base + L.item_bucket);
+  t.item_sub = reinterpret_cast<uint32_t*>(base + L.item_sub);
+  t.item_pts = reinterpret_cast<g1_xyzz*>(base + L.item_pts);
+  t.buckets = reinterpret_cast<g1_xyzz*>(base + L.buckets);
+  t.partial = partial;
+  t.per = per;
+  t.max_items = L.max_items;
+  t.entries = per * sb;
+  t.half = half;
+  t.sb = sb;
+  t.item_len = choose_item_len(per * sb, (size_t)half * sb);
+  t.planes = c;
+  run_tail(t, d_out + first, part_pts, nullptr, stream);
   if (parts > 1)
-    launch("msm_sum_parts", msm_sum_parts, dim3(batch), dim3(64), 0, stream, (const g1_xyzz*)part_pts, parts, out);
+    launch("msm_sum_parts", msm_sum_parts, dim3(batch), dim3(64), 0, stream, (const g1_xyzz*)part_pts, parts, d_out + first);
   return 0;  // launch failures are latched by launch() and reported by take_launch_error()
 }
 }  // namespace
@@ -1327,6 +1823,7 @@ int msm_run(const MsmBases& bases, size_t offset, const fe* d_scalars, size_t ou
     return 0;  // launch failures are latched by launch() and reported by take_launch_error()
   }
   const Plan pl = choose_plan(bases, n, batch);
+  if (pl.deep) return msm_run_deep(bases, pl, offset, d_scalars, n, montgomery, d_out, ws, ws_bytes, stream);
   uint32_t slice = batch_slice(pl, batch);
   if (slice < batch && inner > 1) slice = slice >= inner ? slice / inner * inner : 0;  // slices start on an `inner` boundary
   if (slice == 0) return (int)hipErrorInvalidValue;

@@ -73,6 +73,15 @@ def test_msm_plans_of_the_baseline_sizes(cg, tau):
     assert (p["c"], p["sort"], p["parts"], p["n_sub"]) == (15, "two-level", 64, 8192)    # no part below 8192 points
     assert cg.msm_plan(h, 100, 1)["parts"] == 1
     cg.srs_free(h)
+    # BASELINE config 5 and its neighbours: ONE bucket set on the deep-window table (c = 20: 13 digits per scalar instead
+    # of the 17 of the c = 15 table), three-level sort; 2^20 points stay a batch of sub-MSMs (measured faster there)
+    h = cg.srs_generate_affine_seq(A_SEQ, B_SEQ, 1 << 22)
+    p = cg.msm_plan(h, 1 << 22, 1)
+    assert (p["c"], p["windows"], p["sort"], p["top"], p["mid"], p["low"]) == (20, 13, "deep", 6, 6, 7), p
+    p = cg.msm_plan(h, 1 << 20, 1)                        # a short range of the long table: back to sub-MSMs
+    assert (p["c"], p["sort"], p["parts"]) == (15, "two-level", 128), p
+    assert cg.msm_plan(h, 1 << 22, 2)["sort"] == "two-level"          # batches of long MSMs: sub-MSMs as before
+    cg.srs_free(h)
 
 
 def test_msm_random_configurations_known_tau(cg, tau):
@@ -117,6 +126,61 @@ def test_single_msm_2p20_skewed_scalars(cg):
     s = (A_SEQ * n + B_SEQ * (n * (n - 1) // 2)) % bn.R
     assert got == bn.g1_mul(bn.G1_GEN, k * s % bn.R)
     cg.srs_free(h)
+
+
+def test_deep_plan_skewed_scalars_2p21(cg):
+    """The deep plan's worst case: all scalars equal - each of the 13 windows sends its 2^21 entries into ONE bucket, so
+    every level of the three-level sort meets bins far beyond its LDS stage and the bucket is cut into thousands of work
+    items.  Then a mix: half the scalars tiny (their upper windows are empty, window 0 is crowded)."""
+    n = 1 << 21
+    h = cg.srs_generate_affine_seq(A_SEQ, B_SEQ, n)
+    assert cg.msm_plan(h, n, 1)["sort"] == "deep"
+    k = 0x1F2E3D4C5B6A79880123456789ABCDEF0FEDCBA9876543210011223344556677 % bn.R
+    sc = np.tile(cr.int_to_limbs(k), (n, 1))
+    got = cr.affine_to_ints(cr.g1_to_affine(cg.msm_g1(h, sc)))
+    s = (A_SEQ * n + B_SEQ * (n * (n - 1) // 2)) % bn.R
+    assert got == bn.g1_mul(bn.G1_GEN, k * s % bn.R)
+    sc = bu.random_canonical_scalars(211, n)
+    sc[::2, 1:] = 0                                      # every other scalar below 2^64
+    sc[::2, 0] &= np.uint64(0xFFFF)                      # ... in fact below 2^16
+    assert cr.affine_to_ints(cr.g1_to_affine(cg.msm_g1(h, sc))) == expected_affine_seq(sc)
+    cg.srs_free(h)
+
+
+@pytest.mark.parametrize("c3", [17, 18, 20, 22])
+def test_deep_plan_at_small_sizes_against_the_c_oracle(cg, tau, c3):
+    """The deep plan forced onto a table just above 2^18 points (CAPGPU_MSM_DEEP_MIN / _DEEP_C are read when the SRS is
+    built and when a launch is planned), so that it can be checked against the CPU restatement's Pippenger and the
+    known-tau identity on every window size the code instantiates - ragged sizes, a base offset, Montgomery-form
+    scalars, 0 / 1 / r - 1 among them, and the window sizes whose top window crowds a few buckets (c = 18: four of them)."""
+    import os
+    n_srs = (1 << 18) + 777
+    os.environ["CAPGPU_MSM_DEEP_MIN"] = "4096"
+    os.environ["CAPGPU_MSM_DEEP_DENSITY"] = "0"           # however few entries a bucket gets
+    os.environ["CAPGPU_MSM_DEEP_C"] = str(c3)
+    try:
+        h = cg.srs_generate(tau, n_srs)
+        for n, off in ((n_srs, 0), (200_001, 12_345), (70_000, 1)):
+            plan = cg.msm_plan(h, n, 1)
+            assert (plan["sort"], plan["c"]) == ("deep", c3), plan
+            sc = bu.random_canonical_scalars(c3 * 1000 + n % 1000, n)
+            sc[0] = 0
+            sc[1] = cr.int_to_limbs(1)
+            sc[2] = cr.int_to_limbs(bn.R - 1)
+            got = cr.affine_to_ints(cr.g1_to_affine(cg.msm_g1(h, sc, offset=off)))
+            f_tau = bn.from_mont(cr.poly_eval_fr(cr.vec_to_mont(1, sc), bn.to_mont(tau, bn.R)), bn.R)
+            assert got == bn.g1_mul(bn.G1_GEN, f_tau * pow(tau, off, bn.R) % bn.R), (c3, n, off, plan)
+            if n == 70_000:                               # and bit for bit against the C restatement's Pippenger
+                want = cr.g1_to_affine(cr.msm_g1(cg.srs_download(h, off, n), sc))
+                assert np.array_equal(cr.g1_to_affine(cg.msm_g1(h, sc, offset=off)), want)
+                d = cg.DevBuf.from_numpy(cr.vec_to_mont(1, sc))
+                out = cg.msm_g1_dev(h, d, n, montgomery=True, offset=off).to_numpy()
+                assert np.array_equal(cr.g1_to_affine(out), want)
+                d.free()
+        cg.srs_free(h)
+    finally:
+        for k in ("CAPGPU_MSM_DEEP_MIN", "CAPGPU_MSM_DEEP_DENSITY", "CAPGPU_MSM_DEEP_C"):
+            del os.environ[k]
 
 
 def test_msm_2p20_in_8_point_ranges_on_one_device(cg):
