@@ -12,9 +12,13 @@ proves its own batch (proofs are independent: replicas, no data-path collective)
 value = all proofs of all ranks / max-over-ranks time.
 
 Rank 0 prints ONE JSON line; see DESIGN.md "Measurement" for the definition of every field.  Secondary legs (each
-bounded, all outside the timed region of `value`): reference_schedule, n2p16, latency_ms_batch1, pcie_inclusive,
-cpu_baseline (+ all cores), msm (single 2^17, sharded 2^22 / 2^24 through the library's RCCL exchange), and - with
---workload mixed64 - BASELINE config 4 in both of its modes.
+bounded, all outside the timed region of `value`): reference_schedule, two_contexts_per_device, n2p16,
+latency_ms_batch1, pcie_inclusive, coalesced_single_calls, mixed64 (BASELINE config 4, short), cpu_baseline (+ 64 threads),
+msm (single MSMs of 2^17, 2^20, 2^22 and 2^24 points - configs 2 and 5; with N > 1 the 2^24 one sharded through the library's
+RCCL exchange), and - with --workload mixed64 - config 4 as the headline in both of its modes.
+
+    python bench.py --single-process --devices 0,1,2,3      ONE process driving several GPUs (capgpu_init(ids, n)): the
+                                                            reference's own process model; not what the driver launches
 """
 from __future__ import annotations
 
@@ -125,6 +129,96 @@ def msm_leg(cg, bu, torch, dist, rank, world, log_n, iters=5, coll_dev="cuda", u
             "sharding": how, "plan_per_rank": plan, "identity_check": ok}
 
 
+def single_process_main(args, json_fd):
+    """ONE process, several GPUs: capgpu_init(device_ids, n) binds them all, handles are process-wide, and a host thread
+    per device proves its own resident batch - the process model of the reference itself (one process, rayon threads,
+    src/utils/params_builder.rs:194-226).  The large-MSM leg runs on an SRS the library sharded by point range over the
+    devices at creation: one capgpu_msm_g1_dev call, all devices, partials exchanged by peer copies."""
+    import threading
+    from cap_amd import bench_utils as bu
+    from cap_amd import lib as cg
+    devs = [int(x) for x in args.devices.split(",")] if args.devices else list(range(max(1, args.gpus)))
+    cg.init(devices=devs)
+    S = cg.device_count()
+    P, log_n, num_inputs = args.batch, args.log_n, 27
+    n = 1 << log_n
+    tau = bu.SplitMix64(0xCA9).field()
+    ext_msg = bytes(range(32))
+    srs = cg.srs_generate(tau, n + 3)
+    sc = bu.synthetic_circuit(log_n, num_inputs, seed=2 + log_n + num_inputs)
+    pk, _vk = cg.plonk_preprocess(srs, n, num_inputs, sc.selectors_mont(), sc.sigma_mont())
+    wit = [sc.witness(3 + i) for i in range(4)]
+    wires = np.stack([sc.wires_mont(wit[i % 4][0]) for i in range(P)])
+    pubs = np.stack([bu.to_mont_array(wit[i % 4][1]) for i in range(P)])
+    blind = np.stack([bu.to_mont_array(bu.blinders(7000 + i)) for i in range(P)])
+    res, errs = [None] * S, []
+    bar = threading.Barrier(S + 1)
+
+    def worker(i):
+        try:
+            cg.set_device(i)
+            buf = cg.DevBuf.from_numpy(wires)                       # this device's resident batch
+            for _ in range(max(1, args.warmup)):                    # (the first call copies key and SRS to the device)
+                cg.plonk_prove_batch_dev(pk, buf, pubs, blind, ext_msg, P)
+            bar.wait()
+            for _ in range(args.steps):
+                res[i] = cg.plonk_prove_batch_dev(pk, buf, pubs, blind, ext_msg, P)
+            bar.wait()
+            buf.free()
+        except Exception as e:                                      # noqa: BLE001
+            errs.append(str(e))
+            bar.abort()
+
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(S)]
+    for t in th:
+        t.start()
+    bar.wait()
+    t0 = time.perf_counter()
+    bar.wait()
+    dt = time.perf_counter() - t0
+    for t in th:
+        t.join()
+    if errs:
+        raise RuntimeError(errs[0])
+    same = all([bytes(p) for p in r] == [bytes(p) for p in res[0]] for r in res)
+    out = {"metric": "transfer-note proofs/sec (2-in/2-out)", "value": S * P * args.steps / dt, "unit": "proofs/s",
+           "n_gpus": S, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "u32 limbs (254-bit Montgomery integers; 9 x 29-bit lazy limbs in the hot kernels)", "data": "synthetic",
+           "config": {"workload": f"full 2-in/2-out transfer-note PLONK proof, n=2^{log_n}, 27 public inputs, batch {P} "
+                                  "proofs/step/device, device-resident witness + key + SRS",
+                      "process_model": f"ONE process, {S} device contexts on HIP devices {devs}, one host thread per context",
+                      "parallelism": f"replicas x{S} (independent proofs)"},
+           "every_device_made_the_same_proofs": bool(same)}
+    if not args.no_msm:
+        log_m = args.msm_log_n if args.msm_log_n is not None else 24
+        nm = 1 << log_m
+        a, b = A_SEQ % bu.R, B_SEQ % bu.R
+        h = cg.srs_generate_affine_seq(a, b, nm)
+        scal = bu.random_canonical_scalars(5, nm)
+        d_sc, d_out = cg.DevBuf.from_numpy(scal), cg.DevBuf(96)
+        cg.msm_g1_dev(h, d_sc, nm, d_out=d_out)
+        cg.sync()
+        t0 = time.perf_counter()
+        iters = 3
+        for _ in range(iters):
+            cg.msm_g1_dev(h, d_sc, nm, d_out=d_out)
+        cg.sync()
+        ms = (time.perf_counter() - t0) / iters * 1e3
+        s0, s1 = bu.weighted_scalar_sums(scal, 0)
+        h1 = cg.srs_generate_affine_seq((a * s0 + b * s1) % bu.R, 0, 1)
+        rinv = pow(1 << 256, -1, P_FQ)
+        ex, ey = [v * rinv % P_FQ for v in _words_to_ints(cg.srs_download(h1, 0, 1))]
+        X, Y, Z = [v * rinv % P_FQ for v in _words_to_ints(d_out.to_numpy())]
+        zi = pow(Z, -1, P_FQ) if Z else 0
+        out["msm"] = [{"log_n": log_m, "points": nm, "ms": ms, "GBps_algorithmic": 96.0 * nm / ms / 1e6,
+                       "shards": cg.srs_shards(h), "plan": cg.msm_plan(h, nm, 1),
+                       "identity_check": bool(Z and (X * zi * zi % P_FQ, Y * zi * zi * zi % P_FQ) == (ex, ey)),
+                       "sharding": "SRS cut by point range over the process's device contexts at creation; scalar slices "
+                                   "and 96-byte partials travel by peer copies; one wavefront adds the partials"}]
+    os.write(json_fd, (json.dumps(out) + "\n").encode())
+
+
 def main():
     # stdout carries exactly ONE line, the JSON: whatever the libraries print on file descriptor 1 meanwhile (RCCL's
     # version banner, gloo's connection notes) is sent to stderr
@@ -149,9 +243,16 @@ def main():
                     help="nccl (= RCCL, the real multi-GPU path); gloo only to exercise the N>1 logic on a 1-GPU box "
                          "together with CAPGPU_BENCH_DEVICE=0")
     ap.add_argument("--no-msm", action="store_true")
+    ap.add_argument("--no-mixed", action="store_true", help="skip the short BASELINE config 4 leg of the default run")
+    ap.add_argument("--single-process", action="store_true",
+                    help="ONE process drives every GPU of --devices (capgpu_init with several ids): one host thread per "
+                         "device, each with its own resident batch; prints the same JSON line")
+    ap.add_argument("--devices", default=None, help="HIP device ids for --single-process, e.g. 0,1,2,3 (default: 0..gpus-1)")
     ap.add_argument("--msm-log-n", type=int, default=None,
-                    help="size of the sharded MSM leg (default: 22 on one GPU, 24 = BASELINE config 5 with N > 1)")
+                    help="size of the large (with N > 1: sharded) MSM leg (default 24 = BASELINE config 5)")
     args = ap.parse_args()
+    if args.single_process:
+        return single_process_main(args, json_fd)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -172,36 +273,32 @@ def main():
     from cap_amd import bench_utils as bu
     from cap_amd import lib as cg
 
+    # Two device contexts on the GPU (two streams, two locks): the headline and every leg below run on context 0, to
+    # which this thread binds itself; the second one serves the two_contexts_per_device leg and the coalescer.
+    os.environ.setdefault("CAPGPU_CONTEXTS_PER_DEVICE", "2")
     cg.init(local_rank)                       # raises (no fallback) when the HIP library / a gfx950 device is missing
+    n_ctx = cg.device_count()
+    cg.set_device(0)
     torch.cuda.set_device(local_rank)
     # the library's own RCCL communicator (the sharded-MSM exchange step lives inside the C ABI)
     lib_comm, lib_comm_error = False, None
-    comm_thread_stuck = False
     force_comm = os.environ.get("CAPGPU_BENCH_FORCE_LIB_COMM") == "1"   # test hook: try the bootstrap under gloo too
     if world > 1 and (args.dist_backend == "nccl" or force_comm):
-        import threading
         from cap_amd import parallel as par
-        box = {}
-
-        def _init():
-            try:
-                torch.cuda.set_device(local_rank)     # the current device is per thread
-                par.init_library_comm(cg, device=torch.device("cuda", local_rank) if coll_dev == "cuda" else None)
-                box["ok"] = True
-            except Exception as e:            # reported in the JSON line; the replica headline does not need it
-                box["err"] = str(e)
-
-        th = threading.Thread(target=_init, daemon=True)
-        th.start()
-        th.join(timeout=float(os.environ.get("CAPGPU_BENCH_COMM_TIMEOUT", "180")))   # never let a collective init hang the headline
-        if th.is_alive():
-            comm_thread_stuck = True
-            box["err"] = "capgpu_comm_init did not return in time"
-        mine = torch.tensor([1 if box.get("ok") else 0], device=coll_dev)
+        # capgpu_comm_init gives up by itself (CAPGPU_ERR_COMM) when a rank does not arrive in time
+        os.environ.setdefault("CAPGPU_COMM_TIMEOUT_MS", os.environ.get("CAPGPU_BENCH_COMM_TIMEOUT_MS", "120000"))
+        err = None
+        try:
+            par.init_library_comm(cg, device=torch.device("cuda", local_rank) if coll_dev == "cuda" else None)
+        except Exception as e:                # reported in the JSON line; the replica headline does not need it
+            err = str(e)
+        mine = torch.tensor([0 if err else 1], device=coll_dev)
         dist.all_reduce(mine, op=dist.ReduceOp.MIN)   # every rank takes the same path
         lib_comm = bool(mine.item() == 1)
         if not lib_comm:
-            lib_comm_error = box.get("err", "another rank failed to create the communicator")
+            lib_comm_error = err or "another rank failed to create the communicator"
+            if err is None:
+                cg.comm_destroy()
     P, log_n = args.batch, args.log_n
     n = 1 << log_n
     num_inputs = 27
@@ -382,7 +479,9 @@ def main():
         return ps[min(len(ps) - 1, int(q * len(ps)))] * 1e3
 
     out = {
-        "metric": "transfer-note proofs/sec (2-in/2-out)", "value": value, "unit": "proofs/s", "n_gpus": world,
+        "metric": "transfer-note proofs/sec (2-in/2-out)" if args.workload == "transfer"
+        else "mixed transfer/mint/freeze proofs/sec (64 per step, BASELINE config 4)",
+        "value": value, "unit": "proofs/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True,
         "scaling": "weak" if args.workload == "transfer" else "strong", "vs_baseline": None, "dtype": "u32 limbs (254-bit Montgomery integers; 9 x 29-bit lazy limbs in the hot kernels)", "data": "synthetic",
         "config": {"workload": (f"full 2-in/2-out transfer-note PLONK proof (13 MSM + 33 NTT), n=2^{log_n}, 27 public inputs, "
@@ -391,7 +490,10 @@ def main():
                         "19 freeze(3 inputs, n=2^15), one SRS, three keys, proof i on rank i mod N",
                    "domain_size": n, "batch_per_gpu": P, "parallelism": f"replicas x{world} (independent proofs)",
                    "pk_coset_cache": "18 fixed selector/sigma coset NTTs cached in the proving key (see "
-                                     "reference_schedule for the per-proof recompute number)"},
+                                     "reference_schedule for the per-proof recompute number)",
+                   "timed_region": "one device context, every kernel launch bracketed by HIP events (the roofline's "
+                                   "durations come from the timed steps themselves; costs a few microseconds per launch)",
+                   "device_contexts": n_ctx},
         "step_ms_this_rank": {"p10": pct(0.10), "p50": pct(0.50), "p90": pct(0.90), "min": ps[0] * 1e3, "max": ps[-1] * 1e3},
         "roofline": roofline,
         "alu_roofline": alu,
@@ -417,6 +519,77 @@ def main():
                                      "proof_identical_to_cached_mode": bool(same)}
         cg.plonk_free_key(pk_ref)
 
+    # ---- the same batch on TWO device contexts of the GPU (capgpu_init: CAPGPU_CONTEXTS_PER_DEVICE=2) ------------------
+    # two host threads, each bound to a context and proving half of the batch: the halves run on two streams, so one
+    # half's latency-bound launches and host transcript phases sit under the other half's issue-bound kernels
+    if world == 1 and args.workload == "transfer" and n_ctx >= 2 and P >= 2 and not args.no_extras:
+        import threading
+        halves = [(0, P // 2), (P // 2, P)]
+        res2, errs2 = [None, None], []
+        bar2 = threading.Barrier(3)
+        steps2 = args.steps
+
+        def _half(i):
+            try:
+                cg.set_device(i)
+                lo, hi = halves[i]
+                buf = cg.DevBuf.from_numpy(wires[lo:hi])
+                for _ in range(max(1, args.warmup)):
+                    cg.plonk_prove_batch_dev(pk, buf, pubs[lo:hi], blind[lo:hi], ext_msg, hi - lo)
+                bar2.wait()
+                for _ in range(steps2):
+                    res2[i] = cg.plonk_prove_batch_dev(pk, buf, pubs[lo:hi], blind[lo:hi], ext_msg, hi - lo)
+                bar2.wait()
+                buf.free()
+            except Exception as e:                                  # noqa: BLE001
+                errs2.append(str(e))
+                bar2.abort()
+
+        th2 = [threading.Thread(target=_half, args=(i,)) for i in range(2)]
+        for t in th2:
+            t.start()
+        try:
+            bar2.wait()
+            t0 = time.perf_counter()
+            bar2.wait()
+            dt2 = time.perf_counter() - t0
+        except threading.BrokenBarrierError:
+            dt2 = None
+        for t in th2:
+            t.join()
+        if dt2 and not errs2:
+            out["two_contexts_per_device"] = {
+                "proofs_per_s": P * steps2 / dt2, "ms_per_step": dt2 / steps2 * 1e3, "steps": steps2,
+                "same_proofs_as_the_headline": [bytes(p) for r in res2 for p in r] == [bytes(p) for p in proofs],
+                "note": f"the headline's {P} proofs per step as two concurrent device batches of {P // 2} on two contexts "
+                        "(streams) of the same GPU, one host thread each; unprofiled"}
+        else:
+            out["two_contexts_per_device"] = {"error": errs2[:2]}
+
+    # ---- BASELINE config 4, short: 64 mixed proofs per step on this GPU -----------------------------------------------
+    if world == 1 and args.workload == "transfer" and not args.no_mixed and not args.no_extras and log_n == 15:
+        t_m = time.time()
+        mixed_plan = [("transfer_2x3", 32), ("mint", 13), ("freeze_3", 19)]
+        mg = [make_group(k, bu.NOTE_SHAPES[k][0], bu.NOTE_SHAPES[k][1], c, 0, n_wit=3) for k, c in mixed_plan]
+        merged = merge_by_domain(mg)
+        m_steps = 3
+        dt_m, _, proofs_m, _ = timed(None, m_steps, 1, profile=False, grps=merged)
+        dt_mk, _, proofs_mk, _ = timed(None, m_steps, 1, profile=False, grps=mg)
+        out["mixed64"] = {
+            "one_batch_per_domain_proofs_per_s": 64 * m_steps / dt_m, "one_batch_per_key_proofs_per_s": 64 * m_steps / dt_mk,
+            "steps": m_steps, "same_proofs": sorted(bytes(p) for p in proofs_m) == sorted(bytes(p) for p in proofs_mk),
+            "setup_s": round(time.time() - t_m - dt_m - dt_mk, 1),
+            "note": "BASELINE config 4 on one GPU: 32 transfer(2-in/3-out, n=2^15) + 13 mint (n=2^14) + 19 freeze(3 inputs, "
+                    "n=2^15) per step, one SRS, three keys; per domain = the transfer and freeze proofs share ONE device "
+                    "batch (capgpu_plonk_prove_multi); `--workload mixed64` makes this the headline with more steps"}
+        for g in merged:
+            if g.get("multi"):
+                g["d_wires"].free()
+        for g in mg:
+            if "d_wires" in g:
+                g["d_wires"].free()
+            cg.plonk_free_key(g["pk"])
+
     # ---- bounded secondary measurements on one GPU -------------------------------------------------------
     if world == 1 and args.workload == "transfer" and not args.no_extras:
         # (1) one proof at a time: what the reference's criterion bench times (benches/transfer.rs:103-105)
@@ -436,6 +609,7 @@ def main():
                                             "additions on a few hundred waves"}
         d1.free()
         # (2) the boundary handing over HOST buffers: wires cross PCIe inside the timed region (never `value`)
+        cg.set_device(-1)                  # unbound, as a caller of the ABI is: the library deals the batch over its contexts
         for _ in range(1):
             cg.plonk_prove_batch(pk, wires, pubs, blind, ext_msg, P)
         torch.cuda.synchronize()
@@ -444,10 +618,12 @@ def main():
         for _ in range(reps):
             ph = cg.plonk_prove_batch(pk, wires, pubs, blind, ext_msg, P)
         dt_h = (time.perf_counter() - t0) / reps
+        cg.set_device(0)
         out["pcie_inclusive"] = {"proofs_per_s": P / dt_h, "ms_per_step": dt_h * 1e3,
-                                 "host_bytes_per_step": int(wires.nbytes),
+                                 "host_bytes_per_step": int(wires.nbytes), "device_contexts": n_ctx,
                                  "note": "capgpu_plonk_prove_batch: the 5 wire columns of every proof (5 n x 32 B) are copied "
-                                         "from pageable host memory inside the call, in chunks behind round 1's commitments"}
+                                         "from pageable host memory inside the call, in chunks behind round 1's commitments; "
+                                         "the library cuts the batch into one part per device context"}
         del ph
         # (2b) the reference's calling pattern: many host threads, ONE prove() per note each (rayon par_iter,
         # src/utils/params_builder.rs:194-226), served by the library's call coalescing
@@ -585,7 +761,8 @@ def main():
                                          "restatement of the arkworks/jf-plonk algorithm (reference schedule, no asm)",
                                "gpu_proof_bit_exact_vs_cpu": parity}
         out["speedup_vs_cpu_1core"] = value / (1.0 / t_cpu)
-        # all host cores: one proof per thread, the way the reference parallelises over notes (rayon par_iter,
+        # up to 64 host threads (of the box's logical cores; each proof holds ~0.3 GB of host memory, and the run is
+        # memory-bound well before that): one proof per thread, the way the reference parallelises over notes (rayon par_iter,
         # src/utils/params_builder.rs:194-226); the C prover is re-entrant and ctypes releases the GIL
         from concurrent.futures import ThreadPoolExecutor
         cores = max(1, min(os.cpu_count() or 1, 64))
@@ -594,22 +771,24 @@ def main():
         with ThreadPoolExecutor(cores) as ex:
             res = list(ex.map(lambda i: key.prove(wires[i % n_w], pubs[i % n_w], blind[i % n_w], ext_msg)[0], range(cores)))
         t_all = time.perf_counter() - t0
-        out["cpu_baseline_all_cores"] = {"value": cores / t_all, "unit": "proofs/s", "cores": cores, "kind": "port",
+        out["cpu_baseline_64_threads"] = {"value": cores / t_all, "unit": "proofs/s", "cores": cores, "kind": "port",
                                          "all_ok": bool(all(r == 0 for r in res)),
                                          "sample": f"{cores} proofs, one per thread on {os.cpu_count()} logical cores, {t_all:.1f} s "
                                                    "(the same single-thread C prover run concurrently, as the reference's "
                                                    "par_iter over notes does)"}
-        out["speedup_vs_cpu_all_cores"] = value / (cores / t_all)
+        out["speedup_vs_cpu_64_threads"] = value / (cores / t_all)
     # ---- MSM legs: BASELINE config 2 (2^17 points) on one GPU, and a point-range-sharded MSM over all ranks ------
     if not args.no_msm:
         legs = []
         try:
             if world == 1:
-                legs.append(msm_leg(cg, bu, torch, dist, rank, world, 17, coll_dev=coll_dev))
-                if args.msm_log_n is None:    # 2^20: 128 sub-MSMs of 8192 points, the sparsest buckets of any plan
+                legs.append(msm_leg(cg, bu, torch, dist, rank, world, 17, coll_dev=coll_dev))       # BASELINE config 2
+                if args.msm_log_n is None:    # 2^20: 128 sub-MSMs of 8192 points; 2^22: the deep-window plan
                     legs.append(msm_leg(cg, bu, torch, dist, rank, world, 20, coll_dev=coll_dev))
-            big = args.msm_log_n if args.msm_log_n is not None else (22 if world == 1 else 24)
-            legs.append(msm_leg(cg, bu, torch, dist, rank, world, big, coll_dev=coll_dev, use_lib_comm=lib_comm))
+                    legs.append(msm_leg(cg, bu, torch, dist, rank, world, 22, coll_dev=coll_dev))
+            big = args.msm_log_n if args.msm_log_n is not None else 24                              # BASELINE config 5
+            legs.append(msm_leg(cg, bu, torch, dist, rank, world, big, iters=3 if big >= 24 else 5, coll_dev=coll_dev,
+                                use_lib_comm=lib_comm))
         except Exception as e:                # a failed secondary leg must not lose the headline line
             legs.append({"error": str(e)})
         out["msm"] = legs
@@ -621,9 +800,9 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
-    if comm_thread_stuck:
+    if lib_comm_error:
         sys.stdout.flush()
-        os._exit(0)                           # a thread is still blocked inside RCCL: do not wait for it at exit
+        os._exit(0)                           # a helper thread may still be parked inside RCCL: do not wait for it at exit
 
 
 if __name__ == "__main__":
