@@ -363,8 +363,8 @@ int find_srs(uint64_t h, const MsmBases** out) {
     int rc = srs_record(h, &rec);
     if (rc) return rc;
     if (rec.sharded()) {
-      set_error("capgpu: SRS %llu is sharded by point range over the %zu devices of this process (MSM only)",
-                (unsigned long long)h, rec.shards.size());
+      set_error("capgpu: SRS %llu is sharded by point range over the devices of this process (MSM only)",
+                (unsigned long long)h);
       return CAPGPU_ERR_INVALID_ARG;
     }
     std::shared_ptr<SrsEntry> rep;
@@ -414,7 +414,17 @@ size_t shard_min_points() {
   long long x = e ? atoll(e) : (1ll << 20);
   return (size_t)(x >= 2 ? x : 2);
 }
-bool should_shard(size_t n) { return num_contexts() > 1 && n >= shard_min_points() && n >= num_contexts(); }
+// the contexts a sharded SRS is cut over: one per capgpu_init entry (extra contexts of a device share its shard's device)
+std::vector<size_t> shard_slots() {
+  std::vector<size_t> v;
+  for (auto& c : rt().ctxs)
+    if (c->primary) v.push_back((size_t)c->slot);
+  return v;
+}
+bool should_shard(size_t n) {
+  const size_t S = shard_slots().size();
+  return S > 1 && n >= shard_min_points() && n >= S;
+}
 // range of shard r of S over n points
 void shard_range(size_t n, size_t S, size_t r, size_t* lo, size_t* len) {
   const size_t base = n / S, rem = n % S;
@@ -422,14 +432,15 @@ void shard_range(size_t n, size_t S, size_t r, size_t* lo, size_t* len) {
   *len = base + (r < rem ? 1 : 0);
 }
 
-// runs job(r) for every context r on its own host thread, each thread placed on its context (the caller holds all
+// runs job(r) for the r-th shard context, each on its own host thread placed on that context (the caller holds all
 // context locks: AllEntries); returns the first failure and makes its message the caller's
 int for_each_context(const std::function<int(size_t)>& job) {
-  const size_t S = num_contexts();
+  const std::vector<size_t> slots = shard_slots();
+  const size_t S = slots.size();
   std::vector<int> rcs(S, CAPGPU_OK);
   std::vector<std::string> errs(S);
   auto body = [&](size_t r) {
-    ScopedCtx sc(*rt().ctxs[r]);
+    ScopedCtx sc(*rt().ctxs[slots[r]]);
     rcs[r] = job(r);
     if (rcs[r]) errs[r] = last_error();
   };
@@ -449,13 +460,16 @@ int for_each_context(const std::function<int(size_t)>& job) {
 uint64_t register_shards(std::vector<std::shared_ptr<SrsEntry>>& shards, size_t n) {
   Runtime& R = rt();
   const uint64_t h = R.next_handle.fetch_add(1);
+  const std::vector<size_t> slots = shard_slots();
+  std::vector<std::shared_ptr<SrsEntry>> by_slot(R.ctxs.size());
   for (size_t r = 0; r < shards.size(); r++) {
     shards[r]->is_shard = true;
-    R.ctxs[r]->srs[h] = shards[r];
+    R.ctxs[slots[r]]->srs[h] = shards[r];
+    by_slot[slots[r]] = shards[r];
   }
   std::lock_guard<std::mutex> lk(R.mu);
   SrsRecord rec;
-  rec.shards = shards;
+  rec.shards = by_slot;
   rec.total_n = n;
   R.srs[h] = rec;
   return h;
@@ -467,7 +481,8 @@ uint64_t register_shards(std::vector<std::shared_ptr<SrsEntry>>& shards, size_t 
 // SURVEY 8e) and one wavefront per MSM adds them up into d_out (on home).  The caller holds AllEntries and is on home.
 int msm_sharded(const SrsRecord& rec, Context& home, size_t offset, const uint64_t* h_scalars, const fe* d_scalars,
                 size_t stride, size_t n, int count, int montgomery, g1_jac* d_out) {
-  const size_t S = rec.shards.size();
+  const std::vector<size_t> slots = shard_slots();
+  const size_t S = slots.size();
   int rc = scratch_reserve(home.gather, sizeof(g1_jac) * S * (size_t)count);
   if (rc) return rc;
   g1_jac* gather = (g1_jac*)home.gather.p;
@@ -478,7 +493,8 @@ int msm_sharded(const SrsRecord& rec, Context& home, size_t offset, const uint64
   std::vector<hipEvent_t> done(S, nullptr);
   rc = for_each_context([&](size_t r) -> int {
     Context& c = ctx();
-    const SrsEntry& sh = *rec.shards[r];
+    if (!rec.shards[slots[r]]) return CAPGPU_OK;
+    const SrsEntry& sh = *rec.shards[slots[r]];
     const size_t lo = std::max(offset, sh.range_lo), hi = std::min(offset + n, sh.range_lo + sh.bases.n);
     if (lo >= hi) return CAPGPU_OK;
     const size_t len = hi - lo;
@@ -556,12 +572,16 @@ int capgpu_init(const int* device_ids, int n_devices) {
         return CAPGPU_ERR_INVALID_ARG;
       }
   }
+  std::vector<bool> secondary;  // the extra contexts of CAPGPU_CONTEXTS_PER_DEVICE: they share their device's tables
   {
     const char* pe = getenv("CAPGPU_CONTEXTS_PER_DEVICE");
     const int per = pe ? std::min(std::max(atoi(pe), 1), 8) : 1;
     std::vector<int> x;
     for (int d : ids)
-      for (int k = 0; k < per; k++) x.push_back(d);
+      for (int k = 0; k < per; k++) {
+        x.push_back(d);
+        secondary.push_back(k > 0);
+      }
     ids.swap(x);
   }
   if (ids.size() > 64) {
@@ -593,6 +613,7 @@ int capgpu_init(const int* device_ids, int n_devices) {
     std::unique_ptr<Context> c(new Context);
     c->slot = (int)i;
     c->device = dev;
+    c->primary = !secondary[i];
     he = hipStreamCreateWithFlags(&c->own_stream, hipStreamNonBlocking);
     if (he != hipSuccess) {
       undo();
@@ -765,7 +786,7 @@ int capgpu_srs_upload(const void* bases, size_t n, size_t stride_bytes, int coor
   };
   if (should_shard(n)) {
     AllEntries all;
-    const size_t S = num_contexts();
+    const size_t S = shard_slots().size();
     std::vector<std::shared_ptr<SrsEntry>> shards(S);
     int rc = for_each_context([&](size_t r) -> int {
       size_t lo, len;
@@ -828,7 +849,7 @@ static int srs_generate_common(int mode, const uint64_t a[4], const uint64_t b[4
   };
   if (should_shard(n)) {
     AllEntries all;
-    const size_t S = num_contexts();
+    const size_t S = shard_slots().size();
     std::vector<std::shared_ptr<SrsEntry>> shards(S);
     int rc = for_each_context([&](size_t r) -> int {
       size_t lo, len;
@@ -872,7 +893,12 @@ int capgpu_srs_shards(uint64_t handle, int* shards_out) {
   SrsRecord rec;
   int rc = srs_record(handle, &rec);
   if (rc) return rc;
-  if (shards_out) *shards_out = rec.sharded() ? (int)rec.shards.size() : 1;
+  int cnt = 1;
+  if (rec.sharded()) {
+    cnt = 0;
+    for (auto& sh : rec.shards) cnt += sh ? 1 : 0;
+  }
+  if (shards_out) *shards_out = cnt;
   return CAPGPU_OK;
 }
 
@@ -898,6 +924,7 @@ int capgpu_srs_download(uint64_t handle, size_t offset, size_t n, void* out) {
   g1_affine* pts = reinterpret_cast<g1_affine*>(out);
   if (rec.sharded()) {
     for (size_t r = 0; r < rec.shards.size(); r++) {
+      if (!rec.shards[r]) continue;
       const SrsEntry& sh = *rec.shards[r];
       const size_t lo = std::max(offset, sh.range_lo), hi = std::min(offset + n, sh.range_lo + sh.bases.n);
       if (lo >= hi) continue;
@@ -980,12 +1007,17 @@ int capgpu_msm_plan(uint64_t srs_handle, size_t n, int count, char* buf, size_t 
   int rc = srs_record(srs_handle, &rec);
   if (rc) return rc;
   if (!buf || cap == 0 || count < 1 || n > rec.total_n) return CAPGPU_ERR_INVALID_ARG;
-  if (rec.sharded()) {  // the plan of the largest shard's part, prefixed with the shard count
-    const SrsEntry& sh = *rec.shards[0];
-    int len = snprintf(buf, cap, "shards=%zu ", rec.shards.size());
+  if (rec.sharded()) {  // the plan of the first shard's part, prefixed with the shard count
+    size_t S = 0;
+    const SrsEntry* first = nullptr;
+    for (auto& sh : rec.shards)
+      if (sh) {
+        S++;
+        if (!first) first = sh.get();
+      }
+    int len = snprintf(buf, cap, "shards=%zu ", S);
     if (len > 0 && (size_t)len < cap)
-      msm_plan_describe(sh.bases, std::min(sh.bases.n, (n + rec.shards.size() - 1) / rec.shards.size()), (uint32_t)count,
-                        buf + len, cap - len);
+      msm_plan_describe(first->bases, std::min(first->bases.n, (n + S - 1) / S), (uint32_t)count, buf + len, cap - len);
     return CAPGPU_OK;
   }
   Context& c = ctx();

@@ -56,7 +56,7 @@ struct SrsEntry {
 // a logical SRS handle: one full table (replicated on demand), or one shard per context
 struct SrsRecord {
   std::shared_ptr<SrsEntry> full;                 // null when sharded
-  std::vector<std::shared_ptr<SrsEntry>> shards;  // [slot]; empty when not sharded
+  std::vector<std::shared_ptr<SrsEntry>> shards;  // [slot], null for contexts that hold none; empty when not sharded
   size_t total_n = 0;
   bool sharded() const { return !shards.empty(); }
 };
@@ -67,6 +67,7 @@ struct Context {
   bool initialised = false;
   int slot = 0;    // index in Runtime::ctxs
   int device = 0;  // HIP device id (two contexts may share a device: CAPGPU_CONTEXTS_PER_DEVICE)
+  bool primary = true;  // the first context of its capgpu_init entry: the ones a sharded SRS is cut over
   hipStream_t own_stream = nullptr;
   hipStream_t copy_stream = nullptr;  // H2D of host-resident witnesses (plonk.hip), created on first use
   hipStream_t stream = nullptr;  // the stream work is enqueued on (own_stream unless capgpu_set_stream)

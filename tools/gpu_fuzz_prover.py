@@ -1,5 +1,6 @@
-"""One-off differential fuzz of the device prover against the C restatement: random domain sizes, public-input counts,
-batch sizes, messages, single- and mixed-key batches.  python tools/gpu_fuzz_prover.py [rounds] [seed]"""
+"""Differential fuzz of the device prover against the C restatement: random domain sizes, public-input counts,
+batch sizes, messages, single- and mixed-key batches.  python tools/gpu_fuzz_prover.py [rounds] [seed] [big]
+(also run, bounded, by tests/test_gpu_fuzz.py)"""
 import random
 import sys
 
@@ -10,57 +11,70 @@ from cap_amd import lib as cg, bench_utils as bu  # noqa: E402
 from oracle import capref as cr  # noqa: E402  (checker)
 from tests import helpers as H  # noqa: E402
 
-rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
-rng = random.Random(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-cg.init(0)
-tau = bu.SplitMix64(77).field()
-bad = 0
-# "big" as third argument: shapes that cross the plan thresholds of the prover's MSM launches (narrow / wide tables at
-# 32 MSMs per launch, log-depth / running-sum reduction at 64 of them) instead of random ones
+# "big": shapes that cross the plan thresholds of the prover's MSM launches (narrow / wide tables at 32 MSMs per launch,
+# log-depth / running-sum reduction at 64 of them) instead of random ones
 BIG = [(12, 6), (12, 7), (12, 12), (12, 13), (12, 33), (13, 7), (13, 14), (11, 64), (14, 3)]
-big = len(sys.argv) > 3 and sys.argv[3] == "big"
-if big:
-    rounds = len(BIG)
-for r in range(rounds):
-    log_n = BIG[r][0] if big else rng.choice([4, 4, 5, 5, 6, 7, 8, 9, 10, 11, 12, 13])
-    n = 1 << log_n
-    srs = cg.srs_generate(tau, n + 3)
-    srs_host = cg.srs_download(srs, 0, n + 3)
-    nkeys = rng.choice([1, 1, 2, 3])
-    circuits, keys, ckeys = [], [], []
-    for k in range(nkeys):
-        ni = rng.randint(0, min(30, n // 2 - 1))
-        sc = bu.synthetic_circuit(log_n, ni, seed=rng.randint(1, 10 ** 6))
-        circuits.append(sc)
-        keys.append(cg.plonk_preprocess(srs, n, ni, sc.selectors_mont(), sc.sigma_mont())[0])
-        ckeys.append(cr.PlonkKey(srs_host, n, ni, sc.selectors_mont(), sc.sigma_mont()))
-    P = BIG[r][1] if big else (rng.choice([1, 2, 3, 5, 8, 13, 40]) if log_n <= 10 else rng.randint(1, 4))
-    order = [rng.randrange(nkeys) for _ in range(P)]
-    max_in = max(circuits[k].num_inputs for k in order)      # the row length follows the keys actually in the batch
-    wires, rows, blinds, msgs, exp = [], [], [], [], []
-    for i, k in enumerate(order):
-        sc = circuits[k]
-        w, pubs = sc.witness(rng.randint(1, 10 ** 6))
-        bl = bu.to_mont_array(bu.blinders(rng.randint(1, 10 ** 6)))
-        msg = bytes(rng.getrandbits(8) for _ in range(rng.choice([0, 1, 31, 32, 33, 100])))
-        row = np.zeros((max_in, 4), np.uint64)
-        pm = bu.to_mont_array(pubs) if pubs else np.zeros((0, 4), np.uint64)
-        row[:len(pubs)] = pm
-        wires.append(sc.wires_mont(w)); rows.append(row); blinds.append(bl); msgs.append(msg)
-        rc, comms, evals = ckeys[k].prove(sc.wires_mont(w), pm, bl, msg or None)
-        assert rc == 0
-        exp.append(H.cref_proof_points(comms, evals))
-    got = cg.plonk_prove_multi([keys[k] for k in order], np.stack(wires), np.stack(rows), np.stack(blinds), msgs)
-    ok = all(H.proof_points(got[i]) == exp[i] for i in range(P))
-    if nkeys == 1:
-        pm = np.stack(rows)[:, :circuits[0].num_inputs]
-        for i in range(P):        # the single-key entry point too (per-proof message)
-            one = cg.plonk_prove_batch(keys[0], wires[i][None], pm[i][None], blinds[i][None], msgs[i] or None, 1)[0]
-            ok = ok and H.proof_points(one) == exp[i]
-    print(f"round {r}: log_n={log_n} keys={nkeys} P={P} inputs={[c.num_inputs for c in circuits]} {'ok' if ok else 'MISMATCH'}")
-    bad += 0 if ok else 1
-    for k in keys:
-        cg.plonk_free_key(k)
-    cg.srs_free(srs)
-print("mismatches:", bad)
-sys.exit(1 if bad else 0)
+
+
+def run(rounds=30, seed=1, big=False, max_checked=None, log=print):
+    """returns the number of rounds with a mismatch.  max_checked: proofs per round compared with the C restatement
+    (None: all of them); the others are still compared across the two entry points."""
+    rng = random.Random(seed)
+    cg.init(0)
+    tau = bu.SplitMix64(77).field()
+    bad = 0
+    if big:
+        rounds = len(BIG)
+    for r in range(rounds):
+        log_n = BIG[r][0] if big else rng.choice([4, 4, 5, 5, 6, 7, 8, 9, 10, 11, 12, 13])
+        n = 1 << log_n
+        srs = cg.srs_generate(tau, n + 3)
+        srs_host = cg.srs_download(srs, 0, n + 3)
+        # (a C-side key costs 18 CPU MSMs: the threshold shapes keep to one or two keys)
+        nkeys = (1 if log_n >= 13 else rng.choice([1, 2])) if big else rng.choice([1, 1, 2, 3])
+        circuits, keys, ckeys = [], [], []
+        for k in range(nkeys):
+            ni = rng.randint(0, min(30, n // 2 - 1))
+            sc = bu.synthetic_circuit(log_n, ni, seed=rng.randint(1, 10 ** 6))
+            circuits.append(sc)
+            keys.append(cg.plonk_preprocess(srs, n, ni, sc.selectors_mont(), sc.sigma_mont())[0])
+            ckeys.append(cr.PlonkKey(srs_host, n, ni, sc.selectors_mont(), sc.sigma_mont()))
+        P = BIG[r][1] if big else (rng.choice([1, 2, 3, 5, 8, 13, 40]) if log_n <= 10 else rng.randint(1, 4))
+        order = [rng.randrange(nkeys) for _ in range(P)]
+        max_in = max(circuits[k].num_inputs for k in order)      # the row length follows the keys actually in the batch
+        checked = set(range(P)) if max_checked is None or P <= max_checked else \
+            {0, P - 1} | set(rng.sample(range(P), max_checked - 2))
+        wires, rows, blinds, msgs, exp = [], [], [], [], {}
+        for i, k in enumerate(order):
+            sc = circuits[k]
+            w, pubs = sc.witness(rng.randint(1, 10 ** 6))
+            bl = bu.to_mont_array(bu.blinders(rng.randint(1, 10 ** 6)))
+            msg = bytes(rng.getrandbits(8) for _ in range(rng.choice([0, 1, 31, 32, 33, 100])))
+            row = np.zeros((max_in, 4), np.uint64)
+            pm = bu.to_mont_array(pubs) if pubs else np.zeros((0, 4), np.uint64)
+            row[:len(pubs)] = pm
+            wires.append(sc.wires_mont(w)); rows.append(row); blinds.append(bl); msgs.append(msg)
+            if i in checked:
+                rc, comms, evals = ckeys[k].prove(sc.wires_mont(w), pm, bl, msg or None)
+                assert rc == 0
+                exp[i] = H.cref_proof_points(comms, evals)
+        got = cg.plonk_prove_multi([keys[k] for k in order], np.stack(wires), np.stack(rows), np.stack(blinds), msgs)
+        ok = all(H.proof_points(got[i]) == exp[i] for i in checked)
+        if nkeys == 1:
+            pm = np.stack(rows)[:, :circuits[0].num_inputs]
+            for i in range(P):        # the single-key entry point too (per-proof message)
+                one = cg.plonk_prove_batch(keys[0], wires[i][None], pm[i][None], blinds[i][None], msgs[i] or None, 1)[0]
+                ok = ok and bytes(one) == bytes(got[i])
+        log(f"round {r}: log_n={log_n} keys={nkeys} P={P} inputs={[c.num_inputs for c in circuits]} {'ok' if ok else 'MISMATCH'}")
+        bad += 0 if ok else 1
+        for k in keys:
+            cg.plonk_free_key(k)
+        cg.srs_free(srs)
+    return bad
+
+
+if __name__ == "__main__":
+    bad = run(int(sys.argv[1]) if len(sys.argv) > 1 else 30, int(sys.argv[2]) if len(sys.argv) > 2 else 1,
+              len(sys.argv) > 3 and sys.argv[3] == "big")
+    print("mismatches:", bad)
+    sys.exit(1 if bad else 0)
