@@ -257,6 +257,64 @@ __global__ __launch_bounds__(256) void ubench_mad_kernel(uint64_t* io, int iters
   io[i] = x;
 }
 
+
+// Issue rate of one VALU instruction class (capgpu_ubench_issue_rates): the same shape as ubench_mad_kernel - 8
+// independent dependency chains per lane, 8 waves per SIMD - so that the classes are compared at equal occupancy.
+//   0 v_mad_u64_u32   1 v_add_u32   2 v_and_b32   3 v_mov_b32   4 v_lshl_add_u64   5 v_lshrrev_b64   6 v_alignbit_b32
+//   7 v_mul_lo_u32
+template <int CLS>
+__global__ __launch_bounds__(256) void ubench_issue_kernel(uint64_t* io, int iters) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  uint64_t acc[8];
+  const uint32_t a = (uint32_t)io[i] | 1u, b = (uint32_t)(io[i] >> 32) | 1u;
+#pragma unroll
+  for (int c = 0; c < 8; c++) acc[c] = io[i] + c;
+  for (int k = 0; k < iters; k++) {
+#pragma unroll
+    for (int rep = 0; rep < 8; rep++)
+#pragma unroll
+      for (int c = 0; c < 8; c++) {
+        if constexpr (CLS == 0) {
+          uint64_t r, carry;
+          asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(a), "v"(b + c), "v"(acc[c]));
+          acc[c] = r;
+        } else if constexpr (CLS == 1) {
+          uint32_t r;
+          asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"((uint32_t)acc[c]));
+          acc[c] = r;
+        } else if constexpr (CLS == 2) {
+          uint32_t r;
+          asm volatile("v_and_b32 %0, %1, %2" : "=v"(r) : "v"(a), "v"((uint32_t)acc[c]));
+          acc[c] = r;
+        } else if constexpr (CLS == 3) {
+          uint32_t r;
+          asm volatile("v_mov_b32 %0, %1" : "=v"(r) : "v"((uint32_t)acc[c]));
+          acc[c] = r;
+        } else if constexpr (CLS == 4) {
+          uint64_t r;
+          asm volatile("v_lshl_add_u64 %0, %1, 1, %2" : "=v"(r) : "v"(acc[c]), "v"((uint64_t)a));
+          acc[c] = r;
+        } else if constexpr (CLS == 5) {
+          uint64_t r;
+          asm volatile("v_lshrrev_b64 %0, %1, %2" : "=v"(r) : "v"(b & 3u), "v"(acc[c]));
+          acc[c] = r;
+        } else if constexpr (CLS == 6) {
+          uint32_t r;
+          asm volatile("v_alignbit_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"((uint32_t)acc[c]), "v"(b & 31u));
+          acc[c] = r;
+        } else {
+          uint32_t r;
+          asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"((uint32_t)acc[c]));
+          acc[c] = r;
+        }
+      }
+  }
+  uint64_t x = 0;
+#pragma unroll
+  for (int c = 0; c < 8; c++) x ^= acc[c];
+  io[i] = x;
+}
+
 fe fe_from_u64x4(const uint64_t v[4]) {
   fe r;
   for (int i = 0; i < 4; i++) {
@@ -1185,6 +1243,45 @@ int capgpu_ubench_mad_rate(double* lane_ops_per_s_out) {
   hipEventDestroy(e1);
   *lane_ops_per_s_out = best;
   return take_launch_error();
+}
+
+int capgpu_ubench_issue_rates(double* rates_out, int count) {
+  CAP_CHECK_INIT();
+  if (!rates_out || count < 1) return CAPGPU_ERR_INVALID_ARG;
+  Context& c = ctx();
+  Entry lk(c);
+  hipDeviceProp_t prop;
+  CAP_HIP(hipGetDeviceProperties(&prop, c.device));
+  const int blocks = prop.multiProcessorCount * 8, iters = 1000;
+  DevTmp<uint64_t> d;
+  CAP_HIP(d.alloc((size_t)blocks * 256));
+  CAP_HIP(hipMemsetAsync(d, 0x5a, sizeof(uint64_t) * blocks * 256, c.stream));
+  hipEvent_t e0, e1;
+  CAP_HIP(hipEventCreate(&e0));
+  CAP_HIP(hipEventCreate(&e1));
+  using Kern = void (*)(uint64_t*, int);
+  const Kern kerns[8] = {ubench_issue_kernel<0>, ubench_issue_kernel<1>, ubench_issue_kernel<2>, ubench_issue_kernel<3>,
+                         ubench_issue_kernel<4>, ubench_issue_kernel<5>, ubench_issue_kernel<6>, ubench_issue_kernel<7>};
+  for (int k = 0; k < count && k < 8; k++) {
+    hipLaunchKernelGGL(kerns[k], dim3(blocks), dim3(256), 0, c.stream, d.p, 10);  // warm-up
+    double best = 0;
+    for (int rep = 0; rep < 3; rep++) {
+      hipEventRecord(e0, c.stream);
+      hipLaunchKernelGGL(kerns[k], dim3(blocks), dim3(256), 0, c.stream, d.p, iters);
+      hipEventRecord(e1, c.stream);
+      CAP_HIP(hipEventSynchronize(e1));
+      float ms = 0;
+      hipEventElapsedTime(&ms, e0, e1);
+      const double rate = (double)blocks * 256 * iters * 64 / (ms * 1e-3);
+      if (rate > best) best = rate;
+    }
+    rates_out[k] = best;
+  }
+  for (int k = 8; k < count; k++) rates_out[k] = 0;
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  (void)hipGetLastError();
+  return CAPGPU_OK;
 }
 
 // the profiler is per context (contexts launch concurrently); the ABI reports the sums over all of them

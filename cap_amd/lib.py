@@ -339,6 +339,17 @@ def ubench_mad_rate() -> float:
     return out.value
 
 
+ISSUE_CLASSES = ("v_mad_u64_u32", "v_add_u32", "v_and_b32", "v_mov_b32", "v_lshl_add_u64", "v_lshrrev_b64",
+                 "v_alignbit_b32", "v_mul_lo_u32")
+
+
+def ubench_issue_rates() -> dict:
+    """measured issue rate (lane-operations per second) of each instruction class, at equal occupancy"""
+    out = (ctypes.c_double * len(ISSUE_CLASSES))()
+    check(load().capgpu_ubench_issue_rates(out, len(ISSUE_CLASSES)))
+    return dict(zip(ISSUE_CLASSES, [float(v) for v in out]))
+
+
 def profile_enable(on: bool):
     check(load().capgpu_profile_enable(int(on)))
 

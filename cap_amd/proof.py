@@ -2,6 +2,7 @@
 
 Same names and argument meaning as `/root/reference/src/proof/`:
   universal_setup       src/proof/mod.rs:59-69     (SRS = powers of tau in G1; synthetic tau here)
+  load_srs              src/proof/mod.rs:74-109    (degree bound, SHA-256 integrity check, the whole CRS file loaded)
   preprocess            src/proof/transfer.rs:124-155, mint.rs:69-93, freeze.rs:93-121
   prove                 src/proof/transfer.rs:159-188, mint.rs:97-120, freeze.rs:125-158
   verify                src/proof/transfer.rs:192-212, mint.rs:124-140, freeze.rs:162-178
@@ -109,6 +110,28 @@ def universal_setup(max_degree: int, tau: int) -> UniversalSrs:
         return UniversalSrs(_lib.srs_generate(tau, max_degree + 1), max_degree, h, _lib.g2_mul(h, tau))
     except _lib.CapGpuError as e:
         raise TxnApiError.FailedSnark(f"Failed to generate universal SRS: {e}") from e
+
+
+# SHA-256 of data/aztec-crs-131072.bin as the reference pins it (src/proof/mod.rs:100)
+AZTEC_CRS_SHA256 = bytes.fromhex("6b81e75fb9c14fd0e58fb2b29e48978cdad5511503685a61f1391dc4a4fc7cbf")
+
+
+def load_srs(max_degree: int, crs_bytes: bytes, expected_sha256: bytes = AZTEC_CRS_SHA256) -> UniversalSrs:
+    """src/proof/mod.rs:74-109.  `crs_bytes`: the file the reference embeds with include_bytes! (an ark-serialized
+    UniversalSrs; its tree does not ship it, so the caller hands the bytes in).  As there: max_degree > 2^17 is refused
+    with the reference's message; the SHA-256 of the bytes must equal the pinned digest (or the one the caller states
+    for a test SRS) - a mismatch is the reference's assert_eq! panic, here an AssertionError; the WHOLE file is
+    deserialized, max_degree plays no other role."""
+    import hashlib
+    if max_degree > 1 << 17:
+        raise TxnApiError.FailedSnark("Currently only supports 2^17. Please update Aztec's CRS data file if needed.")
+    assert hashlib.sha256(crs_bytes).digest() == expected_sha256, "Mismatched sha256sum digest, file might be corrupted!"
+    try:
+        _lib.init()
+        handle, h, beta_h, _used = _lib.srs_deserialize(crs_bytes)
+        return UniversalSrs(handle, _lib.srs_size(handle) - 1, h, beta_h)
+    except _lib.CapGpuError as e:
+        raise TxnApiError.FailedSnark(f"Failed to load SRS: {e}") from e
 
 
 def preprocess(srs: UniversalSrs, n: int, num_inputs: int, selectors: np.ndarray, sigma_evals: np.ndarray):

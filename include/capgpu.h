@@ -370,6 +370,11 @@ int capgpu_plonk_key_deserialize(const uint8_t* bytes, size_t len, uint64_t* srs
  * lane, 8 waves per SIMD, ~50 ms).  A lazy Montgomery multiplication is 171 of them (81 + 81 + 9), so rate / 171 is the
  * chip's multiplication ceiling - what bench.py prices the ALU-bound kernels against. */
 int capgpu_ubench_mad_rate(double* lane_ops_per_s_out);
+/* The same measurement for the instruction classes the hot kernels are made of, all at that occupancy and chain count,
+ * in lane-operations per second: rates_out[0..count) = v_mad_u64_u32, v_add_u32, v_and_b32, v_mov_b32, v_lshl_add_u64,
+ * v_lshrrev_b64, v_alignbit_b32, v_mul_lo_u32 (count <= 8; ~0.3 s).  bench.py prices a kernel's instruction mix
+ * (profiles/isa_mix_r03.json) against them: issue_frac. */
+int capgpu_ubench_issue_rates(double* rates_out, int count);
 /* When enabled, every kernel launch is bracketed by HIP events on the launch stream and accumulated
  * per kernel name (costs a few microseconds per launch; leave off for throughput runs). */
 int capgpu_profile_enable(int on);

@@ -4,7 +4,9 @@
 // src/proof/: the same module layout, names, argument meaning and error behaviour -
 //
 //   capgpu::proof::universal_setup            src/proof/mod.rs:59-69
-//   capgpu::proof::load_srs                   src/proof/mod.rs:74-109   (from the UniversalSrs blob, not the Aztec file)
+//   capgpu::proof::load_srs                   src/proof/mod.rs:74-109   (the bytes of data/aztec-crs-131072.bin - an
+//                                             ark-serialized UniversalSrs, src/proof/mod.rs:106 - handed in by the caller:
+//                                             the reference embeds them with include_bytes!, its tree does not ship them)
 //   capgpu::proof::{transfer,mint,freeze}::preprocess   src/proof/transfer.rs:124-155, mint.rs:69-93, freeze.rs:93-121
 //   capgpu::proof::{transfer,mint,freeze}::prove        src/proof/transfer.rs:159-188, mint.rs:97-120, freeze.rs:125-158
 //   capgpu::proof::{transfer,mint,freeze}::verify       src/proof/transfer.rs:192-212, mint.rs:124-140, freeze.rs:162-178
@@ -159,17 +161,82 @@ inline Result<UniversalSrs> universal_setup(size_t max_degree, const Fr& tau) {
   return s;
 }
 
-// src/proof/mod.rs:74-109 with the UniversalSrs blob of parameters.rs (the Aztec file is not shipped with the reference)
-inline Result<UniversalSrs> load_srs(size_t max_degree, const std::vector<uint8_t>& bytes) {
+// SHA-256 (FIPS 180-4) of a byte string: load_srs checks the integrity of the CRS file like the reference does
+// (sha2::Sha256, src/proof/mod.rs:95-102).  Host only, ~1 GB/s: the 4 MB file is 4 ms.
+inline std::array<uint8_t, 32> sha256(const uint8_t* data, size_t len) {
+  static const uint32_t K[64] = {
+      0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+      0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+      0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+      0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+      0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+      0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+      0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+  uint32_t h[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+  auto rotr = [](uint32_t x, int n) { return (x >> n) | (x << (32 - n)); };
+  auto block = [&](const uint8_t* p) {
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++)
+      w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
+    for (int i = 16; i < 64; i++) {
+      const uint32_t s0 = rotr(w[i - 15], 7) ^ rotr(w[i - 15], 18) ^ (w[i - 15] >> 3);
+      const uint32_t s1 = rotr(w[i - 2], 17) ^ rotr(w[i - 2], 19) ^ (w[i - 2] >> 10);
+      w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; i++) {
+      const uint32_t t1 = hh + (rotr(e, 6) ^ rotr(e, 11) ^ rotr(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+      const uint32_t t2 = (rotr(a, 2) ^ rotr(a, 13) ^ rotr(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+      hh = g, g = f, f = e, e = d + t1, d = c, c = b, b = a, a = t1 + t2;
+    }
+    h[0] += a, h[1] += b, h[2] += c, h[3] += d, h[4] += e, h[5] += f, h[6] += g, h[7] += hh;
+  };
+  size_t i = 0;
+  for (; i + 64 <= len; i += 64) block(data + i);
+  uint8_t tail[128] = {0};
+  const size_t rem = len - i;
+  std::memcpy(tail, data + i, rem);
+  tail[rem] = 0x80;
+  const size_t tl = rem < 56 ? 64 : 128;
+  const uint64_t bits = (uint64_t)len * 8;
+  for (int k = 0; k < 8; k++) tail[tl - 1 - k] = (uint8_t)(bits >> (8 * k));
+  block(tail);
+  if (tl == 128) block(tail + 64);
+  std::array<uint8_t, 32> out;
+  for (int k = 0; k < 8; k++)
+    for (int b2 = 0; b2 < 4; b2++) out[4 * k + b2] = (uint8_t)(h[k] >> (24 - 8 * b2));
+  return out;
+}
+
+// SHA-256 of data/aztec-crs-131072.bin as pinned by the reference (src/proof/mod.rs:100)
+inline const std::array<uint8_t, 32>& aztec_crs_sha256() {
+  static const std::array<uint8_t, 32> d = {0x6b, 0x81, 0xe7, 0x5f, 0xb9, 0xc1, 0x4f, 0xd0, 0xe5, 0x8f, 0xb2,
+                                            0xb2, 0x9e, 0x48, 0x97, 0x8c, 0xda, 0xd5, 0x51, 0x15, 0x03, 0x68,
+                                            0x5a, 0x61, 0xf1, 0x39, 0x1d, 0xc4, 0xa4, 0xfc, 0x7c, 0xbf};
+  return d;
+}
+
+// src/proof/mod.rs:74-109.  `bytes`: the CRS file the reference embeds (an ark-serialized UniversalSrs).  As there:
+//   - max_degree > 2^17 is refused with the reference's message (mod.rs:83-88);
+//   - the SHA-256 of the bytes must equal `expected_sha256` - the reference's pinned digest unless the caller states
+//     another one (a test SRS) - or the call PANICS like the reference's assert_eq! (mod.rs:96-102): std::runtime_error;
+//   - the WHOLE file is deserialized and returned; max_degree plays no other role (mod.rs:106).
+inline Result<UniversalSrs> load_srs(size_t max_degree, const std::vector<uint8_t>& bytes,
+                                     const std::array<uint8_t, 32>& expected_sha256 = aztec_crs_sha256()) {
+  if (max_degree > ((size_t)1 << 17))
+    return TxnApiError::failed_snark("Currently only supports 2^17. Please update Aztec's CRS data file if needed.");
+  if (sha256(bytes.data(), bytes.size()) != expected_sha256)
+    throw std::runtime_error("Mismatched sha256sum digest, file might be corrupted!");
   int rc = capgpu_init(nullptr, 0);
   if (rc != CAPGPU_OK) return detail::map_error(rc, "Failed to load SRS");
   UniversalSrs s;
   uint64_t h = 0;
-  size_t used = 0;
-  rc = capgpu_srs_deserialize(bytes.data(), bytes.size(), max_degree, &h, s.h.data(), s.beta_h.data(), &used);
+  size_t used = 0, n = 0;
+  rc = capgpu_srs_deserialize(bytes.data(), bytes.size(), 0, &h, s.h.data(), s.beta_h.data(), &used);
   if (rc != CAPGPU_OK) return detail::map_error(rc, "Failed to load SRS");
   s.powers_of_g = std::make_shared<detail::SrsHandle>(h);
-  s.max_degree = max_degree;
+  capgpu_srs_size(h, &n);
+  s.max_degree = n ? n - 1 : 0;
   return s;
 }
 

@@ -254,6 +254,58 @@ int main(int argc, char** argv) {
     ASSERT(r.is_err() && r.error().kind == TxnApiError::FailedSnark);
   }
 
+  // load_srs (src/proof/mod.rs:74-109): degree bound, SHA-256 integrity check, the whole file is deserialized.  The
+  // CRS bytes here are this SRS's own ark-serialize form (the Aztec file is not shipped with the reference)
+  {
+    // FIPS 180-4 known answers pin the digest the integrity check rests on
+    const std::array<uint8_t, 32> abc = proof::sha256(reinterpret_cast<const uint8_t*>("abc"), 3);
+    ASSERT(abc[0] == 0xba && abc[1] == 0x78 && abc[2] == 0x16 && abc[31] == 0xad);
+    const std::string two_blocks = "abcdbcdecdefdefgefghfghighijhijkijkljklmklmnlmnomnopnopq";
+    const std::array<uint8_t, 32> d2 = proof::sha256(reinterpret_cast<const uint8_t*>(two_blocks.data()), two_blocks.size());
+    ASSERT(d2[0] == 0x24 && d2[1] == 0x8d && d2[30] == 0x06 && d2[31] == 0xc1);
+    size_t need = 0;
+    ASSERT(capgpu_srs_serialize(universal_param.handle(), universal_param.h.data(), universal_param.beta_h.data(), nullptr,
+                                0, &need) == CAPGPU_OK);
+    std::vector<uint8_t> crs(need);
+    ASSERT(capgpu_srs_serialize(universal_param.handle(), universal_param.h.data(), universal_param.beta_h.data(),
+                                crs.data(), crs.size(), &need) == CAPGPU_OK);
+    const std::array<uint8_t, 32> digest = proof::sha256(crs.data(), crs.size());
+    auto too_big = proof::load_srs(((size_t)1 << 17) + 1, crs, digest);
+    ASSERT(too_big.is_err() && too_big.error().kind == TxnApiError::FailedSnark &&
+           too_big.error().msg.find("only supports 2^17") != std::string::npos);
+    bool panicked = false;
+    try {
+      (void)proof::load_srs(max_degree, crs);  // the reference's pinned digest: these are not the Aztec bytes
+    } catch (const std::runtime_error& e) {
+      panicked = std::string(e.what()).find("Mismatched sha256sum digest") != std::string::npos;
+    }
+    ASSERT(panicked);
+    std::vector<uint8_t> corrupted(crs);
+    corrupted[crs.size() / 2] ^= 1;
+    panicked = false;
+    try {
+      (void)proof::load_srs(max_degree, corrupted, digest);
+    } catch (const std::runtime_error&) {
+      panicked = true;
+    }
+    ASSERT(panicked);
+    auto loaded = proof::load_srs(max_degree, crs, digest);
+    ASSERT(loaded.is_ok());
+    if (loaded.is_ok()) {
+      ASSERT(loaded.unwrap().max_degree == max_degree);
+      ASSERT(loaded.unwrap().h == universal_param.h && loaded.unwrap().beta_h == universal_param.beta_h);
+      // a key preprocessed under the loaded parameters makes the same proof
+      auto pre = proof::transfer::preprocess(loaded.unwrap(), 2, 2, 26, in1.circuit());
+      ASSERT(pre.is_ok());
+      if (pre.is_ok()) {
+        FixtureRng rng{in1.blinders};
+        auto p = proof::transfer::prove(rng, pre.unwrap().proving_key, in1.assignment(), recv_memos_ver_key,
+                                        extra_proof_bound_data);
+        ASSERT(p.is_ok() && std::memcmp(&p.unwrap(), &validity_proof_1.unwrap(), sizeof(Proof)) == 0);
+      }
+    }
+  }
+
   if (failures) return 1;
   std::printf("OK\n");
   return 0;

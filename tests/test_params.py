@@ -316,6 +316,68 @@ def test_proving_key_blob_vs_oracle(cg, tau):
 
 
 @pytest.mark.gpu
+def test_hiding_powers_of_a_loaded_srs_in_key_blobs(cg, tau):
+    """CommitKey::powers_of_gamma_g of a ProvingKey blob is a Vec<G1> for degrees 0 .. n + 2 (what jf-plonk's trim
+    emits).  A key preprocessed under a loaded UniversalSrs takes them from that SRS's BTreeMap by DEGREE: all of them in
+    order, or - when the map lacks one - none; a sparse map must not become a shorter, mislabelled vector (round-2
+    ADVICE).  A trimmed load (max_degree) also trims the map, so that a re-stored file is consistent."""
+    g = H.load_golden("proof_log5.json")
+    sc = bu.synthetic_circuit(g["log_n"], g["num_inputs"], seed=g["circuit_seed"])
+    n_ck = sc.n + 3
+    o = pm.deserialize_universal_params(bytes.fromhex(G["srs"]))
+    pts = o["powers_of_g"]
+    assert len(pts) == n_ck
+    gamma_full = {d: pts[(5 * d + 1) % n_ck] for d in range(n_ck + 1)}          # degrees 0 .. max_degree + 1
+    sparse = {0: pts[3], 7: pts[1]}
+    key_blob = {}
+    for name, gm in (("full", gamma_full), ("sparse", sparse)):
+        blob = pm.serialize_universal_params(pts, gm, o["h"], o["beta_h"], {})
+        h, hh, bh, _ = cg.srs_deserialize(blob)
+        assert cg.srs_serialize(h, hh, bh) == blob
+        pk, _vk = cg.plonk_preprocess(h, sc.n, sc.num_inputs, sc.selectors_mont(), sc.sigma_mont())
+        key_blob[name] = cg.plonk_key_serialize(pk, hh, bh)
+        cg.plonk_free_key(pk)
+        cg.srs_free(h)
+    plain = pm.deserialize_proving_key(bytes.fromhex(G["proving_key"]))
+    want_full = pm.serialize_proving_key(plain["sigmas"], plain["selectors"], plain["powers_of_g"], bytes.fromhex(G["vk"]),
+                                         gamma_powers=[gamma_full[d] for d in range(n_ck)])
+    assert key_blob["full"] == want_full                        # degrees 0 .. n + 2, in order
+    assert key_blob["sparse"] == bytes.fromhex(G["proving_key"])  # a map with holes: no hiding powers, not two of them
+    # trimmed load: powers_of_g cut to max_degree + 1, the map to the degrees a setup of that size holds
+    blob = pm.serialize_universal_params(pts, gamma_full, o["h"], o["beta_h"], {})
+    h, hh, bh, _ = cg.srs_deserialize(blob, max_degree=19)
+    back = pm.deserialize_universal_params(cg.srs_serialize(h, hh, bh))
+    assert len(back["powers_of_g"]) == 20 and sorted(back["powers_of_gamma_g"]) == list(range(21))
+    assert all(back["powers_of_gamma_g"][d] == gamma_full[d] for d in range(21))
+    cg.srs_free(h)
+
+
+@pytest.mark.gpu
+def test_load_srs_mirror(cg, tau):
+    """capproof.load_srs (src/proof/mod.rs:74-109) on this SRS's own ark-serialize bytes: the whole file is loaded."""
+    import hashlib
+    blob = bytes.fromhex(G["srs"])
+    srs = capproof.load_srs(20, blob, hashlib.sha256(blob).digest())
+    assert srs.max_degree == 34 and cg.srs_size(srs.handle) == 35
+    cg.srs_free(srs.handle)
+
+
+def test_load_srs_guards_run_before_any_device_work():
+    """the degree bound and the integrity assert of src/proof/mod.rs:83-102 need no GPU"""
+    import hashlib
+    blob = bytes.fromhex(G["srs"])
+    with pytest.raises(capproof.TxnApiError, match="only supports 2\\^17"):
+        capproof.load_srs((1 << 17) + 1, blob, hashlib.sha256(blob).digest())
+    with pytest.raises(AssertionError, match="Mismatched sha256sum digest"):
+        capproof.load_srs(1 << 17, blob)                         # the reference's pinned digest: not the Aztec bytes
+    bad = bytearray(blob)
+    bad[100] ^= 1
+    with pytest.raises(AssertionError, match="Mismatched sha256sum digest"):
+        capproof.load_srs(100, bytes(bad), hashlib.sha256(blob).digest())
+    assert capproof.AZTEC_CRS_SHA256.hex() == "6b81e75fb9c14fd0e58fb2b29e48978cdad5511503685a61f1391dc4a4fc7cbf"
+
+
+@pytest.mark.gpu
 def test_blob_parsers_survive_random_corruption(cg):
     """Same for the device-backed parsers (UniversalSrs, ProvingKey): error or success, never a crash or a HIP fault,
     and every handle a successful parse returns is usable and can be freed."""
