@@ -64,6 +64,7 @@ extern "C" {
     pub fn capgpu_set_device(slot: c_int) -> c_int;
     pub fn capgpu_get_device(slot_out: *mut c_int, hip_device_out: *mut c_int) -> c_int;
     pub fn capgpu_device_info(name_out: *mut c_char, cu_count_out: *mut c_int, hbm_bytes_out: *mut u64) -> c_int;
+    pub fn capgpu_mem_info(free_bytes_out: *mut u64, total_bytes_out: *mut u64) -> c_int;
     // ---- device memory / stream
     pub fn capgpu_malloc(dev_ptr_out: *mut *mut c_void, bytes: usize) -> c_int;
     pub fn capgpu_free(dev_ptr: *mut c_void) -> c_int;

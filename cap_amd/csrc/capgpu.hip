@@ -772,6 +772,16 @@ int capgpu_device_info(char* name_out, int* cu_count_out, uint64_t* hbm_bytes_ou
   return CAPGPU_OK;
 }
 
+int capgpu_mem_info(uint64_t* free_bytes_out, uint64_t* total_bytes_out) {
+  CAP_CHECK_INIT();
+  Entry lk(ctx());
+  size_t f = 0, t = 0;
+  CAP_HIP(hipMemGetInfo(&f, &t));
+  if (free_bytes_out) *free_bytes_out = (uint64_t)f;
+  if (total_bytes_out) *total_bytes_out = (uint64_t)t;
+  return CAPGPU_OK;
+}
+
 int capgpu_malloc(void** dev_ptr_out, size_t bytes) {
   CAP_CHECK_INIT();
   if (!dev_ptr_out) return CAPGPU_ERR_INVALID_ARG;

@@ -111,6 +111,13 @@ def get_device():
     return s.value, d.value
 
 
+def mem_info():
+    """(free, total) device memory in bytes"""
+    f, t = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    check(load().capgpu_mem_info(ctypes.byref(f), ctypes.byref(t)))
+    return f.value, t.value
+
+
 def _p(a: np.ndarray):
     assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(u64p)

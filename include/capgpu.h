@@ -104,6 +104,8 @@ const char* capgpu_last_error(void);
 const char* capgpu_version(void);
 /* name (<= 255 chars + NUL), compute units, HBM bytes of the bound device */
 int capgpu_device_info(char* name_out, int* cu_count_out, uint64_t* hbm_bytes_out);
+/* free / total device memory of the calling thread's device, in bytes (hipMemGetInfo) */
+int capgpu_mem_info(uint64_t* free_bytes_out, uint64_t* total_bytes_out);
 
 /* ---- device memory / stream (plumbing for callers that keep data resident) -------------- */
 int capgpu_malloc(void** dev_ptr_out, size_t bytes);

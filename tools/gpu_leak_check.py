@@ -35,19 +35,16 @@ def cycle(i, tau):
 
 def run(cycles=200, warm=10):
     """returns the device memory (bytes) that `cycles` create / use / free cycles left allocated"""
-    import torch
     cg.init(0)
     tau = bu.SplitMix64(5).field()
     for i in range(warm):
         cycle(i, tau)
     cg.sync()
-    torch.cuda.synchronize()
-    f0 = torch.cuda.mem_get_info()[0]
+    f0 = cg.mem_info()[0]
     for i in range(cycles):
         cycle(i, tau)
     cg.sync()
-    torch.cuda.synchronize()
-    f1 = torch.cuda.mem_get_info()[0]
+    f1 = cg.mem_info()[0]
     return f0 - f1
 
 
