@@ -491,6 +491,7 @@ __global__ __launch_bounds__(kDeepThreads) void msm_deep_sort(const uint32_t* __
   __shared__ uint32_t start[kKeys];
   __shared__ uint32_t run_pre[kDeepMaxRuns + 1];  // run lengths, then their inclusive prefix (run_pre[0] = 0)
   __shared__ uint32_t run_src[kDeepMaxRuns];
+  __shared__ uint32_t coarse[kDeepStage / 256];  // the run that holds staged position b * 256
   __shared__ uint32_t stage[kDeepStage];
   const uint32_t S = blockIdx.y, tid = threadIdx.x;
   uint32_t R, nkeys, out_base;
@@ -557,19 +558,22 @@ __global__ __launch_bounds__(kDeepThreads) void msm_deep_sort(const uint32_t* __
            (v & 0x80000000u);
   };
   auto fetch = [&](uint32_t p, uint32_t& key) -> uint32_t { return fetch_in(p, find_run(p), key); };
+  if (tid < kDeepStage / 256) coarse[tid] = tid * 256 < cnt ? find_run(tid * 256) : 0;
+  __syncthreads();
   constexpr int kPer = kDeepStage / kDeepThreads;
   const uint32_t staged = cnt < kDeepStage ? cnt : kDeepStage;
   uint32_t ev[kPer], keys[kPer / 2];  // 16-bit keys, two per register
 #pragma unroll
   for (int i = 0; i < kPer / 2; i++) keys[i] = 0;
-  // a thread takes kPer CONSECUTIVE entries: one search for the run of the first, then a walk (the binary search per
-  // entry - 8 dependent LDS reads - was most of this kernel's time); a lane reads a 64-byte piece of a run
+  // Entry p = tid + i * 1024 (a wave reads 256 contiguous bytes per load).  Its run is found from a coarse table - the
+  // run that holds position b * 256, one binary search per 256 positions - and a short walk, instead of a binary search
+  // (8-9 dependent LDS reads) per entry.
   {
-    uint32_t run = tid * kPer < staged ? find_run(tid * kPer) : 0;
 #pragma unroll
     for (int i = 0; i < kPer; i++) {
-      const uint32_t p = tid * kPer + i;
+      const uint32_t p = tid + i * kDeepThreads;
       if (p < staged) {
+        uint32_t run = coarse[p >> 8];
         while (run + 1 < R && run_pre[run + 1] <= p) run++;
         uint32_t k;
         ev[i] = fetch_in(p, run, k);
@@ -618,7 +622,7 @@ __global__ __launch_bounds__(kDeepThreads) void msm_deep_sort(const uint32_t* __
   uint32_t* out = dst + out_base;
 #pragma unroll
   for (int i = 0; i < kPer; i++) {
-    if (tid * kPer + i < staged) {
+    if (tid + i * kDeepThreads < staged) {
       const uint32_t pos = atomicAdd(&start[(keys[i >> 1] >> (16 * (i & 1))) & 0xFFFFu], 1u);
       if (pos < kDeepStage) stage[pos] = ev[i];
       else out[pos] = ev[i];
