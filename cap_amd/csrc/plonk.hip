@@ -1481,13 +1481,33 @@ int capgpu_plonk_prove(uint64_t pk_handle, const uint64_t* wires, const uint64_t
     q.erase(q.begin(), q.begin() + take);
     co.leader[group] = false;
     lk.unlock();
+    // a second free context takes half of a batch large enough to cut (like deal() does for host batches): the halves
+    // overlap on the device, or run on two devices
+    std::vector<ProveReq*> second;
+    Context* c2 = nullptr;
+    if (reqs.size() >= 2 * (size_t)deal_min() && thread_bound_slot() < 0 && num_contexts() > 1 &&
+        (c2 = try_acquire_context()) != nullptr) {
+      c2->mu.unlock();  // the helper thread locks it itself (the lock belongs to the thread that takes it)
+      const size_t half = reqs.size() / 2;
+      second.assign(reqs.begin() + half, reqs.end());
+      reqs.resize(half);
+    }
+    std::thread helper;
+    if (c2)
+      helper = std::thread([&second, c2] {
+        ScopedCtx sc(*c2);
+        Entry elk(*c2);
+        run_coalesced(second);
+      });
     {
       ScopedCtx sc(*c);
       run_coalesced(reqs);  // re-enters the (recursive) context lock this thread holds
     }
     c->mu.unlock();
+    if (helper.joinable()) helper.join();
     lk.lock();
     for (ProveReq* r : reqs) r->done = true;
+    for (ProveReq* r : second) r->done = true;
     co.cv.notify_all();
   }
   if (req.rc != CAPGPU_OK) set_error("%s", req.err.c_str());
