@@ -4,12 +4,15 @@
 tag=$1
 O=gpurun_out/final_$tag
 mkdir -p $O
-python -m pytest tests -m gpu -q --durations=10 > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
+timeout 1500 python -m pytest tests -m gpu -q --durations=10 --timeout=600 > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
-python bench.py > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err
-python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-reference-schedule --no-msm > $O/bench_20steps.json 2>/dev/null
-python bench.py --workload mixed64 --steps 12 --warmup 3 --no-msm > $O/bench_mixed64.json 2>/dev/null
-MSM_LOGS=15,17,20,22,24 python tools/gpu_msm_profile.py > $O/msm_single_profile.json 2>/dev/null
+timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err
+timeout 600 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-reference-schedule --no-msm > $O/bench_20steps.json 2>/dev/null
+timeout 600 python bench.py --workload mixed64 --steps 12 --warmup 3 --no-msm > $O/bench_mixed64.json 2>/dev/null
+CAPGPU_ALLOW_DUPLICATE_DEVICES=1 timeout 600 python bench.py --single-process --devices 0,0 --batch 128 --steps 4 --warmup 1 --msm-log-n 22 > $O/bench_single_process.json 2>/dev/null
+MINLOG=21 timeout 300 python tools/gpu_msm_deep_ab.py 24 > $O/msm_deep_ab.jsonl 2>/dev/null
+timeout 300 python tools/gpu_two_ctx.py 15 256 2>/dev/null | tail -1 > $O/two_ctx.json
+MSM_LOGS=15,17,20,22,24 timeout 600 python tools/gpu_msm_profile.py > $O/msm_single_profile.json 2>/dev/null
 bash tools/gpuprof.sh $tag > $O/gpuprof.log 2>&1
 python tools/make_traffic.py gpurun_out/prof_$tag 256 $O/traffic.json > $O/traffic.log 2>&1
 bash tools/gpuprof_insts.sh $tag > $O/insts.txt 2>&1

@@ -8,7 +8,7 @@ import shutil
 import sys
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r02"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, prof, dst = (os.path.join(root, "gpurun_out", "final_" + tag), os.path.join(root, "gpurun_out", "prof_" + tag),
                   os.path.join(root, "profiles"))
@@ -25,6 +25,10 @@ b = one_line_json(os.path.join(src, "bench.json"), os.path.join(dst, f"bench_{rn
 b20 = one_line_json(os.path.join(src, "bench_20steps.json"), os.path.join(dst, f"bench_20steps_{rnd}.json"))
 bm = one_line_json(os.path.join(src, "bench_mixed64.json"), os.path.join(dst, f"bench_mixed64_{rnd}.json"))
 shutil.copy(os.path.join(src, "msm_single_profile.json"), os.path.join(dst, f"msm_single_profile_{rnd}.json"))
+for name, out_name in (("bench_single_process.json", f"bench_single_process_dev0x2_{rnd}.json"),
+                       ("msm_deep_ab.jsonl", f"msm_deep_ab_{rnd}.jsonl"), ("two_ctx.json", f"two_contexts_ab_{rnd}.json")):
+    if os.path.exists(os.path.join(src, name)) and os.path.getsize(os.path.join(src, name)):
+        shutil.copy(os.path.join(src, name), os.path.join(dst, out_name))
 shutil.copy(os.path.join(src, "traffic.json"), os.path.join(dst, f"traffic_{rnd}.json"))
 shutil.copy(os.path.join(src, "pytest_gpu.txt"), os.path.join(dst, f"pytest_gpu_{rnd}_final.txt"))
 w2 = [open(os.path.join(src, n)).read().strip() for n in ("bench_w2.json", "bench_w2_mixed.json")]
@@ -43,7 +47,8 @@ for ln in open(os.path.join(src, "insts.txt")):
     d = ast.literal_eval("{" + rest.strip())
     launches = max(v[1] for v in d.values())
     kern[name.strip()] = dict(launches=launches, **{k: round(v[0] / v[1]) if isinstance(v[0], float) else v[0] for k, v in d.items()})
-old = json.load(open(os.path.join(dst, f"inst_counters_{rnd}.json")))
+prev = os.path.join(dst, f"inst_counters_{rnd}.json")
+old = json.load(open(prev if os.path.exists(prev) else os.path.join(dst, "inst_counters_r02.json")))
 adds = b["alu_roofline"]["mixed_adds_per_step"] / 4           # four large msm_accumulate launches per step
 acc = kern["msm_accumulate"]
 # the PMC run has 8 large launches and the small one of preprocess; its counters are per-launch averages over all 9
