@@ -1083,7 +1083,12 @@ int capgpu_plonk_key_deserialize(const uint8_t* bytes, size_t len, uint64_t* srs
   }
   auto K = std::make_shared<ProvingKey>();
   auto bail = [&](int code) {
-    capgpu_srs_free(srs_handle);
+    // the SRS was registered a moment ago on THIS context and nobody else knows its handle: drop it here (going through
+    // capgpu_srs_free would take the other contexts' locks while this one is held - out of lock order)
+    (void)hipStreamSynchronize(c.stream);
+    c.srs.erase(srs_handle);
+    std::lock_guard<std::mutex> rlk(rt().mu);
+    rt().srs.erase(srs_handle);
     return code;
   };
   if ((rc = key_init(*K, n, vk.num_inputs, srs_handle))) return bail(rc);

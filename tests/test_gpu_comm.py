@@ -135,6 +135,29 @@ def test_sharded_msm_loopback_world(loop, tau):
     cg.srs_free(h)
 
 
+def test_sum_over_more_ranks_than_lanes(cg, tau):
+    """g1_sum_ranks with 130 ranks: the wavefront's lanes stride over the ranks (two and a bit rounds), two MSMs per
+    exchange, most ranks holding two or three points"""
+    k, n, count = 130, 301, 2
+    cg.comm_init_loopback(k)
+    try:
+        h = cg.srs_generate(tau, n)
+        scs = np.stack([cr.random_field(90 + i, 1, n, False) for i in range(count)])
+        d_out = cg.DevBuf(96 * count)
+        for rank in range(k):
+            lo, ln = _split(n, k, rank)
+            cg.comm_loopback_set_rank(rank)
+            d = cg.DevBuf.from_numpy(np.ascontiguousarray(scs[:, lo:lo + ln]).reshape(-1, 4))
+            cg.msm_g1_sharded_dev(h, d, ln, count=count, offset=lo, d_out=d_out)
+            d.free()
+        out = d_out.to_numpy().reshape(count, 12)
+        for i in range(count):
+            assert np.array_equal(cr.g1_to_affine(out[i]), cr.g1_to_affine(cg.msm_g1(h, scs[i]))), i
+        cg.srs_free(h)
+    finally:
+        cg.comm_destroy()
+
+
 def test_a_failed_rank_fails_every_rank(loop, tau):
     """comm.hip: the status word behind every rank's partials.  Rank 1 fails locally (its range lies beyond the SRS);
     it still deposits its payload, and the rank that completes the exchange reports the peer's failure."""
