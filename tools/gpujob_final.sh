@@ -21,7 +21,7 @@ python - <<PY
 import json
 d = json.load(open("$O/bench.json"))
 print("value", round(d["value"], 1), "ms/step", round(d["ms_per_step"], 2), {k: round(v / d["steps"], 2) for k, v in d["top_kernels_ms"].items()})
-for k in ("alu_roofline", "reference_schedule", "latency_ms_batch1", "pcie_inclusive", "n2p16", "cpu_baseline", "cpu_baseline_all_cores"):
+for k in ("alu_roofline", "reference_schedule", "latency_ms_batch1", "pcie_inclusive", "n2p16", "cpu_baseline", "cpu_baseline_64_threads", "two_contexts_per_device", "mixed64", "coalesced_single_calls"):
     print(k, d.get(k))
 print([ (l.get("log_n"), round(l.get("ms", 0), 3), l.get("identity_check")) for l in d.get("msm", [])])
 print("20 steps:", round(json.load(open("$O/bench_20steps.json"))["value"], 1), "mixed64:", round(json.load(open("$O/bench_mixed64.json"))["value"], 1))
