@@ -296,3 +296,72 @@ def test_mixed_batch_of_64_full_size_split_over_two_contexts(cg2, tau):
     for g in groups:
         cg.plonk_free_key(g[0])
     cg.srs_free(h)
+
+
+def test_two_contexts_under_concurrent_mixed_load(cg2, tau):
+    """Lock-order check by brute force: for a few seconds, threads make every kind of call that takes context locks in
+    a different way - dealt host batches (one lock per part, from helper threads), MSMs on a sharded SRS (all locks, in
+    slot order), coalesced single proofs (a leader's try-lock plus a helper's lock), bound device-pointer calls, handle
+    creation / replication / release - and every result must equal the lone caller's; nothing may deadlock."""
+    import time
+    cg = cg2
+    sc = bu.synthetic_circuit(9, 3, seed=8)
+    os.environ["CAPGPU_SHARD_MIN_POINTS"] = str(1 << 20)
+    h = cg.srs_generate(tau, sc.n + 3)                               # a commit key: never sharded
+    os.environ["CAPGPU_SHARD_MIN_POINTS"] = "4096"
+    hs = cg.srs_generate_affine_seq(A_SEQ, B_SEQ, 9000)             # sharded over the two contexts
+    assert cg.srs_shards(h) == 1 and cg.srs_shards(hs) == 2
+    pkh, _vk = cg.plonk_preprocess(h, sc.n, 3, sc.selectors_mont(), sc.sigma_mont())
+    ws, ps, bls = _witnesses(sc, 20, 700)
+    k9 = bu.random_canonical_scalars(3, 9000)
+    ref_batch = [bytes(p) for p in cg.plonk_prove_batch(pkh, ws, ps, bls, b"x", 20)]
+    ref_msm = cr.g1_to_affine(cg.msm_g1(hs, k9)).tobytes()
+    ref_small = cr.g1_to_affine(cg.msm_g1(h, k9[:sc.n])).tobytes()
+    stop = time.time() + 4.0
+    errors, counts = [], {}
+    lock = threading.Lock()
+
+    def worker(kind, slot):
+        n_ok = 0
+        try:
+            if slot is not None:
+                cg.set_device(slot)
+            while time.time() < stop:
+                if kind == "batch":
+                    ok = [bytes(p) for p in cg.plonk_prove_batch(pkh, ws, ps, bls, b"x", 20)] == ref_batch
+                elif kind == "sharded":
+                    ok = cr.g1_to_affine(cg.msm_g1(hs, k9)).tobytes() == ref_msm
+                elif kind == "single":
+                    i = n_ok % 20
+                    ok = bytes(cg.plonk_prove(pkh, ws[i], ps[i], bls[i], b"x")) == ref_batch[i]
+                elif kind == "dev":
+                    d = cg.DevBuf.from_numpy(np.ascontiguousarray(k9[:sc.n]))
+                    ok = cr.g1_to_affine(cg.msm_g1_dev(h, d, sc.n).to_numpy()).tobytes() == ref_small
+                    d.free()
+                else:                                                 # handles come and go on both contexts
+                    h2 = cg.srs_generate(tau, 700)
+                    ok = cg.srs_size(h2) == 700 and cg.msm_g1(h2, k9[:700]) is not None
+                    cg.srs_free(h2)
+                if not ok:
+                    errors.append(kind)
+                n_ok += 1
+        except Exception as ex:                                      # noqa: BLE001
+            errors.append(f"{kind}: {ex}")
+        with lock:
+            counts[kind] = counts.get(kind, 0) + n_ok
+
+    cg.plonk_set_coalescing(300, 16)
+    plan = [("batch", None), ("batch", None), ("sharded", None), ("sharded", 1), ("single", None), ("single", None),
+            ("single", None), ("dev", 0), ("dev", 1), ("handles", None)]
+    ths = [threading.Thread(target=worker, args=a) for a in plan]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join(timeout=120)
+    cg.plonk_set_coalescing(0, 0)
+    assert not any(t.is_alive() for t in ths), "deadlock"
+    assert not errors, errors[:5]
+    assert all(counts.get(k, 0) > 0 for k in ("batch", "sharded", "single", "dev", "handles")), counts
+    cg.plonk_free_key(pkh)
+    cg.srs_free(h)
+    cg.srs_free(hs)
