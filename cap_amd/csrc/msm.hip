@@ -1235,7 +1235,8 @@ uint32_t deep_c(size_t n) {
     const int x = atoi(e);
     if (x >= 17 && x <= 22) return (uint32_t)x;  // (c = 16 has 17 windows: one more than the entry's window field holds)
   }
-  return n < ((size_t)3 << 19) ? 17u : 20u;  // 1.5 M points: 13 digits + 2^19 buckets overtake 15 digits + 2^16 buckets
+  (void)n;
+  return 20u;  // (c = 17 measured at 2^19 .. 2^21 points: 1.57 / 2.20 / 3.75 ms against 1.47 / 2.07 / 3.26 ms for c = 20)
 }
 bool deep_enabled() {
   const char* e = getenv("CAPGPU_MSM_DEEP");
@@ -1243,8 +1244,9 @@ bool deep_enabled() {
 }
 size_t deep_min_points() {  // shortest MSM that takes the deep plan
   const char* e = getenv("CAPGPU_MSM_DEEP_MIN");
-  // measured (tools/gpu_msm_deep_ab.py): 2^20 points 2.83 ms deep against 2.55 ms as 128 sub-MSMs, 2^21 3.6 against 4.0
-  const long long x = e ? atoll(e) : (3ll << 19);
+  // measured (tools/gpu_msm_deep_ab.py, c = 20): 2^19 points 1.47 ms deep against 1.85 ms as 64 sub-MSMs, 2^20 2.07
+  // against 2.56, 2^21 3.26 against 4.03
+  const long long x = e ? atoll(e) : (1ll << 19);
   return (size_t)(x >= 4096 ? x : 4096);
 }
 size_t deep_min_density() {  // average entries per bucket below which a launch leaves the deep plan (tests: 0)

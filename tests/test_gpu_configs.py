@@ -69,17 +69,19 @@ def test_msm_plans_of_the_baseline_sizes(cg, tau):
     assert cr.affine_to_ints(cr.g1_to_affine(got[7])) == bn.g1_mul(bn.G1_GEN, ftau)
     cg.srs_free(h)
     h = cg.srs_generate_affine_seq(A_SEQ, B_SEQ, 1 << 19)
-    p = cg.msm_plan(h, 1 << 19, 1)
+    p = cg.msm_plan(h, (1 << 19) - 1, 1)                  # just below the deep plan's threshold: sub-MSMs
     assert (p["c"], p["sort"], p["parts"], p["n_sub"]) == (15, "two-level", 64, 8192)    # no part below 8192 points
+    assert cg.msm_plan(h, 1 << 19, 1)["sort"] == "deep"
     assert cg.msm_plan(h, 100, 1)["parts"] == 1
     cg.srs_free(h)
     # BASELINE config 5 and its neighbours: ONE bucket set on the deep-window table (c = 20: 13 digits per scalar instead
-    # of the 17 of the c = 15 table), three-level sort; 2^20 points stay a batch of sub-MSMs (measured faster there)
+    # of the 17 of the c = 15 table), three-level sort, from 2^19 points
     h = cg.srs_generate_affine_seq(A_SEQ, B_SEQ, 1 << 22)
     p = cg.msm_plan(h, 1 << 22, 1)
     assert (p["c"], p["windows"], p["sort"], p["top"], p["mid"], p["low"]) == (20, 13, "deep", 6, 6, 7), p
-    p = cg.msm_plan(h, 1 << 20, 1)                        # a short range of the long table: back to sub-MSMs
-    assert (p["c"], p["sort"], p["parts"]) == (15, "two-level", 128), p
+    assert cg.msm_plan(h, 1 << 20, 1)["sort"] == "deep"
+    p = cg.msm_plan(h, 1 << 18, 1)                        # a short range of the long table: back to sub-MSMs
+    assert (p["c"], p["sort"]) == (15, "two-level"), p
     assert cg.msm_plan(h, 1 << 22, 2)["sort"] == "two-level"          # batches of long MSMs: sub-MSMs as before
     cg.srs_free(h)
 
