@@ -31,6 +31,19 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(L, name), f"{name} declared in include/capgpu.h but not exported by libcapgpu.so"
 
 
+def test_rust_bindings_cover_the_header():
+    """bindings/capgpu-sys is unbuilt source (no Rust toolchain here): at least it must name exactly the symbols the
+    header declares and the error codes the header defines, so that it cannot drift unnoticed."""
+    rs = open(os.path.join(ROOT, "bindings", "capgpu-sys", "src", "lib.rs")).read()
+    bound = set(re.findall(r"pub fn (capgpu_[a-z0-9_]+)\s*\(", rs))
+    declared = set(declared_symbols())
+    assert declared - bound == set(), f"declared in capgpu.h, missing in lib.rs: {sorted(declared - bound)}"
+    assert bound - declared == set(), f"bound in lib.rs, not in capgpu.h: {sorted(bound - declared)}"
+    hdr = open(os.path.join(ROOT, "include", "capgpu.h")).read()
+    for name, val in re.findall(r"#define (CAPGPU_(?:OK|ERR_[A-Z_]+)) \(?(-?\d+)\)?", hdr):
+        assert re.search(rf"pub const {name}: c_int = {val};", rs), name
+
+
 def test_struct_layouts_match_header():
     assert ctypes.sizeof(cg.Proof) == 13 * 64 + 10 * 32
     assert ctypes.sizeof(cg.VerifyingKey) == 16 + 5 * 32 + 18 * 64
