@@ -1262,7 +1262,9 @@ int capgpu_ubench_issue_rates(double* rates_out, int count) {
   Entry lk(c);
   hipDeviceProp_t prop;
   CAP_HIP(hipGetDeviceProperties(&prop, c.device));
-  const int blocks = prop.multiProcessorCount * 8, iters = 1000;
+  // CAPGPU_UBENCH_ITERS: length of one measurement launch (1000 iterations of 64 instructions ~ 0.4-0.7 ms)
+  const char* ie = getenv("CAPGPU_UBENCH_ITERS");
+  const int blocks = prop.multiProcessorCount * 8, iters = ie && atoi(ie) > 0 ? atoi(ie) : 1000;
   DevTmp<uint64_t> d;
   CAP_HIP(d.alloc((size_t)blocks * 256));
   CAP_HIP(hipMemsetAsync(d, 0x5a, sizeof(uint64_t) * blocks * 256, c.stream));

@@ -1,4 +1,6 @@
-"""Multi-GPU sharding of the hot path: one process per GPU, torch.distributed.
+"""Multi-GPU sharding of the hot path for jobs that run one process per GPU under torch.distributed.
+(A single process can also drive every GPU itself - `lib.init(devices=[0, 1, ...])`: batches are dealt and long SRSs
+sharded inside the library, no communicator involved; see cap_amd/csrc/context.hpp and tests/test_gpu_multidev.py.)
 
 * Whole proofs are independent -> replicas, no data-path collective (`shard_proofs`).
 * One MSM shards by contiguous point range: rank g owns bases[g*N/G, (g+1)*N/G) resident on its GPU
