@@ -885,9 +885,20 @@ __global__ __launch_bounds__(1024) void msm_sort_items(const uint32_t* __restric
 // and the items of a wavefront come from a length-sorted list (msm_sort_items), so every lane of a wavefront runs
 // practically the same number of mixed additions whatever the bucket sizes are; a skewed scalar distribution (one
 // giant bucket) is cut into many items instead of one serial chain.
-// (A fourth wave per SIMD - amdgpu_waves_per_eu(4, 4): 128 VGPRs, 6 of them spilled - was measured: 130.73 vs 130.75 ms
-// per step.  The kernel is bound by instruction issue, not by latency hiding.)
-__global__ __launch_bounds__(kThreads) void msm_accumulate(const g1_affine* __restrict__ ext,
+// Occupancy does not move it (147 VGPRs: three waves per SIMD).  Measured per step: a fourth wave -
+// amdgpu_waves_per_eu(4, 4), 128 VGPRs, 7 of them spilled - 115.9 against 116.3 ms (round 2: 130.73 vs 130.75); two waves
+// (64 KiB of dynamic LDS per workgroup, CAPGPU_ACC_LDS) 116.7 against 113.9; four waves WITHOUT scratch spills - the
+// accumulator's y, zz, zzz kept in LDS between their uses, 27 limbs read twice and written once per addition - 126.7
+// against 114.9 (the extra instructions and LDS round trips cost more than the fourth wave gives).  tools/ubench_chain.hip
+// shows what the issue rate of v_mad_u64_u32 does with the waves on a SIMD - 1: 17 T, 2: 34 T, 3: 28 T, 4+: 35-36 T
+// lane-operations/s, whatever the number of independent chains - but this kernel sits at 0.79-0.80 of its per-class
+// issue floor at two, three and four waves alike: what it loses is lost per instruction, not to occupancy.
+#ifdef CAP_ACC_WAVES  // experiments: occupancy the compiler budgets registers for
+#define CAP_ACC_ATTR __attribute__((amdgpu_waves_per_eu(CAP_ACC_WAVES, CAP_ACC_WAVES)))
+#else
+#define CAP_ACC_ATTR
+#endif
+__global__ __launch_bounds__(kThreads) CAP_ACC_ATTR void msm_accumulate(const g1_affine* __restrict__ ext,
                                                            const uint32_t* __restrict__ sorted,
                                                            const uint32_t* __restrict__ counts,
                                                            const uint32_t* __restrict__ offsets,
@@ -923,6 +934,7 @@ __global__ __launch_bounds__(kThreads) void msm_accumulate(const g1_affine* __re
   if (items == 1) buckets[gb] = G1L::store(acc);
   else item_pts[item_base[b] + item_off[gb] + j] = G1L::store(acc);
 }
+
 
 // ---- K6: bucket reduction by running sums ------------------------------------------------------------------
 // sum_j (j + 1) B_j.  One thread per segment of seg_len consecutive buckets walks it from the top with S += B_j,
@@ -1566,6 +1578,14 @@ const char* msm_plan_describe(const MsmBases& bases, size_t n, uint32_t batch, c
 }
 
 namespace {
+// Dynamic LDS msm_accumulate is launched with - not to use it, but to set how many of its workgroups a CU holds
+// (experiments: CAPGPU_ACC_LDS).
+size_t accumulate_lds_bytes() {
+  const char* e = getenv("CAPGPU_ACC_LDS");
+  const long x = e ? atol(e) : 0;
+  return (size_t)(x >= 0 && x <= 65536 ? x : 0);
+}
+
 // K5 + K6 over `sb` batch entries of `half` buckets each: work items, accumulation, bucket reduction.  One result per
 // entry goes to out (Jacobian), out_part (XYZZ: parts of a longer MSM) or out_pair (XYZZ (sum, weighted sum): entries
 // that are slices of one bucket set).
@@ -1591,8 +1611,8 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
   launch("msm_sort_items", msm_sort_items, dim3(sb), dim3(1024), 0, stream, (const uint32_t*)t.counts,
          (const uint32_t*)t.item_base, half, item_len, t.item_bucket, t.item_sub);
   if (t.max_items > 0) {
-    launch("msm_accumulate", msm_accumulate, dim3((unsigned)((t.max_items + kThreads - 1) / kThreads)), dim3(kThreads), 0,
-           stream, t.ext, (const uint32_t*)t.sorted, (const uint32_t*)t.counts, (const uint32_t*)t.offsets,
+    launch("msm_accumulate", msm_accumulate, dim3((unsigned)((t.max_items + kThreads - 1) / kThreads)), dim3(kThreads),
+           accumulate_lds_bytes(), stream, t.ext, (const uint32_t*)t.sorted, (const uint32_t*)t.counts, (const uint32_t*)t.offsets,
            (const uint32_t*)t.item_off, (const uint32_t*)t.item_base, (const uint32_t*)t.item_bucket,
            (const uint32_t*)t.item_sub, t.per, half, sb, item_len, t.item_pts, t.buckets);
   }
