@@ -892,7 +892,9 @@ __global__ __launch_bounds__(1024) void msm_sort_items(const uint32_t* __restric
 // against 114.9 (the extra instructions and LDS round trips cost more than the fourth wave gives).  tools/ubench_chain.hip
 // shows what the issue rate of v_mad_u64_u32 does with the waves on a SIMD - 1: 17 T, 2: 34 T, 3: 28 T, 4+: 35-36 T
 // lane-operations/s, whatever the number of independent chains - but this kernel sits at 0.79-0.80 of its per-class
-// issue floor at two, three and four waves alike: what it loses is lost per instruction, not to occupancy.
+// issue floor at two, three and four waves alike, and a two-stage software pipeline of its gathers (list entry two steps
+// ahead, table point one ahead: 168 VGPRs) changes nothing at three waves nor at two (119.6 vs 119.4, 121.5 vs 122.1 ms):
+// what it loses is lost per instruction, not to occupancy or memory latency.
 #ifdef CAP_ACC_WAVES  // experiments: occupancy the compiler budgets registers for
 #define CAP_ACC_ATTR __attribute__((amdgpu_waves_per_eu(CAP_ACC_WAVES, CAP_ACC_WAVES)))
 #else
@@ -926,15 +928,14 @@ __global__ __launch_bounds__(kThreads) CAP_ACC_ATTR void msm_accumulate(const g1
   // addition on the common path).
   for (uint32_t e = lo; e < hi; e++) {
     const uint32_t v = lst[e];
-    const g1a q = G1L::load(ext[v & 0x7FFFFFFFu]);
+    const g1a pt = G1L::load(ext[v & 0x7FFFFFFFu]);
     const bool negate = (v >> 31) != 0;
-    if (__builtin_expect(G1L::is_inf(q) || !G1L::madd_acc(acc, q, negate), 0)) acc = G1L::add_mixed(acc, q, negate);
+    if (__builtin_expect(G1L::is_inf(pt) || !G1L::madd_acc(acc, pt, negate), 0)) acc = G1L::add_mixed(acc, pt, negate);
   }
   // a bucket made of a single item is final: it goes straight to the bucket array and msm_combine skips it
   if (items == 1) buckets[gb] = G1L::store(acc);
   else item_pts[item_base[b] + item_off[gb] + j] = G1L::store(acc);
 }
-
 
 // ---- K6: bucket reduction by running sums ------------------------------------------------------------------
 // sum_j (j + 1) B_j.  One thread per segment of seg_len consecutive buckets walks it from the top with S += B_j,
