@@ -258,7 +258,10 @@ int capgpu_plonk_set_coalescing(uint32_t window_us, uint32_t max_batch);
 /* device batches run and proofs made through the coalescer so far */
 int capgpu_plonk_coalescing_stats(uint64_t* batches_out, uint64_t* proofs_out);
 /* Same, `count` independent proofs under one key pipelined on the device; per-proof arrays are
- * consecutive (wires: count * 5 * n, pub_inputs: count * num_inputs, blinders: count * 13). */
+ * consecutive (wires: count * 5 * n, pub_inputs: count * num_inputs, blinders: count * 13).  With several device
+ * contexts bound (capgpu_init) and a calling thread that did not bind itself to one, the batch is cut into contiguous
+ * parts of at least CAPGPU_DEAL_MIN (default 8) proofs, one per context, proved concurrently; the proofs are those of the
+ * undivided call.  On failure the first failing part's code and message are returned and proofs_out is unspecified. */
 int capgpu_plonk_prove_batch(uint64_t pk_handle, int count, const uint64_t* wires, const uint64_t* pub_inputs,
                              size_t num_inputs, const uint8_t* ext_msg, size_t ext_msg_len,
                              const uint64_t* blinders, capgpu_proof* proofs_out);
