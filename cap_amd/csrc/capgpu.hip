@@ -349,6 +349,8 @@ int clone_srs_to_current(const SrsEntry& src, std::shared_ptr<SrsEntry>* out) {
   e->gamma_pts = src.gamma_pts;
   e->neg_h = src.neg_h;
   e->ck_gamma_pts = src.ck_gamma_pts;
+  e->ck_gamma_g = src.ck_gamma_g;
+  e->has_ck_gamma_g = src.has_ck_gamma_g;
   MsmBases& b = e->bases;
   b.n = src.bases.n;
   b.c = src.bases.c;

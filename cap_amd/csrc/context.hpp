@@ -47,6 +47,9 @@ struct SrsEntry {
   // CommitKey::powers_of_gamma_g of a ProvingKey blob (a Vec<G1>, degrees 0, 1, ...): only capgpu_plonk_key_deserialize
   // fills it, only capgpu_plonk_key_serialize reads it
   std::vector<uint8_t> ck_gamma_pts;
+  // the open key's gamma_g of that blob (affine, Montgomery words; valid when has_ck_gamma_g)
+  g1_affine ck_gamma_g{};
+  bool has_ck_gamma_g = false;
   SrsEntry() = default;
   SrsEntry(const SrsEntry&) = delete;
   SrsEntry& operator=(const SrsEntry&) = delete;

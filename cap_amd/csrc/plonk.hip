@@ -996,8 +996,23 @@ int capgpu_plonk_key_serialize(uint64_t pk_handle, const uint64_t gamma_g[8], co
     if (!params::g1_decompress_host(ck.data(), &g0)) return CAPGPU_ERR_SERIALIZATION;
     ok.g = g0;
   }
+  // open key's gamma_g: the caller's, else what the blob this key (or its SRS) was loaded from held - the key blob's own
+  // value, or degree 0 of a UniversalSrs's hiding powers - else infinity (a synthetic SRS has none)
   ok.gamma_g.x = ok.gamma_g.y = Fq::zero();
-  if (gamma_g) ok.gamma_g = params::g1_from_words(gamma_g);
+  if (gamma_g) {
+    ok.gamma_g = params::g1_from_words(gamma_g);
+  } else if (const SrsEntry* Eg = find_srs_entry(K->srs_handle)) {
+    if (Eg->has_ck_gamma_g) {
+      ok.gamma_g = Eg->ck_gamma_g;
+    } else {
+      for (size_t i = 0; i < Eg->gamma_deg.size(); i++)
+        if (Eg->gamma_deg[i] == 0) {
+          g1_affine g0;
+          if (params::g1_decompress_host(&Eg->gamma_pts[32 * i], &g0)) ok.gamma_g = g0;
+          break;
+        }
+    }
+  }
   ok.h = params::g2_from_words(h);
   ok.beta_h = params::g2_from_words(beta_h);
   params::write_vk(w, K->vk, ok);
@@ -1079,7 +1094,11 @@ int capgpu_plonk_key_deserialize(const uint8_t* bytes, size_t len, uint64_t* srs
     if (rc == CAPGPU_OK) rc = params::decompress_g1(ck, n_ck, d_ck, s);
     if (rc == CAPGPU_OK) rc = register_srs(d_ck, n_ck, &srs_handle);
     if (rc) return rc;
-    if (SrsEntry* E = find_srs_entry(srs_handle)) E->ck_gamma_pts.assign(gamma, gamma + 32 * n_gamma);
+    if (SrsEntry* E = find_srs_entry(srs_handle)) {
+      E->ck_gamma_pts.assign(gamma, gamma + 32 * n_gamma);
+      E->ck_gamma_g = ok.gamma_g;
+      E->has_ck_gamma_g = true;
+    }
   }
   auto K = std::make_shared<ProvingKey>();
   auto bail = [&](int code) {

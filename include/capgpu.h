@@ -351,7 +351,9 @@ int capgpu_srs_serialize(uint64_t handle, const uint64_t h[16], const uint64_t b
 /* jf-plonk VerifyingKey blob (store_/load_*_verifying_key, src/parameters.rs:190-241, 314-362, 438-478) without
  * the note-shape trailer the Transfer/Mint/Freeze wrappers append (src/proof/transfer.rs:83-94); host only.
  * g, gamma_g: the G1 part of the open key (gamma_g may be NULL on serialize = infinity: commitments here are
- * non-hiding and neither prover nor verifier reads it). */
+ * non-hiding and neither prover nor verifier reads it).  capgpu_plonk_key_serialize with gamma_g == NULL writes the
+ * gamma_g of the blob the key - or the UniversalSrs it was preprocessed under (degree 0 of its hiding powers) - was
+ * loaded from, so that load -> store gives the file back; infinity for a synthetic SRS. */
 int capgpu_plonk_vk_serialize(const capgpu_verifying_key* vk, const uint64_t g[8], const uint64_t gamma_g[8],
                               const uint64_t h[16], const uint64_t beta_h[16], uint8_t* out, size_t cap,
                               size_t* len_out);

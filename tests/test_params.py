@@ -339,10 +339,18 @@ def test_hiding_powers_of_a_loaded_srs_in_key_blobs(cg, tau):
         cg.plonk_free_key(pk)
         cg.srs_free(h)
     plain = pm.deserialize_proving_key(bytes.fromhex(G["proving_key"]))
-    want_full = pm.serialize_proving_key(plain["sigmas"], plain["selectors"], plain["powers_of_g"], bytes.fromhex(G["vk"]),
+    v = pm.read_verifying_key(pm.Reader(bytes.fromhex(G["vk"])))
+
+    def vk_bytes(gamma_g):                                       # the open key's gamma_g = degree 0 of the hiding powers
+        return pm.serialize_verifying_key(v["domain_size"], v["num_inputs"], v["sigma_comms"], v["selector_comms"], v["k"],
+                                          v["g"], gamma_g, v["h"], v["beta_h"])
+
+    want_full = pm.serialize_proving_key(plain["sigmas"], plain["selectors"], plain["powers_of_g"], vk_bytes(gamma_full[0]),
                                          gamma_powers=[gamma_full[d] for d in range(n_ck)])
     assert key_blob["full"] == want_full                        # degrees 0 .. n + 2, in order
-    assert key_blob["sparse"] == bytes.fromhex(G["proving_key"])  # a map with holes: no hiding powers, not two of them
+    # a map with holes: no hiding powers in the commit key - not two of them - but the open key's gamma_g is degree 0
+    assert key_blob["sparse"] == pm.serialize_proving_key(plain["sigmas"], plain["selectors"], plain["powers_of_g"],
+                                                          vk_bytes(sparse[0]))
     # trimmed load: powers_of_g cut to max_degree + 1, the map to the degrees a setup of that size holds
     blob = pm.serialize_universal_params(pts, gamma_full, o["h"], o["beta_h"], {})
     h, hh, bh, _ = cg.srs_deserialize(blob, max_degree=19)

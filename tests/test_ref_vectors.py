@@ -207,6 +207,18 @@ def test_ref_params_gpu(cg):
     assert used == len(kb) and cg.plonk_key_serialize(pk_h, h2, bh2) == kb
     cg.plonk_free_key(pk_h)
     cg.srs_free(srs_h)
+    # ... and the other way round: the reference's UniversalSrs loaded, the reference's circuit (its tables travel in
+    # ref_proof.json) preprocessed under it, the key stored - the reference's own ProvingKey bytes, hiding powers
+    # (CommitKey::powers_of_gamma_g: degrees 0 .. n + 2 of the SRS's map) and the open key's gamma_g included
+    gp = ref("ref_proof.json")
+    n = 1 << gp["log_n"]
+    h, hh, bh, _ = cg.srs_deserialize(blob)
+    sel = bu.to_mont_array([fr(v) for col in gp["selectors"] for v in col]).reshape(13, n, 4)
+    sig = bu.to_mont_array([fr(v) for col in gp["sigma"] for v in col]).reshape(5, n, 4)
+    pk2, _vk2 = cg.plonk_preprocess(h, n, gp["num_inputs"], sel, sig)
+    assert cg.plonk_key_serialize(pk2, hh, bh) == kb
+    cg.plonk_free_key(pk2)
+    cg.srs_free(h)
 
 
 # ---- the consumers themselves, exercised on stand-ins made by this repository's oracle -------------------------------
@@ -239,10 +251,14 @@ def _stand_ins(directory):
              "wire_sigma_evals": [hx(v) for v in p.wire_sigma_evals], "perm_next_eval": hx(p.perm_next_eval)}
     powers = [bn.g1_mul(bn.G1_GEN, pow(tau, i, bn.R)) for i in range(sc.n + 3)]
     h, beta_h = pr2.G2_GEN, pr2.g2_mul(pr2.G2_GEN, tau)
-    vkb = pm.serialize_verifying_key(sc.n, 2, pk.sigma_comms, pk.selector_comms, pl.K, powers[0], bn.INF, h, beta_h)
+    # hiding powers [gamma tau^i] G for degrees 0 .. max_degree + 1, as ark-poly-commit's KZG10 setup makes them
+    gamma = bn.SplitMix64(0x6A).field(bn.R)
+    gmap = {i: bn.g1_mul(bn.G1_GEN, gamma * pow(tau, i, bn.R) % bn.R) for i in range(sc.n + 4)}
+    vkb = pm.serialize_verifying_key(sc.n, 2, pk.sigma_comms, pk.selector_comms, pl.K, powers[0], gmap[0], h, beta_h)
     params = {"log_n": 4, "num_inputs": 2, "tau": hx(tau),
-              "srs": pm.serialize_universal_params(powers, {}, h, beta_h, {}).hex(), "vk": vkb.hex(),
-              "proving_key": pm.serialize_proving_key(pk.sigma_polys, pk.selector_polys, powers, vkb).hex()}
+              "srs": pm.serialize_universal_params(powers, gmap, h, beta_h, {}).hex(), "vk": vkb.hex(),
+              "proving_key": pm.serialize_proving_key(pk.sigma_polys, pk.selector_polys, powers, vkb,
+                                                      gamma_powers=[gmap[i] for i in range(sc.n + 3)]).hex()}
     for name, data in (("ref_msm.json", msm), ("ref_ntt.json", ntt), ("ref_proof.json", proof), ("ref_params.json", params)):
         with open(os.path.join(directory, name), "w") as f:
             json.dump(data, f)
@@ -254,6 +270,18 @@ def test_consumers_accept_oracle_made_stand_ins(tmp_path):
     check_ntt_cpu(ref("ref_ntt.json", str(tmp_path)))
     check_proof_cpu(ref("ref_proof.json", str(tmp_path)))
     check_params_cpu(ref("ref_params.json", str(tmp_path)))
+
+
+@pytest.mark.gpu
+def test_gpu_consumers_accept_oracle_made_stand_ins(cg, tmp_path, monkeypatch):
+    """the -m gpu consumers above, run on stand-in files of the reference tool's format (made by this repository's
+    oracle): they execute today, and turn into the pin the day the real files exist"""
+    _stand_ins(str(tmp_path))
+    monkeypatch.setenv("CAP_REF_VECTOR_DIR", str(tmp_path))
+    test_ref_msm_gpu(cg)
+    test_ref_ntt_gpu(cg)
+    test_ref_proof_gpu(cg)
+    test_ref_params_gpu(cg)
 
 
 def test_unpinned_status_is_reported():

@@ -137,10 +137,20 @@ fn known_tau_srs(tau: Fr, max_degree: usize) -> UniversalSrs<Bn254> {
         x *= tau;
     }
     let beta_h = h.mul(tau.into_repr()).into_affine();
+    // hiding powers [gamma tau^i] G for degrees 0 ..= max_degree + 1, as KZG10::setup fills the map: jf-plonk's
+    // preprocess trims them into CommitKey::powers_of_gamma_g by degree (an empty map would panic there), and the
+    // consumer checks that capgpu_plonk_key_serialize emits exactly that vector for a key made under the loaded SRS
+    let gamma = SplitMix64(0x6A).field();
+    let mut powers_of_gamma_g = BTreeMap::new();
+    let mut y = gamma;
+    for i in 0..=(max_degree + 1) {
+        powers_of_gamma_g.insert(i, g.mul(y.into_repr()).into_affine());
+        y *= tau;
+    }
     // [DEP-RECALLED] field names of ark_poly_commit::kzg10::UniversalParams
     UniversalSrs::<Bn254> {
         powers_of_g: powers,
-        powers_of_gamma_g: BTreeMap::new(),
+        powers_of_gamma_g,
         h,
         beta_h,
         neg_powers_of_h: BTreeMap::new(),
