@@ -32,7 +32,7 @@ for name, out_name in (("bench_single_process.json", f"bench_single_process_dev0
 shutil.copy(os.path.join(src, "traffic.json"), os.path.join(dst, f"traffic_{rnd}.json"))
 shutil.copy(os.path.join(src, "pytest_gpu.txt"), os.path.join(dst, f"pytest_gpu_{rnd}_final.txt"))
 w2 = [open(os.path.join(src, n)).read().strip() for n in ("bench_w2.json", "bench_w2_mixed.json")]
-open(os.path.join(dst, f"bench_world2_gloo_sameGPU_{rnd}.json"), "w").write("\n".join(w2) + "\n")
+open(os.path.join(dst, f"bench_world2_gloo_sameGPU_{rnd}.jsonl"), "w").write("\n".join(w2) + "\n")
 os.makedirs(os.path.join(dst, "rocprof_" + rnd), exist_ok=True)
 shutil.copy(os.path.join(prof, "summary.txt"), os.path.join(dst, "rocprof_" + rnd, "summary.txt"))
 stats = glob.glob(os.path.join(prof, "trace", "**", "*kernel_stats.csv"), recursive=True)
