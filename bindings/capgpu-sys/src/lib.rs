@@ -76,6 +76,7 @@ extern "C" {
     pub fn capgpu_srs_upload(bases: *const c_void, n: usize, stride_bytes: usize, coords_montgomery: c_int,
                              handle_out: *mut u64) -> c_int;
     pub fn capgpu_srs_generate(tau: *const u64, n: usize, handle_out: *mut u64) -> c_int;
+    pub fn capgpu_srs_generate_hiding(tau: *const u64, gamma: *const u64, n: usize, handle_out: *mut u64) -> c_int;
     pub fn capgpu_srs_generate_affine_seq(a: *const u64, b: *const u64, n: usize, handle_out: *mut u64) -> c_int;
     pub fn capgpu_srs_size(handle: u64, n_out: *mut usize) -> c_int;
     pub fn capgpu_srs_shards(handle: u64, shards_out: *mut c_int) -> c_int;

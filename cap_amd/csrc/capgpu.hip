@@ -14,6 +14,7 @@
 #include "context.hpp"
 #include "curve29.hpp"
 #include "launch.hpp"
+#include "params.hpp"
 
 namespace cap {
 
@@ -197,6 +198,11 @@ __global__ void fr_powers_kernel(fe* out, size_t n, const fe* __restrict__ pw, s
     }
   }
   *dst = r;
+}
+
+__global__ void fr_scale_kernel(fe* data, size_t count, fe factor_mont) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < count) data[i] = Fr::mul(data[i], factor_mont);
 }
 
 __global__ void fq_to_mont_kernel(fe* data, size_t count) {
@@ -947,6 +953,64 @@ int capgpu_srs_generate(const uint64_t tau[4], size_t n, uint64_t* handle_out) {
 int capgpu_srs_generate_affine_seq(const uint64_t a[4], const uint64_t b[4], size_t n, uint64_t* handle_out) {
   if (!b) return CAPGPU_ERR_INVALID_ARG;
   return srs_generate_common(1, a, b, n, handle_out);
+}
+
+// universal_setup with hiding powers (src/proof/mod.rs:59-69 -> KZG10::setup): besides [tau^i] G the SRS carries
+// powers_of_gamma_g = { i: [gamma tau^i] G } for degrees 0 ..= max_degree + 1 (n + 1 entries for n powers), which
+// capgpu_srs_serialize writes and jf-plonk's trim reads when a reference-side consumer preprocesses under the stored file.
+int capgpu_srs_generate_hiding(const uint64_t tau[4], const uint64_t gamma[4], size_t n, uint64_t* handle_out) {
+  CAP_CHECK_INIT();
+  if (!tau || !gamma || !handle_out || n == 0) {
+    set_error("capgpu_srs_generate_hiding: bad argument");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  if (should_shard(n)) {
+    set_error("capgpu_srs_generate_hiding: %zu points would be sharded over the devices; hiding powers belong to a commit-key "
+              "sized SRS", n);
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  Context& c = ctx();
+  Entry lk(c);
+  uint64_t h = 0;
+  int rc = capgpu_srs_generate(tau, n, &h);
+  if (rc) return rc;
+  auto fail = [&](int code) {
+    (void)hipStreamSynchronize(c.stream);
+    c.srs.erase(h);
+    std::lock_guard<std::mutex> rlk(rt().mu);
+    rt().srs.erase(h);
+    return code;
+  };
+  const size_t m = n + 1;
+  DevTmp<fe> d_pw, d_tab;
+  DevTmp<g1_affine> d_pts;
+  hipError_t e = d_pw.alloc(64);
+  if (e == hipSuccess) e = d_tab.alloc(m);
+  if (e == hipSuccess) e = d_pts.alloc(m);
+  if (e != hipSuccess) return fail(hip_fail(e, "hipMalloc"));
+  std::vector<fe> pw(64);
+  const fe tm = Fr::to_mont(fe_from_u64x4(tau)), gm = Fr::to_mont(fe_from_u64x4(gamma));
+  fe x = tm;
+  for (int i = 0; i < 64; i++) {
+    pw[i] = x;
+    x = Fr::sqr(x);
+  }
+  e = hipMemcpyAsync(d_pw, pw.data(), sizeof(fe) * 64, hipMemcpyHostToDevice, c.stream);
+  if (e != hipSuccess) return fail(hip_fail(e, "hipMemcpyAsync"));
+  const unsigned blocks = (unsigned)((m + 255) / 256);
+  launch("fr_powers_kernel", fr_powers_kernel, dim3(blocks), dim3(256), 0, c.stream, d_tab.p, m, (const fe*)d_pw.p, (size_t)0);
+  launch("fr_scale_kernel", fr_scale_kernel, dim3(blocks), dim3(256), 0, c.stream, d_tab.p, m, gm);
+  launch("srs_fixed_base_kernel", srs_fixed_base_kernel, dim3(blocks), dim3(256), 0, c.stream, d_pts.p, m, 0,
+         (const fe*)d_tab.p, tm, Fr::zero(), (size_t)0);
+  std::vector<uint8_t> bytes(32 * m);
+  if ((rc = params::compress_g1(d_pts, 0, m, bytes.data(), c.stream))) return fail(rc);
+  if ((rc = take_launch_error())) return fail(rc);
+  SrsEntry* E = find_srs_entry(h);
+  E->gamma_deg.resize(m);
+  for (size_t i = 0; i < m; i++) E->gamma_deg[i] = i;
+  E->gamma_pts = std::move(bytes);
+  *handle_out = h;
+  return CAPGPU_OK;
 }
 
 int capgpu_srs_size(uint64_t handle, size_t* n_out) {

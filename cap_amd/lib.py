@@ -181,6 +181,12 @@ def srs_generate(tau: int, n: int) -> int:
     return h.value
 
 
+def srs_generate_hiding(tau: int, gamma: int, n: int) -> int:
+    h = ctypes.c_uint64()
+    check(load().capgpu_srs_generate_hiding(_limbs(tau), _limbs(gamma), ctypes.c_size_t(n), ctypes.byref(h)))
+    return h.value
+
+
 def srs_generate_affine_seq(a: int, b: int, n: int) -> int:
     h = ctypes.c_uint64()
     check(load().capgpu_srs_generate_affine_seq(_limbs(a), _limbs(b), ctypes.c_size_t(n), ctypes.byref(h)))

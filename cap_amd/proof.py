@@ -101,13 +101,17 @@ def compute_universal_param_size(note_type: str, num_inputs: int, num_outputs: i
             "universal_param_size_for_gates instead") from None
 
 
-def universal_setup(max_degree: int, tau: int) -> UniversalSrs:
-    """SRS [tau^i] G for i <= max_degree, generated and kept on the device.
-    (The reference samples tau from its rng; benches use test_rng, benches/transfer.rs:71.)"""
+def universal_setup(max_degree: int, tau: int, gamma: int | None = None) -> UniversalSrs:
+    """SRS [tau^i] G for i <= max_degree, generated and kept on the device.  With `gamma`, also the hiding powers
+    [gamma tau^i] G for i <= max_degree + 1 that KZG10::setup produces (they travel with stored files; the prover's
+    commitments do not use them).  (The reference samples tau - and gamma - from its rng; benches use test_rng,
+    benches/transfer.rs:71.)"""
     try:
         _lib.init()
         h = _lib.g2_generator()
-        return UniversalSrs(_lib.srs_generate(tau, max_degree + 1), max_degree, h, _lib.g2_mul(h, tau))
+        handle = _lib.srs_generate(tau, max_degree + 1) if gamma is None else \
+            _lib.srs_generate_hiding(tau, gamma, max_degree + 1)
+        return UniversalSrs(handle, max_degree, h, _lib.g2_mul(h, tau))
     except _lib.CapGpuError as e:
         raise TxnApiError.FailedSnark(f"Failed to generate universal SRS: {e}") from e
 

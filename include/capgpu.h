@@ -127,6 +127,11 @@ int capgpu_srs_upload(const void* bases, size_t n, size_t stride_bytes, int coor
  * universal_setup(max_degree, rng) (src/proof/mod.rs:59-69) for benches without the Aztec file.
  * tau: canonical Fr integer. */
 int capgpu_srs_generate(const uint64_t tau[4], size_t n, uint64_t* handle_out);
+/* The same with the hiding powers a KZG10 setup also produces: powers_of_gamma_g = { i: [gamma tau^i] G } for degrees
+ * 0 .. n (max_degree + 1), kept with the handle, written by capgpu_srs_serialize and - by degree - into the commit key of
+ * every proving key preprocessed under it (capgpu_plonk_key_serialize).  The prover's commitments stay non-hiding, as
+ * jf-plonk's are; the powers exist so that the stored files are what a reference-side consumer expects. */
+int capgpu_srs_generate_hiding(const uint64_t tau[4], const uint64_t gamma[4], size_t n, uint64_t* handle_out);
 /* bases[i] = [a + i*b] G (canonical Fr integers) - synthetic bases for the 2^24 scaling config */
 int capgpu_srs_generate_affine_seq(const uint64_t a[4], const uint64_t b[4], size_t n, uint64_t* handle_out);
 int capgpu_srs_size(uint64_t handle, size_t* n_out);

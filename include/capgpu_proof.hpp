@@ -147,11 +147,14 @@ namespace proof {
 
 // src/proof/mod.rs:59-69.  The reference samples tau from its rng (benches: test_rng); here the caller passes it
 // (canonical words) - the SRS is generated on the device.
-inline Result<UniversalSrs> universal_setup(size_t max_degree, const Fr& tau) {
+// `gamma`, when given, also produces the hiding powers [gamma tau^i] G, i <= max_degree + 1, that KZG10::setup samples
+// next to tau: they travel with stored parameter files and keys; the prover does not use them.
+inline Result<UniversalSrs> universal_setup(size_t max_degree, const Fr& tau, const Fr* gamma = nullptr) {
   int rc = capgpu_init(nullptr, 0);
   if (rc != CAPGPU_OK) return detail::map_error(rc, "Failed to generate universal SRS");
   uint64_t h = 0;
-  rc = capgpu_srs_generate(tau.data(), max_degree + 1, &h);
+  rc = gamma ? capgpu_srs_generate_hiding(tau.data(), gamma->data(), max_degree + 1, &h)
+             : capgpu_srs_generate(tau.data(), max_degree + 1, &h);
   if (rc != CAPGPU_OK) return detail::map_error(rc, "Failed to generate universal SRS");
   UniversalSrs s;
   s.powers_of_g = std::make_shared<detail::SrsHandle>(h);

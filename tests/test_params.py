@@ -361,6 +361,41 @@ def test_hiding_powers_of_a_loaded_srs_in_key_blobs(cg, tau):
 
 
 @pytest.mark.gpu
+def test_generated_srs_with_hiding_powers(cg, tau):
+    """universal_setup(max_degree, tau, gamma): powers_of_gamma_g = { i: [gamma tau^i] G, i <= max_degree + 1 } like
+    KZG10::setup's (src/proof/mod.rs:59-69); stored with the SRS and - by degree - with every key preprocessed under it."""
+    import oracle.bn254 as bn
+    gamma = 0x1D2C3B4A5968778695A4B3C2D1E0F11223344556677889900AABBCCDDEEFF01 % bn.R
+    max_degree = 34
+    srs = capproof.universal_setup(max_degree, tau, gamma)
+    plain = capproof.universal_setup(max_degree, tau)
+    o = pm.deserialize_universal_params(prm.serialize_universal_parameter(srs))
+    assert o["powers_of_g"] == pm.deserialize_universal_params(prm.serialize_universal_parameter(plain))["powers_of_g"]
+    assert sorted(o["powers_of_gamma_g"]) == list(range(max_degree + 2))
+    for d in (0, 1, 2, 17, max_degree, max_degree + 1):
+        assert o["powers_of_gamma_g"][d] == bn.g1_mul(bn.G1_GEN, gamma * pow(tau, d, bn.R) % bn.R)
+    # the oracle's own setup gives the same file
+    want = pm.serialize_universal_params(o["powers_of_g"],
+                                         {d: bn.g1_mul(bn.G1_GEN, gamma * pow(tau, d, bn.R) % bn.R)
+                                          for d in range(max_degree + 2)}, o["h"], o["beta_h"], {})
+    assert prm.serialize_universal_parameter(srs) == want
+    # a key preprocessed under it: commit key = degrees 0 .. n + 2 of both vectors, open key's gamma_g = degree 0
+    g = H.load_golden("proof_log5.json")
+    sc = bu.synthetic_circuit(g["log_n"], g["num_inputs"], seed=g["circuit_seed"])
+    pk, vk, _ = capproof.preprocess(srs, sc.n, sc.num_inputs, sc.selectors_mont(), sc.sigma_mont())
+    k = pm.deserialize_proving_key(prm.serialize_proving_key(pk))
+    assert k["powers_of_gamma_g"] == [o["powers_of_gamma_g"][d] for d in range(sc.n + 3)]
+    assert k["vk"]["gamma_g"] == o["powers_of_gamma_g"][0]
+    # ... and proofs are the same as under the plain SRS: commitments stay non-hiding
+    w, pubs = sc.witness(g["witness_seed"])
+    bl = bu.to_mont_array(bu.blinders(g["blinder_seed"]))
+    pa = bu.to_mont_array(pubs)
+    p = capproof.prove(pk, sc.wires_mont(w), pa, bl, g["ext_msg"].encode())
+    assert H.proof_points(p)[0][:5] == [H.unhex_pt(q) for q in g["wires_poly_comms"]]
+    capproof.verify(vk, pa, p, g["ext_msg"].encode())
+
+
+@pytest.mark.gpu
 def test_load_srs_mirror(cg, tau):
     """capproof.load_srs (src/proof/mod.rs:74-109) on this SRS's own ark-serialize bytes: the whole file is loaded."""
     import hashlib
