@@ -268,6 +268,9 @@ __global__ __launch_bounds__(256) void ubench_mad_kernel(uint64_t* io, int iters
 // independent dependency chains per lane, 8 waves per SIMD - so that the classes are compared at equal occupancy.
 //   0 v_mad_u64_u32   1 v_add_u32   2 v_and_b32   3 v_mov_b32   4 v_lshl_add_u64   5 v_lshrrev_b64   6 v_alignbit_b32
 //   7 v_mul_lo_u32
+//   8 the mixed stream of a column-wise Montgomery product: three multiply-adds, then one plain instruction (and / add
+//     alternating) - msm_accumulate's common path is 1558 : 563.  Is a mix issued in the sum of its classes' own times?
+//     (rates_out[9] is the same kernel held to three waves per SIMD, msm_accumulate's occupancy.)
 template <int CLS>
 __global__ __launch_bounds__(256) void ubench_issue_kernel(uint64_t* io, int iters) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -308,9 +311,18 @@ __global__ __launch_bounds__(256) void ubench_issue_kernel(uint64_t* io, int ite
           uint32_t r;
           asm volatile("v_alignbit_b32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"((uint32_t)acc[c]), "v"(b & 31u));
           acc[c] = r;
-        } else {
+        } else if constexpr (CLS == 7) {
           uint32_t r;
           asm volatile("v_mul_lo_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"((uint32_t)acc[c]));
+          acc[c] = r;
+        } else if ((c & 3) != 3) {  // chains 0-2, 4-6: multiply-adds
+          uint64_t r, carry;
+          asm volatile("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(a), "v"(b + c), "v"(acc[c]));
+          acc[c] = r;
+        } else {  // chains 3 and 7: v_and_b32 / v_add_u32
+          uint32_t r;
+          if (c == 3) asm volatile("v_and_b32 %0, %1, %2" : "=v"(r) : "v"(a), "v"((uint32_t)acc[c]));
+          else asm volatile("v_add_u32 %0, %1, %2" : "=v"(r) : "v"(a), "v"((uint32_t)acc[c]));
           acc[c] = r;
         }
       }
@@ -1338,14 +1350,17 @@ int capgpu_ubench_issue_rates(double* rates_out, int count) {
   CAP_HIP(hipEventCreate(&e0));
   CAP_HIP(hipEventCreate(&e1));
   using Kern = void (*)(uint64_t*, int);
-  const Kern kerns[8] = {ubench_issue_kernel<0>, ubench_issue_kernel<1>, ubench_issue_kernel<2>, ubench_issue_kernel<3>,
-                         ubench_issue_kernel<4>, ubench_issue_kernel<5>, ubench_issue_kernel<6>, ubench_issue_kernel<7>};
-  for (int k = 0; k < count && k < 8; k++) {
-    hipLaunchKernelGGL(kerns[k], dim3(blocks), dim3(256), 0, c.stream, d.p, 10);  // warm-up
+  const Kern kerns[10] = {ubench_issue_kernel<0>, ubench_issue_kernel<1>, ubench_issue_kernel<2>, ubench_issue_kernel<3>,
+                          ubench_issue_kernel<4>, ubench_issue_kernel<5>, ubench_issue_kernel<6>, ubench_issue_kernel<7>,
+                          ubench_issue_kernel<8>, ubench_issue_kernel<8>};
+  for (int k = 0; k < count && k < 10; k++) {
+    // 52 KiB of dynamic LDS per 4-wave workgroup: three workgroups per CU = three waves per SIMD
+    const size_t lds = k == 9 ? 52 * 1024 : 0;
+    hipLaunchKernelGGL(kerns[k], dim3(blocks), dim3(256), lds, c.stream, d.p, 10);  // warm-up
     double best = 0;
     for (int rep = 0; rep < 3; rep++) {
       hipEventRecord(e0, c.stream);
-      hipLaunchKernelGGL(kerns[k], dim3(blocks), dim3(256), 0, c.stream, d.p, iters);
+      hipLaunchKernelGGL(kerns[k], dim3(blocks), dim3(256), lds, c.stream, d.p, iters);
       hipEventRecord(e1, c.stream);
       CAP_HIP(hipEventSynchronize(e1));
       float ms = 0;
@@ -1355,7 +1370,7 @@ int capgpu_ubench_issue_rates(double* rates_out, int count) {
     }
     rates_out[k] = best;
   }
-  for (int k = 8; k < count; k++) rates_out[k] = 0;
+  for (int k = 10; k < count; k++) rates_out[k] = 0;
   hipEventDestroy(e0);
   hipEventDestroy(e1);
   (void)hipGetLastError();

@@ -162,6 +162,9 @@ struct G1LT {
     const fl s2 = F::mul(qy, a.zzz);
     const fl p = F::sub(u2, a.x);
     if (F::is_zero(p)) return false;
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("; madd_acc: common path");  // no instruction: tools/isa_mix.py finds the hot block by this line
+#endif
     const fl r = F::sub(s2, a.y);
     const fl pp = F::sqr(p);
     const fl ppp = F::mul(p, pp);

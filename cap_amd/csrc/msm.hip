@@ -1586,6 +1586,15 @@ size_t accumulate_lds_bytes() {
   const long x = e ? atol(e) : 0;
   return (size_t)(x >= 0 && x <= 65536 ? x : 0);
 }
+// Workgroup size of msm_accumulate (experiments: CAPGPU_ACC_THREADS = 64, 128 or 256)
+unsigned accumulate_threads() {
+  static const unsigned v = [] {
+    const char* e = getenv("CAPGPU_ACC_THREADS");
+    const long x = e ? atol(e) : 0;
+    return (unsigned)(x == 64 || x == 128 ? x : kThreads);
+  }();
+  return v;
+}
 
 // K5 + K6 over `sb` batch entries of `half` buckets each: work items, accumulation, bucket reduction.  One result per
 // entry goes to out (Jacobian), out_part (XYZZ: parts of a longer MSM) or out_pair (XYZZ (sum, weighted sum): entries
@@ -1612,7 +1621,8 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
   launch("msm_sort_items", msm_sort_items, dim3(sb), dim3(1024), 0, stream, (const uint32_t*)t.counts,
          (const uint32_t*)t.item_base, half, item_len, t.item_bucket, t.item_sub);
   if (t.max_items > 0) {
-    launch("msm_accumulate", msm_accumulate, dim3((unsigned)((t.max_items + kThreads - 1) / kThreads)), dim3(kThreads),
+    const unsigned at = accumulate_threads();
+    launch("msm_accumulate", msm_accumulate, dim3((unsigned)((t.max_items + at - 1) / at)), dim3(at),
            accumulate_lds_bytes(), stream, t.ext, (const uint32_t*)t.sorted, (const uint32_t*)t.counts, (const uint32_t*)t.offsets,
            (const uint32_t*)t.item_off, (const uint32_t*)t.item_base, (const uint32_t*)t.item_bucket,
            (const uint32_t*)t.item_sub, t.per, half, sb, item_len, t.item_pts, t.buckets);

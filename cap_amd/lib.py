@@ -353,7 +353,7 @@ def ubench_mad_rate() -> float:
 
 
 ISSUE_CLASSES = ("v_mad_u64_u32", "v_add_u32", "v_and_b32", "v_mov_b32", "v_lshl_add_u64", "v_lshrrev_b64",
-                 "v_alignbit_b32", "v_mul_lo_u32")
+                 "v_alignbit_b32", "v_mul_lo_u32", "mixed_3mad_1plain", "mixed_3mad_1plain_at_3_waves_per_simd")
 
 
 def ubench_issue_rates() -> dict:

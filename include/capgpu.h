@@ -384,7 +384,9 @@ int capgpu_plonk_key_deserialize(const uint8_t* bytes, size_t len, uint64_t* srs
 int capgpu_ubench_mad_rate(double* lane_ops_per_s_out);
 /* The same measurement for the instruction classes the hot kernels are made of, all at that occupancy and chain count,
  * in lane-operations per second: rates_out[0..count) = v_mad_u64_u32, v_add_u32, v_and_b32, v_mov_b32, v_lshl_add_u64,
- * v_lshrrev_b64, v_alignbit_b32, v_mul_lo_u32 (count <= 8; ~0.3 s).  bench.py prices a kernel's instruction mix
+ * v_lshrrev_b64, v_alignbit_b32, v_mul_lo_u32, then [8] a mixed stream - three multiply-adds, one plain instruction, the
+ * shape of a column-wise Montgomery product - at the same occupancy and [9] the same stream held to three waves per SIMD,
+ * msm_accumulate's occupancy (count <= 10; ~0.4 s).  bench.py prices a kernel's instruction mix
  * (profiles/isa_mix_r03.json) against them: issue_frac. */
 int capgpu_ubench_issue_rates(double* rates_out, int count);
 /* When enabled, every kernel launch is bracketed by HIP events on the launch stream and accumulated

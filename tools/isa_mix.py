@@ -40,23 +40,35 @@ with tempfile.TemporaryDirectory() as tmp:
     lines = open(asm).read().split("\n")
 start = [i for i, ln in enumerate(lines) if re.match(r"^_ZN3cap12_GLOBAL__N_114msm_accumulate.*:\s*", ln)][0]
 end = [i for i in range(start, len(lines)) if lines[i].strip().startswith(".Lfunc_end")][0]
+# basic blocks: branch targets (.LBBn_m:) and fall-through blocks ("; %bb.k:")
 blocks, cur = [], None
 for ln in lines[start:end]:
     s = ln.strip()
-    if re.match(r"^\.LBB\d+_\d+:", s):
-        cur = {"label": s.split(":")[0], "header": "Loop Header" in s, "ops": []}
+    if re.match(r"^\.LBB\d+_\d+:", s) or s.startswith("; %bb."):
+        cur = {"label": s.split(":")[0].replace("; ", ""), "header": "Loop Header: Depth=1" in s, "marked": False, "ops": []}
         blocks.append(cur)
+    elif cur is not None and "madd_acc: common path" in s:
+        cur["marked"] = True
     elif cur is not None and s and not s.startswith((".", ";", "//")):
         cur["ops"].append(s.split()[0])
-hot = max(blocks, key=lambda b: len(b["ops"]))
-header = [b for b in blocks if b["header"] and "Depth=1" in lines[start:end][0] or b["header"]][0]
+# The common path of one mixed addition, in layout order: the loop header and the small blocks after it (list entry,
+# 64-byte gather, unpack, sign), the block with the two products that feed the x-difference test (u2, s2), and the block
+# G1L::madd_acc marks with an asm comment - everything after the test.  (Round 3 took "the largest block" here, which is
+# the general addition G1L::add_mixed - the fallback for a bucket still at infinity - with 64 x 32-bit products that the
+# common path does not have.)
+ih = [i for i, b in enumerate(blocks) if b["header"]][0]
+im = [i for i, b in enumerate(blocks) if b["marked"]]
+assert len(im) == 1, "expected exactly one marked block in msm_accumulate"
+im = im[0]
+ip = max(i for i in range(ih, im) if sum(op.startswith("v_mad_u64") for op in blocks[i]["ops"]) >= 300)
+path = [b for b in blocks[ih:ip] if len(b["ops"]) < 150 and "v_mad_i64_i32" not in b["ops"]] + [blocks[ip], blocks[im]]
 mix = collections.Counter()
-for b in (header, hot):
+for b in path:
     for op in b["ops"]:
         mix[classify(op)] += 1
 valu = sum(v for k, v in mix.items() if k != "non_valu")
 out = {"kernel": "msm_accumulate", "source": "hipcc -S --cuda-device-only -O3 --offload-arch=gfx950 cap_amd/csrc/msm.hip (tools/isa_mix.py)",
-       "blocks": {header["label"]: len(header["ops"]), hot["label"]: len(hot["ops"])},
+       "blocks": {b["label"]: len(b["ops"]) for b in path},
        "what": "loop header (list entry, 64-byte gather, unpack, sign) + the inlined G1L::madd_acc: one mixed addition on "
                "the common path",
        "valu_instructions_per_mixed_addition": valu, "per_class": dict(mix)}
