@@ -16,6 +16,8 @@ MSM_LOGS=15,17,20,22,24 timeout 600 python tools/gpu_msm_profile.py > $O/msm_sin
 bash tools/gpuprof.sh $tag > $O/gpuprof.log 2>&1
 python tools/make_traffic.py gpurun_out/prof_$tag 256 $O/traffic.json > $O/traffic.log 2>&1
 bash tools/gpuprof_insts.sh $tag > $O/insts.txt 2>&1
+bash tools/gpuprof_clock.sh $tag > $O/clock.log 2>&1; cp gpurun_out/clock_$tag/clock.json $O/clock.json
+timeout 120 tools/ubench_mix.bin > $O/ubench_mix.txt 2>&1
 bash tools/gpujob_w2.sh > $O/w2.log 2>&1; cp gpurun_out/bench_w2.json $O/bench_w2.json; cp gpurun_out/bench_w2_mixed.json $O/bench_w2_mixed.json
 python - <<PY
 import json
