@@ -1,0 +1,38 @@
+"""The roofline bookkeeping bench.py relies on: the committed instruction mix of msm_accumulate's hot path must be priced
+by classes the library's issue-rate microbenchmark really measures, and that microbenchmark must behave on the device."""
+import json
+import os
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_isa_mix_classes_are_priced():
+    from cap_amd import lib as cg
+    mix = json.load(open(os.path.join(ROOT, "profiles", "isa_mix_r03.json")))
+    valu = {k: v for k, v in mix["per_class"].items() if k != "non_valu"}
+    assert set(valu) <= set(cg.ISSUE_CLASSES)                       # every class has a measured rate to be priced at
+    assert sum(valu.values()) == mix["valu_instructions_per_mixed_addition"]
+    # one XYZZ mixed addition = 6 products + 2 squarings + one fused pair of products on 9 x 29-bit limbs:
+    # 6 * 171 + 2 * 135 + 252 multiply-adds, a handful more in the gather / sign handling
+    assert 1548 <= valu["v_mad_u64_u32"] <= 1600
+    assert valu.get("v_mov_b32", 0) < 60                            # the general addition's 64 x 32-bit products are not in it
+    clock = json.load(open(os.path.join(ROOT, "profiles", "clock_r03.json")))["derived"]
+    assert 1.5 < clock["msm_accumulate"]["clock_GHz"] < 2.5 and 0.5 < clock["msm_accumulate"]["cu_busy_frac"] <= 1.02
+
+
+@pytest.mark.gpu
+def test_issue_rate_microbenchmark(monkeypatch):
+    from cap_amd import lib as cg
+    monkeypatch.setenv("CAPGPU_UBENCH_ITERS", "200")
+    cg.init()
+    r = cg.ubench_issue_rates()
+    assert list(r) == list(cg.ISSUE_CLASSES) and all(v > 0 for v in r.values())
+    T = 1e12
+    assert 20 * T < r["v_mad_u64_u32"] < 50 * T
+    assert r["v_add_u32"] > 1.4 * r["v_mad_u64_u32"] and r["v_and_b32"] > 1.4 * r["v_mad_u64_u32"]
+    # a 3 : 1 mix of multiply-adds and plain instructions cannot beat the sum of its classes' own times
+    floor = 4 / (3 / r["v_mad_u64_u32"] + 0.5 / r["v_add_u32"] + 0.5 / r["v_and_b32"])
+    for k in ("mixed_3mad_1plain", "mixed_3mad_1plain_at_3_waves_per_simd"):
+        assert 0.6 * floor < r[k] < 1.05 * floor
