@@ -306,6 +306,34 @@ int main(int argc, char** argv) {
     }
   }
 
+  // universal_setup with hiding powers (KZG10::setup samples gamma beside tau): the stored parameters carry
+  // powers_of_gamma_g for degrees 0 ..= max_degree + 1, the powers of g are those of the plain setup
+  {
+    capgpu::Fr gamma = in1.tau;
+    gamma[0] ^= 0x5a5a5a5a;  // any other canonical scalar
+    gamma[3] &= 0x0fffffffffffffffull;
+    auto hiding = proof::universal_setup(max_degree, in1.tau, &gamma);
+    ASSERT(hiding.is_ok());
+    if (hiding.is_ok()) {
+      size_t plain_len = 0, hiding_len = 0;
+      ASSERT(capgpu_srs_serialize(universal_param.handle(), universal_param.h.data(), universal_param.beta_h.data(), nullptr,
+                                  0, &plain_len) == CAPGPU_OK);
+      ASSERT(capgpu_srs_serialize(hiding.unwrap().handle(), hiding.unwrap().h.data(), hiding.unwrap().beta_h.data(), nullptr,
+                                  0, &hiding_len) == CAPGPU_OK);
+      ASSERT(hiding_len == plain_len + (max_degree + 2) * (8 + 32));  // BTreeMap<usize, G1>: key + compressed point
+      std::vector<uint8_t> a(plain_len), b(hiding_len);
+      ASSERT(capgpu_srs_serialize(universal_param.handle(), universal_param.h.data(), universal_param.beta_h.data(), a.data(),
+                                  a.size(), &plain_len) == CAPGPU_OK);
+      ASSERT(capgpu_srs_serialize(hiding.unwrap().handle(), hiding.unwrap().h.data(), hiding.unwrap().beta_h.data(), b.data(),
+                                  b.size(), &hiding_len) == CAPGPU_OK);
+      const size_t powers = 8 + 32 * (max_degree + 1);
+      ASSERT(std::memcmp(a.data(), b.data(), powers) == 0);  // Vec<G1> powers_of_g
+      uint64_t map_len = 0;
+      std::memcpy(&map_len, b.data() + powers, 8);
+      ASSERT(map_len == max_degree + 2);
+    }
+  }
+
   if (failures) return 1;
   std::printf("OK\n");
   return 0;
