@@ -894,7 +894,8 @@ __global__ __launch_bounds__(1024) void msm_sort_items(const uint32_t* __restric
 // lane-operations/s, whatever the number of independent chains - but this kernel sits at 0.79-0.80 of its per-class
 // issue floor at two, three and four waves alike, and a two-stage software pipeline of its gathers (list entry two steps
 // ahead, table point one ahead: 168 VGPRs) changes nothing at three waves nor at two (119.6 vs 119.4, 121.5 vs 122.1 ms):
-// what it loses is lost per instruction, not to occupancy or memory latency.
+// what it loses is lost per instruction, not to occupancy or memory latency.  (The same one-entry-ahead gather for the deep
+// plan alone, whose 14 GB table at 2^24 points lives in HBM rather than in the Infinity Cache: 15.5 ms with and without.)
 #ifdef CAP_ACC_WAVES  // experiments: occupancy the compiler budgets registers for
 #define CAP_ACC_ATTR __attribute__((amdgpu_waves_per_eu(CAP_ACC_WAVES, CAP_ACC_WAVES)))
 #else
