@@ -25,6 +25,8 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 A_SEQ, B_SEQ = 0x1234567890ABCDEF1234567890ABCDEF % bn.R, 0xFEDCBA0987654321FEDCBA % bn.R
+# contexts a plain cg.init(0) gives in this environment (the suite is also run with CAPGPU_CONTEXTS_PER_DEVICE=2)
+AMBIENT_CONTEXTS = max(int(os.environ.get("CAPGPU_CONTEXTS_PER_DEVICE", "1") or 1), 1)
 
 
 @pytest.fixture(scope="module")
@@ -33,6 +35,8 @@ def cg2(cg):
     cg.shutdown()
     os.environ["CAPGPU_ALLOW_DUPLICATE_DEVICES"] = "1"
     os.environ["CAPGPU_SHARD_MIN_POINTS"] = "4096"
+    ambient = os.environ.get("CAPGPU_CONTEXTS_PER_DEVICE")
+    os.environ["CAPGPU_CONTEXTS_PER_DEVICE"] = "1"       # two "devices", one context each
     try:
         cg.init(devices=[0, 0])
         assert cg.device_count() == 2
@@ -41,8 +45,12 @@ def cg2(cg):
         cg.shutdown()
         del os.environ["CAPGPU_ALLOW_DUPLICATE_DEVICES"]
         del os.environ["CAPGPU_SHARD_MIN_POINTS"]
+        if ambient is None:
+            del os.environ["CAPGPU_CONTEXTS_PER_DEVICE"]
+        else:
+            os.environ["CAPGPU_CONTEXTS_PER_DEVICE"] = ambient
         cg.init(0)
-        assert cg.device_count() == 1
+        assert cg.device_count() == AMBIENT_CONTEXTS
 
 
 def test_a_device_may_be_listed_once(cg):
@@ -58,9 +66,9 @@ def test_a_device_may_be_listed_once(cg):
         assert cg.device_count() == 0
     finally:
         cg.init(0)
-    assert cg.device_count() == 1
+    assert cg.device_count() == AMBIENT_CONTEXTS
     with pytest.raises(cg.CapGpuError):
-        cg.set_device(1)
+        cg.set_device(AMBIENT_CONTEXTS)
     cg.set_device(0)
     assert cg.get_device() == (0, 0)
     cg.set_device(-1)
