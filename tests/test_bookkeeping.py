@@ -22,6 +22,13 @@ def test_isa_mix_classes_are_priced():
     assert 1.5 < clock["msm_accumulate"]["clock_GHz"] < 2.5 and 0.5 < clock["msm_accumulate"]["cu_busy_frac"] <= 1.02
 
 
+def test_hot_path_marker_is_in_the_source():
+    """tools/isa_mix.py finds msm_accumulate's common path by the asm comment G1L::madd_acc emits behind its one test"""
+    src = open(os.path.join(ROOT, "cap_amd", "csrc", "curve29.hpp")).read()
+    tool = open(os.path.join(ROOT, "tools", "isa_mix.py")).read()
+    assert src.count('asm volatile("; madd_acc: common path")') == 1 and "madd_acc: common path" in tool
+
+
 @pytest.mark.gpu
 def test_issue_rate_microbenchmark(monkeypatch):
     from cap_amd import lib as cg
