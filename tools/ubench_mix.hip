@@ -10,7 +10,7 @@
 #include <stdint.h>
 #include <stdio.h>
 
-template <int C, int MODE>  // MODE 0: mads only   1: plain only   2: 3 mads + 1 plain
+template <int C, int MODE, int U = 1>  // MODE 0: mads only   1: plain only   2: 3 mads + 1 plain;  U: body copies per iteration
 __global__ __launch_bounds__(256) void k(uint64_t* io, int iters) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   uint64_t acc[C], carry;
@@ -23,7 +23,7 @@ __global__ __launch_bounds__(256) void k(uint64_t* io, int iters) {
   }
   for (int it = 0; it < iters; it++) {
 #pragma unroll
-    for (int rep = 0; rep < 16 / C; rep++) {
+    for (int rep = 0; rep < U * 16 / C; rep++) {
 #pragma unroll
       for (int m = 0; m < 3; m++)
 #pragma unroll
@@ -43,23 +43,23 @@ __global__ __launch_bounds__(256) void k(uint64_t* io, int iters) {
   io[i] = r;
 }
 
-template <int C, int MODE>
+template <int C, int MODE, int U = 1>
 double run(int waves_per_simd, uint64_t* d) {  // ns of SIMD time per wave-instruction
   hipDeviceProp_t prop;
   hipGetDeviceProperties(&prop, 0);
   const size_t lds = waves_per_simd >= 8 ? 0 : (size_t)(160 * 1024 / waves_per_simd) & ~(size_t)1023;
-  hipFuncSetAttribute((const void*)k<C, MODE>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute((const void*)k<C, MODE, U>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   const int blocks = prop.multiProcessorCount * waves_per_simd * 4;  // four rounds of resident workgroups
-  const int iters = 4000;
-  const int per_iter = (MODE == 0 ? 48 : MODE == 1 ? 16 : 64);
+  const int iters = 4000 / U;
+  const int per_iter = U * (MODE == 0 ? 48 : MODE == 1 ? 16 : 64);
   hipEvent_t e0, e1;
   hipEventCreate(&e0);
   hipEventCreate(&e1);
-  hipLaunchKernelGGL((k<C, MODE>), dim3(blocks), dim3(256), lds, 0, d, 10);
+  hipLaunchKernelGGL((k<C, MODE, U>), dim3(blocks), dim3(256), lds, 0, d, 10);
   double best = 1e30;
   for (int rep = 0; rep < 3; rep++) {
     hipEventRecord(e0, 0);
-    hipLaunchKernelGGL((k<C, MODE>), dim3(blocks), dim3(256), lds, 0, d, iters);
+    hipLaunchKernelGGL((k<C, MODE, U>), dim3(blocks), dim3(256), lds, 0, d, iters);
     hipEventRecord(e1, 0);
     hipEventSynchronize(e1);
     float ms;
@@ -81,5 +81,11 @@ int main() {
     printf("%5d %8.3f %8.3f %8.3f | %9.3f %9.3f | %7.3f %8.3f %8.3f %8.3f\n", w, run<1, 0>(w, d), run<2, 0>(w, d),
            run<8, 0>(w, d), run<1, 1>(w, d), run<8, 1>(w, d), run<1, 2>(w, d), run<2, 2>(w, d), run<4, 2>(w, d),
            run<8, 2>(w, d));
+  // the same mixed stream as straight-line code of msm_accumulate's size: 32 copies of the body = 2048 instructions,
+  // ~16 KB per loop iteration (the instruction cache is 64 KB per two CUs)
+  printf("\nmix C=1, loop body of 64 / 512 / 2048 / 8192 instructions\n");
+  for (int w : {2, 3, 4, 8})
+    printf("%5d %8.3f %8.3f %8.3f %8.3f\n", w, run<1, 2, 1>(w, d), run<1, 2, 8>(w, d), run<1, 2, 32>(w, d),
+           run<1, 2, 128>(w, d));
   return 0;
 }
