@@ -1,10 +1,10 @@
 #!/bin/bash
 # Where do the 3.4 ms of a single proof go?  Kernel trace of batch-1 steps: busy time (union of kernel intervals), gaps,
-# per-kernel sums, per step.
+# per-kernel sums, per step.  BATCH=32 bash tools/gpujob_lat1.sh: the same for a mid-size batch.
 cd /tmp && export TMPDIR=/tmp
 cd $GRAFT_REPO_ROOT
 rm -rf gpurun_out/lat1; mkdir -p gpurun_out/lat1
-timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/lat1 -- python3 bench.py --batch 1 --steps 40 --warmup 5 --no-extras --no-cpu-baseline --no-reference-schedule --no-msm > gpurun_out/lat1/bench.json 2> gpurun_out/lat1/err.txt
+timeout 300 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/lat1 -- python3 bench.py --batch ${BATCH:-1} --steps 40 --warmup 5 --no-extras --no-cpu-baseline --no-reference-schedule --no-msm > gpurun_out/lat1/bench.json 2> gpurun_out/lat1/err.txt
 python3 - <<'PY'
 import csv, glob, collections, json
 f = glob.glob("gpurun_out/lat1/**/*kernel_trace.csv", recursive=True)[0]
