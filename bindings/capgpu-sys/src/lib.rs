@@ -28,6 +28,11 @@ pub const CAPGPU_ERR_COMM: c_int = -9;
 pub const NUM_WIRE_TYPES: usize = 5;
 pub const NUM_SELECTORS: usize = 13;
 
+/// `input_form` of the `_ex` PLONK entry points: values on the domain, or polynomials in coefficient form - what
+/// jf-relation's `Arithmetization` trait returns, passed through without a CPU transform.
+pub const CAPGPU_INPUT_EVALS: c_int = 0;
+pub const CAPGPU_INPUT_COEFFS: c_int = 1;
+
 /// `capgpu_proof`: the fields of `jf_plonk::proof_system::structs::Proof`, in order (plookup_proof = None).
 #[repr(C)]
 #[derive(Clone, Copy)]
@@ -112,6 +117,9 @@ extern "C" {
     pub fn capgpu_plonk_preprocess(srs_handle: u64, n: usize, num_inputs: usize, selectors: *const u64,
                                    sigma_evals: *const u64, pk_handle_out: *mut u64,
                                    vk_out: *mut capgpu_verifying_key) -> c_int;
+    pub fn capgpu_plonk_preprocess_ex(srs_handle: u64, n: usize, num_inputs: usize, selectors: *const u64,
+                                      sigmas: *const u64, input_form: c_int, pk_handle_out: *mut u64,
+                                      vk_out: *mut capgpu_verifying_key) -> c_int;
     pub fn capgpu_plonk_free_key(pk_handle: u64) -> c_int;
     pub fn capgpu_plonk_key_info(pk_handle: u64, domain_size_out: *mut usize, num_inputs_out: *mut usize,
                                  srs_handle_out: *mut u64) -> c_int;
@@ -133,6 +141,24 @@ extern "C" {
     pub fn capgpu_plonk_prove_batch_dev(pk_handle: u64, count: c_int, d_wires: *const c_void, pub_inputs: *const u64,
                                         num_inputs: usize, ext_msg: *const u8, ext_msg_len: usize,
                                         blinders: *const u64, proofs_out: *mut capgpu_proof) -> c_int;
+    pub fn capgpu_plonk_prove_ex(pk_handle: u64, wires: *const u64, pub_inputs: *const u64, num_inputs: usize,
+                                 ext_msg: *const u8, ext_msg_len: usize, blinders: *const u64, input_form: c_int,
+                                 proof_out: *mut capgpu_proof) -> c_int;
+    pub fn capgpu_plonk_prove_batch_ex(pk_handle: u64, count: c_int, wires: *const u64, pub_inputs: *const u64,
+                                       num_inputs: usize, ext_msg: *const u8, ext_msg_len: usize,
+                                       blinders: *const u64, input_form: c_int, proofs_out: *mut capgpu_proof) -> c_int;
+    pub fn capgpu_plonk_prove_multi_ex(pk_handles: *const u64, count: c_int, wires: *const u64,
+                                       pub_inputs: *const u64, num_inputs: usize, ext_msgs: *const *const u8,
+                                       ext_msg_lens: *const usize, blinders: *const u64, input_form: c_int,
+                                       proofs_out: *mut capgpu_proof) -> c_int;
+    pub fn capgpu_plonk_prove_multi_dev_ex(pk_handles: *const u64, count: c_int, d_wires: *const c_void,
+                                           pub_inputs: *const u64, num_inputs: usize, ext_msgs: *const *const u8,
+                                           ext_msg_lens: *const usize, blinders: *const u64, input_form: c_int,
+                                           proofs_out: *mut capgpu_proof) -> c_int;
+    pub fn capgpu_plonk_prove_batch_dev_ex(pk_handle: u64, count: c_int, d_wires: *const c_void,
+                                           pub_inputs: *const u64, num_inputs: usize, ext_msg: *const u8,
+                                           ext_msg_len: usize, blinders: *const u64, input_form: c_int,
+                                           proofs_out: *mut capgpu_proof) -> c_int;
     // ---- verification (host only)
     pub fn capgpu_g2_generator(out: *mut u64) -> c_int;
     pub fn capgpu_g2_mul(q: *const u64, scalar: *const u64, out: *mut u64) -> c_int;
@@ -282,31 +308,45 @@ pub struct ProvingKey {
     pub num_inputs: usize,
 }
 impl ProvingKey {
-    /// `PlonkKzgSnark::preprocess(srs, circuit)`.  `selectors`: 13 columns of n evaluations (q_lc x4, q_mul x2,
-    /// q_hash x4, q_o, q_c, q_ecc), `sigma`: 5 columns of n evaluations of the extended permutation; both column-major,
-    /// Montgomery words.  See `arkworks::circuit_columns` for how to obtain them from jf-relation's public API.
+    /// `PlonkKzgSnark::preprocess(srs, circuit)`.  `selectors`: the 13 selector POLYNOMIALS (q_lc x4, q_mul x2,
+    /// q_hash x4, q_o, q_c, q_ecc), `sigma`: the 5 extended-permutation polynomials - n coefficients each, column-major,
+    /// Montgomery words: `arkworks::poly_columns(&circuit.compute_selector_polynomials()?, n)` and
+    /// `..compute_extended_permutation_polynomials()`, passed through as jf-relation computed them (no transform on the
+    /// CPU; the device evaluates sigma where round 2 needs its values).
     pub fn preprocess(srs: &Srs, n: usize, num_inputs: usize, selectors: &[[u64; 4]], sigma: &[[u64; 4]]) -> Result<ProvingKey> {
+        Self::preprocess_form(srs, n, num_inputs, selectors, sigma, CAPGPU_INPUT_COEFFS)
+    }
+    /// The same from the circuit's tables of VALUES on the domain (`input_form` = `CAPGPU_INPUT_EVALS`), for a caller
+    /// that holds those instead of polynomials.
+    pub fn preprocess_form(srs: &Srs, n: usize, num_inputs: usize, selectors: &[[u64; 4]], sigma: &[[u64; 4]],
+                           input_form: c_int) -> Result<ProvingKey> {
         assert_eq!(selectors.len(), NUM_SELECTORS * n);
         assert_eq!(sigma.len(), NUM_WIRE_TYPES * n);
         let mut handle = 0u64;
         let mut vk: capgpu_verifying_key = unsafe { std::mem::zeroed() };
         check(unsafe {
-            capgpu_plonk_preprocess(srs.handle, n, num_inputs, selectors.as_ptr() as *const u64,
-                                    sigma.as_ptr() as *const u64, &mut handle, &mut vk)
+            capgpu_plonk_preprocess_ex(srs.handle, n, num_inputs, selectors.as_ptr() as *const u64,
+                                       sigma.as_ptr() as *const u64, input_form, &mut handle, &mut vk)
         })?;
         Ok(ProvingKey { handle, vk, domain_size: n, num_inputs })
     }
     /// `PlonkKzgSnark::prove::<_, _, SolidityTranscript>(rng, circuit, pk, Some(ext_msg))` for one note: callable from
-    /// any thread; with coalescing on, concurrent calls share device batches.  `wires`: the 5 finalised wire columns
-    /// (n evaluations each); `blinders`: 13 `Fr::rand(rng)` draws in jf-plonk's order (2 per wire polynomial, then 3).
+    /// any thread; with coalescing on, concurrent calls share device batches.  `wires`: the 5 UNBLINDED wire
+    /// polynomials, n coefficients each - `arkworks::poly_columns(&circuit.compute_wire_polynomials()?, n)`;
+    /// `blinders`: 13 `Fr::rand(rng)` draws in jf-plonk's order (2 per wire polynomial, then 3).
     pub fn prove(&self, wires: &[[u64; 4]], pub_inputs: &[[u64; 4]], ext_msg: &[u8], blinders: &[[u64; 4]; 13]) -> Result<capgpu_proof> {
+        self.prove_form(wires, pub_inputs, ext_msg, blinders, CAPGPU_INPUT_COEFFS)
+    }
+    /// The same from the 5 finalised wire COLUMNS (n values each): `input_form` = `CAPGPU_INPUT_EVALS`.
+    pub fn prove_form(&self, wires: &[[u64; 4]], pub_inputs: &[[u64; 4]], ext_msg: &[u8], blinders: &[[u64; 4]; 13],
+                      input_form: c_int) -> Result<capgpu_proof> {
         assert_eq!(wires.len(), NUM_WIRE_TYPES * self.domain_size);
         assert_eq!(pub_inputs.len(), self.num_inputs);
         let mut proof: capgpu_proof = unsafe { std::mem::zeroed() };
         check(unsafe {
-            capgpu_plonk_prove(self.handle, wires.as_ptr() as *const u64, pub_inputs.as_ptr() as *const u64,
-                               pub_inputs.len(), ext_msg.as_ptr(), ext_msg.len(), blinders.as_ptr() as *const u64,
-                               &mut proof)
+            capgpu_plonk_prove_ex(self.handle, wires.as_ptr() as *const u64, pub_inputs.as_ptr() as *const u64,
+                                  pub_inputs.len(), ext_msg.as_ptr(), ext_msg.len(), blinders.as_ptr() as *const u64,
+                                  input_form, &mut proof)
         })?;
         Ok(proof)
     }
@@ -335,7 +375,7 @@ pub fn proof_bytes(proof: &capgpu_proof) -> Result<Vec<u8>> {
 pub mod arkworks {
     use ark_bn254::{Fq, Fr, G1Projective};
     use ark_ff::{BigInteger256, PrimeField};
-    use ark_poly::{univariate::DensePolynomial, EvaluationDomain, Radix2EvaluationDomain};
+    use ark_poly::univariate::DensePolynomial;
 
     /// `Fp256` keeps its Montgomery limbs in `.0.0`: the ABI's "Montgomery words".
     pub fn fr_words(x: &Fr) -> [u64; 4] {
@@ -353,20 +393,21 @@ pub mod arkworks {
         let f = |i: usize| Fq::new(BigInteger256([w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]]));
         G1Projective::new(f(0), f(1), f(2))
     }
-    /// Evaluation columns of a family of polynomials on the circuit's domain, column-major.  jf-relation's
-    /// `Arithmetization` trait exposes the selector / extended-permutation / wire polynomials in COEFFICIENT form
-    /// (`compute_selector_polynomials`, `compute_extended_permutation_polynomials`, `compute_wire_polynomials`); the
-    /// device prover takes evaluations, one n-point FFT each:
+    /// A family of polynomials as the ABI's coefficient-form columns (`CAPGPU_INPUT_COEFFS`): n coefficients each,
+    /// column-major, a `DensePolynomial` shorter than n (arkworks strips trailing zeros) zero-padded.  jf-relation's
+    /// `Arithmetization` trait hands the prover exactly these polynomials, so nothing is transformed on the CPU:
     ///   let n = circuit.eval_domain_size()?;
-    ///   let selectors = circuit_columns(&circuit.compute_selector_polynomials()?, n);           // 13 x n
-    ///   let sigma     = circuit_columns(&circuit.compute_extended_permutation_polynomials()?, n); // 5 x n
-    ///   let wires     = circuit_columns(&circuit.compute_wire_polynomials()?, n);               // 5 x n (per proof)
-    pub fn circuit_columns(polys: &[DensePolynomial<Fr>], n: usize) -> Vec<[u64; 4]> {
-        let domain = Radix2EvaluationDomain::<Fr>::new(n).expect("power-of-two domain");
-        let mut out = Vec::with_capacity(polys.len() * n);
-        for p in polys {
-            for e in domain.fft(&p.coeffs) {
-                out.push(fr_words(&e));
+    ///   let selectors = poly_columns(&circuit.compute_selector_polynomials()?, n);              // 13 x n
+    ///   let sigma     = poly_columns(&circuit.compute_extended_permutation_polynomials()?, n);  // 5 x n
+    ///   let wires     = poly_columns(&circuit.compute_wire_polynomials()?, n);                  // 5 x n (per proof)
+    /// A memcpy of 5 n field elements per proof - against the 10 n-point FFTs per proof the evaluation form used to
+    /// cost this shim (5 here to undo jf-relation's interpolation, 5 on the device to redo it).
+    pub fn poly_columns(polys: &[DensePolynomial<Fr>], n: usize) -> Vec<[u64; 4]> {
+        let mut out = vec![[0u64; 4]; polys.len() * n];
+        for (i, p) in polys.iter().enumerate() {
+            assert!(p.coeffs.len() <= n, "polynomial longer than the evaluation domain");
+            for (j, c) in p.coeffs.iter().enumerate() {
+                out[i * n + j] = fr_words(c);
             }
         }
         out

@@ -36,19 +36,40 @@ Context& ctx() {
   const int s = tl_bound >= 0 && (size_t)tl_bound < R.ctxs.size() ? tl_bound : 0;
   return *R.ctxs[s];
 }
-int thread_bound_slot() { return tl_bound; }
+// a binding made before a shutdown / re-init with fewer contexts is stale: treated as unbound
+bool force_replicate() {
+  const char* e = getenv("CAPGPU_FORCE_REPLICATE");
+  return e && atoi(e) != 0;
+}
+ScalarSet::~ScalarSet() {
+  Runtime& R = rt();
+  for (ScalarSlice& sl : slices) {
+    if (!sl.d) continue;
+    if (sl.slot >= 0 && (size_t)sl.slot < R.ctxs.size()) {
+      Context& c = *R.ctxs[(size_t)sl.slot];
+      ScopedCtx sc(c);
+      (void)hipStreamSynchronize(c.stream);
+      (void)hipFree(sl.d);
+    }
+    sl.d = nullptr;
+  }
+}
+int thread_bound_slot() { return tl_bound >= 0 && (size_t)tl_bound < rt().ctxs.size() ? tl_bound : -1; }
 int& thread_entry_depth() {
   static thread_local int d = 0;
   return d;
 }
 
 ScopedCtx::ScopedCtx(Context& c) : prev(tl_ctx) {
+  // an unbound caller thread keeps ITS HIP device across the call (it may be torch's, or another library's)
+  if (!prev && hipGetDevice(&prev_device) != hipSuccess) prev_device = -1;
   tl_ctx = &c;
   (void)hipSetDevice(c.device);
 }
 ScopedCtx::~ScopedCtx() {
   tl_ctx = prev;
   if (prev) (void)hipSetDevice(prev->device);
+  else if (prev_device >= 0) (void)hipSetDevice(prev_device);
 }
 
 Profiler& profiler() { return ctx().prof; }
@@ -139,6 +160,7 @@ Context* try_acquire_context() {
 Context& pick_context() {
   Runtime& R = rt();
   if (tl_ctx) return *tl_ctx;  // already placed by a dispatcher
+  if (const int ss = comm_shard_slot(); ss >= 0 && (size_t)ss < R.ctxs.size()) return *R.ctxs[(size_t)ss];
   if (tl_bound >= 0 || R.ctxs.size() <= 1) return ctx();
   if (Context* c = try_acquire_context()) {
     c->mu.unlock();  // the caller takes the lock through Entry; losing the race to another thread only costs a wait
@@ -353,6 +375,9 @@ int make_srs_entry(g1_affine* d_bases, size_t n, size_t range_lo, std::shared_pt
   int rc = msm_precompute(&e->bases, d_bases, n, cw, c.stream);
   if (rc) return hip_fail((hipError_t)rc, "msm_precompute");
   CAP_HIP(hipStreamSynchronize(c.stream));
+  // msm_precompute latches a failed launch of its table kernels (launch.hpp); a handle whose window tables were never
+  // written must not be published: the entry is dropped here (its destructor frees the tables)
+  if ((rc = take_launch_error())) return rc;
   *out = e;
   return CAPGPU_OK;
 }
@@ -446,8 +471,9 @@ int find_srs(uint64_t h, const MsmBases** out) {
       return CAPGPU_ERR_INVALID_ARG;
     }
     std::shared_ptr<SrsEntry> rep;
-    if (rec.full->device == c.device) rep = rec.full;
+    if (rec.full->device == c.device && !force_replicate()) rep = rec.full;
     else if ((rc = clone_srs_to_current(*rec.full, &rep))) return rc;
+    else rt().replications++;
     {
       Runtime& R = rt();
       std::lock_guard<std::mutex> lk(R.mu);
@@ -557,9 +583,12 @@ uint64_t register_shards(std::vector<std::shared_ptr<SrsEntry>>& shards, size_t 
 // memory of context `home` (d_scalars), array k at + k * stride elements.  Every context runs the part of the range it
 // holds down to one point per MSM; the partials travel to `home` (peer copies of count * 96 bytes: the exchange step of
 // SURVEY 8e) and one wavefront per MSM adds them up into d_out (on home).  The caller holds AllEntries and is on home.
+// resident (optional): the scalar slices already sit on the shard contexts (capgpu_msm_scalars_*): nothing but the
+// partials moves.
 int msm_sharded(const SrsRecord& rec, Context& home, size_t offset, const uint64_t* h_scalars, const fe* d_scalars,
-                size_t stride, size_t n, int count, int montgomery, g1_jac* d_out) {
+                size_t stride, size_t n, int count, int montgomery, g1_jac* d_out, const ScalarSet* resident = nullptr) {
   const std::vector<size_t> slots = shard_slots();
+  rt().shard_calls++;
   const size_t S = slots.size();
   int rc = scratch_reserve(home.gather, sizeof(g1_jac) * S * (size_t)count);
   if (rc) return rc;
@@ -576,18 +605,30 @@ int msm_sharded(const SrsRecord& rec, Context& home, size_t offset, const uint64
     const size_t lo = std::max(offset, sh.range_lo), hi = std::min(offset + n, sh.range_lo + sh.bases.n);
     if (lo >= hi) return CAPGPU_OK;
     const size_t len = hi - lo;
-    int r2 = scratch_reserve(c.stage_a, sizeof(fe) * len * (size_t)count + sizeof(g1_jac) * (size_t)count);
+    const ScalarSlice* res = nullptr;
+    if (resident) {
+      for (const ScalarSlice& sl : resident->slices)
+        if (sl.slot == c.slot) res = &sl;
+      if (!res || res->lo != lo || res->len != len) {
+        set_error("capgpu_msm_g1_resident: the scalar set was not cut for this SRS's point ranges");
+        return CAPGPU_ERR_INVALID_ARG;
+      }
+    }
+    int r2 = scratch_reserve(c.stage_a, (res ? 0 : sizeof(fe) * len * (size_t)count) + sizeof(g1_jac) * (size_t)count);
     if (r2) return r2;
-    fe* d_sc = (fe*)c.stage_a.p;
-    g1_jac* d_part = (g1_jac*)((char*)c.stage_a.p + sizeof(fe) * len * (size_t)count);
+    fe* d_sc = res ? res->d : (fe*)c.stage_a.p;
+    g1_jac* d_part = (g1_jac*)((char*)c.stage_a.p + (res ? 0 : sizeof(fe) * len * (size_t)count));
     CAP_HIP(hipStreamWaitEvent(c.stream, ready, 0));
-    for (int k = 0; k < count; k++) {
+    for (int k = 0; k < count && !res; k++) {
+      // fallback form: the scalars live on the caller's side and every call scatters them again (448 MB leaving one GPU
+      // per 2^24-point MSM) - capgpu_msm_scalars_scatter_dev / _upload make them resident once instead
       if (h_scalars)
         CAP_HIP(hipMemcpyAsync(d_sc + (size_t)k * len, h_scalars + 4 * ((size_t)k * stride + (lo - offset)),
                                sizeof(fe) * len, hipMemcpyHostToDevice, c.stream));
       else
         CAP_HIP(copy_between(d_sc + (size_t)k * len, c.device, d_scalars + (size_t)k * stride + (lo - offset),
                              home.device, sizeof(fe) * len, c.stream));
+      if (h_scalars || c.slot != home.slot) rt().shard_scalar_bytes += sizeof(fe) * len;
     }
     if ((r2 = scratch_reserve(c.msm_ws, msm_workspace_bytes(sh.bases, len, (uint32_t)count)))) return r2;
     r2 = msm_run(sh.bases, lo - sh.range_lo, d_sc, len, 1, 0, len, (uint32_t)count, montgomery, d_part, c.msm_ws.p,
@@ -595,6 +636,7 @@ int msm_sharded(const SrsRecord& rec, Context& home, size_t offset, const uint64
     if (r2) return hip_fail((hipError_t)r2, "msm_run");
     CAP_HIP(copy_between(gather + r * (size_t)count, home.device, d_part, c.device, sizeof(g1_jac) * (size_t)count,
                          c.stream));
+    if (c.slot != home.slot) rt().shard_partial_bytes += sizeof(g1_jac) * (size_t)count;
     CAP_HIP(hipEventCreateWithFlags(&done[r], hipEventDisableTiming));
     CAP_HIP(hipEventRecord(done[r], c.stream));
     return take_launch_error();
@@ -706,6 +748,21 @@ int capgpu_init(const int* device_ids, int n_devices) {
     }
     made.back()->initialised = true;
   }
+  // Peer access between every pair of bound devices: without it hipMemcpyPeerAsync - key / SRS replication, the scalar
+  // slices and the 96-byte partials of a sharded MSM - is staged through host memory by the runtime.  A pair without
+  // a peer path keeps working that way; capgpu_device_peer_info reports which pairs got the direct path.
+  R.peer.clear();
+  for (auto& a : made)
+    for (auto& b : made) {
+      if (a->device == b->device || R.peer.count({a->device, b->device})) continue;
+      int can = 0, state = 0;
+      if (hipSetDevice(a->device) == hipSuccess && hipDeviceCanAccessPeer(&can, a->device, b->device) == hipSuccess && can) {
+        const hipError_t pe = hipDeviceEnablePeerAccess(b->device, 0);
+        if (pe == hipSuccess || pe == hipErrorPeerAccessAlreadyEnabled) state = 1;
+        (void)hipGetLastError();
+      }
+      R.peer[{a->device, b->device}] = state;
+    }
   R.ctxs = std::move(made);
   R.rr.store(0);
   R.initialised.store(true, std::memory_order_release);
@@ -726,9 +783,14 @@ void capgpu_shutdown(void) {
       if (c.copy_stream) (void)hipStreamSynchronize(c.copy_stream);
     }
     {
-      std::lock_guard<std::mutex> lk(R.mu);
-      R.srs.clear();
-      R.keys.clear();
+      std::map<uint64_t, std::shared_ptr<ScalarSet>> sets;
+      {
+        std::lock_guard<std::mutex> lk(R.mu);
+        sets.swap(R.scalar_sets);
+        R.srs.clear();
+        R.keys.clear();
+      }
+      sets.clear();  // frees the slices on their devices (the contexts and their streams still exist)
     }
     for (auto& cp : R.ctxs) {
       Context& c = *cp;
@@ -1145,6 +1207,193 @@ int capgpu_msm_g1_dev(uint64_t srs_handle, size_t offset, const void* d_scalars,
                (g1_jac*)d_out_xyz, c.msm_ws.p, c.msm_ws.cap, c.stream);
   if (rc) return hip_fail((hipError_t)rc, "msm_run");
   return take_launch_error();
+}
+
+// ---- scalars resident with their points ----------------------------------------------------------------
+namespace {
+// cuts [offset, offset + n) by the point ranges of `rec` and allocates one slice per range on its context; `fill`
+// copies a slice's scalars into place (enqueued on the slice's context stream)
+int make_scalar_set(uint64_t srs_handle, const SrsRecord& rec, size_t offset, size_t n, int count,
+                    const std::function<int(Context&, ScalarSlice&)>& fill, uint64_t* handle_out) {
+  auto set = std::make_shared<ScalarSet>();
+  set->srs = srs_handle;
+  set->offset = offset;
+  set->n = n;
+  set->count = count;
+  if (rec.sharded()) {
+    for (size_t slot = 0; slot < rec.shards.size(); slot++) {
+      if (!rec.shards[slot]) continue;
+      const SrsEntry& sh = *rec.shards[slot];
+      const size_t lo = std::max(offset, sh.range_lo), hi = std::min(offset + n, sh.range_lo + sh.bases.n);
+      if (lo >= hi) continue;
+      ScalarSlice sl;
+      sl.slot = (int)slot;
+      sl.lo = lo;
+      sl.len = hi - lo;
+      set->slices.push_back(sl);
+    }
+  } else {
+    ScalarSlice sl;
+    sl.slot = ctx().slot;
+    sl.lo = offset;
+    sl.len = n;
+    set->slices.push_back(sl);
+  }
+  for (ScalarSlice& sl : set->slices) {
+    Context& c = *rt().ctxs[(size_t)sl.slot];
+    ScopedCtx sc(c);
+    CAP_HIP(hipMalloc(&sl.d, sizeof(fe) * (sl.len ? sl.len : 1) * (size_t)count));
+    int rc = fill(c, sl);
+    if (rc) return rc;
+  }
+  for (ScalarSlice& sl : set->slices) {  // the caller may reuse its buffer once this returns
+    Context& c = *rt().ctxs[(size_t)sl.slot];
+    ScopedCtx sc(c);
+    CAP_HIP(hipStreamSynchronize(c.stream));
+  }
+  Runtime& R = rt();
+  const uint64_t h = R.next_handle.fetch_add(1);
+  std::lock_guard<std::mutex> lk(R.mu);
+  R.scalar_sets[h] = set;
+  *handle_out = h;
+  return CAPGPU_OK;
+}
+int scalar_set_args(uint64_t srs_handle, size_t offset, const void* scalars, size_t stride, size_t n, int count,
+                    uint64_t* handle_out, SrsRecord* rec) {
+  int rc = srs_record(srs_handle, rec);
+  if (rc) return rc;
+  if (!handle_out || !scalars || n == 0 || count < 1 || offset + n > rec->total_n || (count > 1 && stride < n)) {
+    set_error("capgpu_msm_scalars: bad argument (offset %zu + n %zu vs SRS size %zu, count %d, stride %zu)", offset, n,
+              rec->total_n, count, stride);
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  if (thread_entry_depth() > 0) {
+    set_error("capgpu_msm_scalars: cannot be used from inside another entry point");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  return CAPGPU_OK;
+}
+}  // namespace
+
+int capgpu_msm_scalars_upload(uint64_t srs_handle, size_t offset, const uint64_t* scalars, size_t scalar_stride, size_t n,
+                              int count, uint64_t* scalars_handle_out) {
+  CAP_CHECK_INIT();
+  SrsRecord rec;
+  int rc = scalar_set_args(srs_handle, offset, scalars, scalar_stride, n, count, scalars_handle_out, &rec);
+  if (rc) return rc;
+  AllEntries all;
+  ScopedCtx sc(ctx());
+  return make_scalar_set(srs_handle, rec, offset, n, count, [&](Context& c, ScalarSlice& sl) -> int {
+    for (int k = 0; k < count; k++)  // host -> the slice's own device: no hop through a "home" GPU
+      CAP_HIP(hipMemcpyAsync(sl.d + (size_t)k * sl.len, scalars + 4 * ((size_t)k * scalar_stride + (sl.lo - offset)),
+                             sizeof(fe) * sl.len, hipMemcpyHostToDevice, c.stream));
+    rt().shard_scalar_bytes += sizeof(fe) * sl.len * (size_t)count;
+    return CAPGPU_OK;
+  }, scalars_handle_out);
+}
+
+int capgpu_msm_scalars_scatter_dev(uint64_t srs_handle, size_t offset, const void* d_scalars, size_t scalar_stride,
+                                   size_t n, int count, uint64_t* scalars_handle_out) {
+  CAP_CHECK_INIT();
+  SrsRecord rec;
+  int rc = scalar_set_args(srs_handle, offset, d_scalars, scalar_stride, n, count, scalars_handle_out, &rec);
+  if (rc) return rc;
+  Context& home = ctx();
+  AllEntries all;
+  ScopedCtx sc(home);
+  CAP_HIP(hipStreamSynchronize(home.stream));  // the scalars were written by work on the caller's context
+  const fe* src = (const fe*)d_scalars;
+  return make_scalar_set(srs_handle, rec, offset, n, count, [&](Context& c, ScalarSlice& sl) -> int {
+    for (int k = 0; k < count; k++)
+      CAP_HIP(copy_between(sl.d + (size_t)k * sl.len, c.device, src + (size_t)k * scalar_stride + (sl.lo - offset),
+                           home.device, sizeof(fe) * sl.len, c.stream));
+    if (c.slot != home.slot) rt().shard_scalar_bytes += sizeof(fe) * sl.len * (size_t)count;
+    return CAPGPU_OK;
+  }, scalars_handle_out);
+}
+
+int capgpu_msm_scalars_free(uint64_t scalars_handle) {
+  CAP_CHECK_INIT();
+  std::shared_ptr<ScalarSet> set;
+  {
+    Runtime& R = rt();
+    std::lock_guard<std::mutex> lk(R.mu);
+    auto it = R.scalar_sets.find(scalars_handle);
+    if (it == R.scalar_sets.end()) {
+      set_error("capgpu: unknown scalar-set handle %llu", (unsigned long long)scalars_handle);
+      return CAPGPU_ERR_BAD_HANDLE;
+    }
+    set = it->second;
+    R.scalar_sets.erase(it);
+  }
+  set.reset();  // frees the slices (each on its device, after its stream drained)
+  return CAPGPU_OK;
+}
+
+int capgpu_msm_g1_resident(uint64_t srs_handle, uint64_t scalars_handle, int scalars_montgomery, void* d_out_xyz) {
+  CAP_CHECK_INIT();
+  SrsRecord rec;
+  int rc = srs_record(srs_handle, &rec);
+  if (rc) return rc;
+  std::shared_ptr<ScalarSet> set;
+  {
+    Runtime& R = rt();
+    std::lock_guard<std::mutex> lk(R.mu);
+    auto it = R.scalar_sets.find(scalars_handle);
+    if (it != R.scalar_sets.end()) set = it->second;
+  }
+  if (!set) {
+    set_error("capgpu: unknown scalar-set handle %llu", (unsigned long long)scalars_handle);
+    return CAPGPU_ERR_BAD_HANDLE;
+  }
+  if (set->srs != srs_handle || !d_out_xyz) {
+    set_error("capgpu_msm_g1_resident: the scalar set belongs to SRS %llu", (unsigned long long)set->srs);
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  Context& c = ctx();
+  if (rec.sharded()) {
+    if (thread_entry_depth() > 0) {
+      set_error("capgpu_msm_g1_resident: a sharded SRS cannot be used from inside another entry point");
+      return CAPGPU_ERR_INVALID_ARG;
+    }
+    AllEntries all;
+    ScopedCtx sc(c);
+    return msm_sharded(rec, c, set->offset, nullptr, nullptr, 0, set->n, set->count, scalars_montgomery,
+                       (g1_jac*)d_out_xyz, set.get());
+  }
+  const ScalarSlice& sl = set->slices[0];
+  if (sl.slot != c.slot && rt().ctxs[(size_t)sl.slot]->device != c.device) {
+    set_error("capgpu_msm_g1_resident: the scalars live on context %d, this thread is on context %d", sl.slot, c.slot);
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  return capgpu_msm_g1_dev(srs_handle, set->offset, sl.d, sl.len, sl.len, set->count, scalars_montgomery, d_out_xyz);
+}
+
+int capgpu_msm_shard_stats(uint64_t* scalar_bytes_out, uint64_t* partial_bytes_out, uint64_t* calls_out,
+                           uint64_t* replications_out) {
+  Runtime& R = rt();
+  if (scalar_bytes_out) *scalar_bytes_out = R.shard_scalar_bytes.load();
+  if (partial_bytes_out) *partial_bytes_out = R.shard_partial_bytes.load();
+  if (calls_out) *calls_out = R.shard_calls.load();
+  if (replications_out) *replications_out = R.replications.load();
+  return CAPGPU_OK;
+}
+
+int capgpu_device_peer_info(int slot_a, int slot_b, int* access_out) {
+  CAP_CHECK_INIT();
+  const int S = (int)num_contexts();
+  if (slot_a < 0 || slot_b < 0 || slot_a >= S || slot_b >= S || !access_out) {
+    set_error("capgpu_device_peer_info: slots %d, %d out of range (0 .. %d)", slot_a, slot_b, S - 1);
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  const int da = rt().ctxs[(size_t)slot_a]->device, db = rt().ctxs[(size_t)slot_b]->device;
+  if (da == db) {
+    *access_out = 2;
+    return CAPGPU_OK;
+  }
+  auto it = rt().peer.find({da, db});
+  *access_out = it != rt().peer.end() ? it->second : 0;
+  return CAPGPU_OK;
 }
 
 int capgpu_msm_plan(uint64_t srs_handle, size_t n, int count, char* buf, size_t cap) {

@@ -188,6 +188,7 @@ void g1_sum_ranks(const g1_jac* d_all, uint32_t world, uint32_t stride, uint32_t
 static bool comm_exists() { return comm().comm != nullptr || comm().loopback; }
 bool comm_active() { return comm_exists() && comm().world > 1; }
 bool comm_shard_prover() { return comm_exists() && comm().shard_prover && comm().slot == ctx().slot; }
+int comm_shard_slot() { return comm_exists() && comm().shard_prover ? comm().slot : -1; }
 bool comm_loopback() { return comm().loopback; }
 void comm_loopback_rank(int r) {
   if (comm().loopback && r >= 0 && r < comm().world) comm().rank = r;

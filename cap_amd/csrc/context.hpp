@@ -66,6 +66,25 @@ struct SrsRecord {
 
 struct ProvingKey;  // plonk.hip
 
+// Scalars of MSMs on a (possibly sharded) SRS, resident where their points are ("GPU g holds its bases
+// resident and receives the matching scalar slice"): `count` arrays over logical points [offset, offset + n), cut by the
+// SRS's point ranges at upload / scatter time.  An MSM on a ScalarSet exchanges nothing but the 96-byte partials.
+struct ScalarSlice {
+  int slot = -1;         // context the slice lives on
+  fe* d = nullptr;       // [count][len], array k at + k * len
+  size_t lo = 0, len = 0;  // logical points [lo, lo + len)
+};
+struct ScalarSet {
+  uint64_t srs = 0;
+  size_t offset = 0, n = 0;
+  int count = 0;
+  std::vector<ScalarSlice> slices;
+  ScalarSet() = default;
+  ScalarSet(const ScalarSet&) = delete;
+  ScalarSet& operator=(const ScalarSet&) = delete;
+  ~ScalarSet();  // capgpu.hip: frees every slice on its device
+};
+
 struct Context {
   bool initialised = false;
   int slot = 0;    // index in Runtime::ctxs
@@ -93,9 +112,20 @@ struct Runtime {
   std::vector<std::unique_ptr<Context>> ctxs;
   std::map<uint64_t, SrsRecord> srs;
   std::map<uint64_t, std::shared_ptr<ProvingKey>> keys;  // home copies
+  std::map<uint64_t, std::shared_ptr<ScalarSet>> scalar_sets;
   std::atomic<uint64_t> next_handle{1};
   std::atomic<uint32_t> rr{0};  // round-robin cursor of the dealers
+  // peer[a][b] for HIP devices a, b of the bound contexts: 1 = a reads / writes b's memory directly
+  // (hipDeviceEnablePeerAccess done at init), 0 = no peer path (copies are staged by the runtime)
+  std::map<std::pair<int, int>, int> peer;
+  // bytes moved BETWEEN contexts (or from the host) by sharded MSMs since init: scalar slices / 96-byte partials
+  std::atomic<uint64_t> shard_scalar_bytes{0}, shard_partial_bytes{0}, shard_calls{0};
+  // tables replicated onto another context (SRS window tables, proving keys): count since init
+  std::atomic<uint64_t> replications{0};
 };
+// CAPGPU_FORCE_REPLICATE=1 (tests): a context replicates SRS / key tables even from a context on the SAME device, so a
+// one-GPU box executes clone_srs_to_current / clone_key_to_current and the proofs made from replicas
+bool force_replicate();
 Runtime& rt();
 
 // The context of the calling thread: the one a dispatcher put it on (ScopedCtx), else the one it bound with
@@ -107,6 +137,7 @@ inline size_t num_contexts() { return rt().ctxs.size(); }
 // puts the calling thread on context c for a scope (and makes c's device the thread's HIP device)
 struct ScopedCtx {
   Context* prev;
+  int prev_device = -1;  // the thread's HIP device before the outermost scope (restored on exit)
   explicit ScopedCtx(Context& c);
   ~ScopedCtx();
   ScopedCtx(const ScopedCtx&) = delete;
@@ -172,6 +203,9 @@ hipError_t copy_between(void* dst, int dst_device, const void* src, int src_devi
 // comm.hip: the RCCL communicator of a multi-process job (one process per GPU)
 bool comm_active();        // a communicator of more than one rank exists
 bool comm_shard_prover();  // the prover's commitment MSMs are sharded by point range over the ranks
+// slot of the context the prover's sharded commitment MSMs run on while capgpu_plonk_shard_msm is on, else -1: every
+// rank must then prove the same batch in the same order, so the dealers keep such batches whole and on that context
+int comm_shard_slot();
 bool comm_loopback();      // test communicator: the ranks are played one after the other on this device
 void comm_loopback_rank(int r);
 int comm_rank();

@@ -216,7 +216,7 @@ struct Carver {
 };
 
 struct BatchWs {
-  fe *wpoly, *pi, *num, *den, *pre, *sfx, *scan_tot, *inv_total, *zpoly, *coset, *pkc, *t, *pows, *pows_small, *pw, *batchpoly,
+  fe *wpoly, *wev, *pi, *num, *den, *pre, *sfx, *scan_tot, *inv_total, *zpoly, *coset, *pkc, *t, *pows, *pows_small, *pw, *batchpoly,
       *hbuf, *quot, *evals, *eval_partial, *d_pub, *d_blind;
   Chal* chal;
   Chal* chal29;  // the same challenges in the internal form
@@ -230,11 +230,13 @@ struct BatchWs {
 constexpr uint32_t kEvalChunks = 16;
 constexpr uint32_t kLinTerms = 29;
 
-BatchWs carve(void* base, const ProvingKey& K, uint32_t P, size_t num_inputs) {
+BatchWs carve(void* base, const ProvingKey& K, uint32_t P, size_t num_inputs, bool coeffs) {
   Carver c(base);
   BatchWs w{};
   size_t n = K.n, m = K.m, ps = K.ps;
   w.wpoly = c.take<fe>((size_t)P * NW * ps);
+  // coefficient-form input: the witness VALUES round 2 reads are one forward transform of the caller's polynomials
+  w.wev = coeffs ? c.take<fe>((size_t)P * NW * n) : nullptr;
   w.pi = c.take<fe>((size_t)P * n);
   w.num = c.take<fe>((size_t)P * n);
   w.den = c.take<fe>((size_t)P * n);
@@ -300,7 +302,12 @@ uint32_t h2d_chunks(uint32_t P) {
 int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64_t* pub_inputs, size_t num_inputs,
                 const uint8_t* ext_msg, size_t ext_len, const uint64_t* blinders, capgpu_proof* proofs,
                 const uint8_t* const* msgs = nullptr, const size_t* msg_lens = nullptr,
-                const std::vector<const ProvingKey*>* keys = nullptr, const uint64_t* const* h_wires = nullptr) {
+                const std::vector<const ProvingKey*>* keys = nullptr, const uint64_t* const* h_wires = nullptr,
+                int form = CAPGPU_INPUT_EVALS) {
+  // form: CAPGPU_INPUT_EVALS - d_wires / h_wires hold the wire assignment, 5 columns of n values per proof (round 1
+  // interpolates them); CAPGPU_INPUT_COEFFS - they hold the 5 wire POLYNOMIALS, n coefficients each, as jf-relation's
+  // compute_wire_polynomials returns them (src/proof/transfer.rs:181-186 holds that circuit): round 1 takes them as they
+  // are and round 2's witness values come from ONE forward transform on the device.  The proofs are the same bytes.
   // h_wires (optional): the wire columns are still in host memory - h_wires[p] points to the 5 n elements of proof p -
   // and d_wires is an empty device buffer for them.
   // Round 1 then runs in chunks of proofs - copy, interpolate, blind, commit - so that the copy of a chunk (pageable
@@ -337,12 +344,18 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
     set_error("capgpu_plonk_prove: %zu public inputs given, key expects %zu", num_inputs, K.num_inputs);
     return CAPGPU_ERR_INVALID_ARG;
   }
+  if (const int ss = comm_shard_slot(); ss >= 0 && ss != c.slot) {
+    set_error("capgpu_plonk_prove: commitment MSMs are sharded over the communicator of context %d (capgpu_plonk_shard_msm); "
+              "this call runs on context %d and would prove unsharded while its peers wait", ss, c.slot);
+    return CAPGPU_ERR_INVALID_ARG;
+  }
   const MsmBases* B = nullptr;
   int rc = find_srs(K.srs_handle, &B);
   if (rc) return rc;
   // workspace
-  if ((rc = scratch_reserve(c.prove_ws, carve(nullptr, K, P, num_inputs).total))) return rc;
-  BatchWs w = carve(c.prove_ws.p, K, P, num_inputs);
+  const bool coeffs = form == CAPGPU_INPUT_COEFFS;
+  if ((rc = scratch_reserve(c.prove_ws, carve(nullptr, K, P, num_inputs, coeffs).total))) return rc;
+  BatchWs w = carve(c.prove_ws.p, K, P, num_inputs, coeffs);
   const NttDomain* dom_n = nullptr;
   const Ntt3Domain* dom_q = nullptr;
   if ((rc = get_domain(K.log_n, &dom_n))) return rc;
@@ -447,7 +460,12 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
       }
     }
     fe* wp = w.wpoly + (size_t)p0 * NW * ps;
-    if ((rc = run_ntt_from(s, K.log_n, d_wires + wo, n, n, wp, ps, cnt * NW, 1, 0))) return rc;
+    if (coeffs) {
+      pad_copy(s, wp, ps, 0, d_wires + wo, n, 0, 1, cnt * NW, n, n);
+      if ((rc = run_ntt_from(s, K.log_n, d_wires + wo, n, n, w.wev + wo, n, cnt * NW, 0, 0))) return rc;
+    } else if ((rc = run_ntt_from(s, K.log_n, d_wires + wo, n, n, wp, ps, cnt * NW, 1, 0))) {
+      return rc;
+    }
     launch("k_blind", k_blind<1>, dim3(cnt * NW), dim3(64), 0, s, wp, ps, n, (const fe*)(w.d_blind + (size_t)p0 * 13),
            (uint32_t)NW, 0u, 2u, cnt * NW);
     if (chunks > 1 && (rc = run_msm(s, *B, wp, ps, 1, 0, n + 2, cnt * NW, w.comms + (size_t)p0 * NW))) return rc;
@@ -481,7 +499,8 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   CAP_HIP(hipMemcpyAsync(w.chal, chal.data(), sizeof(Chal) * P, hipMemcpyHostToDevice, s));
 
   // ---- round 2: permutation grand product --------------------------------------------------------------
-  launch("k_perm_numden", k_perm_numden, dim3(cdiv(n, kThreads), P), dim3(kThreads), 0, s, d_wires,
+  launch("k_perm_numden", k_perm_numden, dim3(cdiv(n, kThreads), P), dim3(kThreads), 0, s,
+         coeffs ? (const fe*)w.wev : d_wires,
          (const fe*)K.sig_eval, sig_of, (const fe*)dom_n->tw_fwd, (const Chal*)w.chal, K.qc29, n, w.num, w.den);
   {
     uint32_t nb = cdiv(n, kScanBlock);
@@ -783,6 +802,7 @@ struct ProveReq {
   size_t msg_len;
   const uint64_t* blinders;
   capgpu_proof* out;
+  int form = CAPGPU_INPUT_EVALS;  // the requests of one gathered batch share it (it is part of the group id)
   int rc = CAPGPU_OK;
   std::string err;
   bool done = false;
@@ -863,8 +883,9 @@ int lookup_key(uint64_t h, std::shared_ptr<ProvingKey>* out) {
   std::shared_ptr<ProvingKey> home, rep;
   int rc = home_key(h, &home);
   if (rc) return rc;
-  if (home->device == c.device) rep = home;
+  if (home->device == c.device && !force_replicate()) rep = home;
   else if ((rc = clone_key_to_current(*home, home->device, &rep))) return rc;
+  else rt().replications++;
   if ((rc = home_key(h, &home))) return rc;  // freed while it was being copied
   c.keys[h] = rep;
   *out = rep;
@@ -877,9 +898,17 @@ using namespace cap;
 
 extern "C" {
 
-int capgpu_plonk_preprocess(uint64_t srs_handle, size_t n, size_t num_inputs, const uint64_t* selectors,
-                            const uint64_t* sigma_evals, uint64_t* pk_handle_out, capgpu_verifying_key* vk_out) {
+static bool bad_form(int form) {
+  if (form == CAPGPU_INPUT_EVALS || form == CAPGPU_INPUT_COEFFS) return false;
+  set_error("capgpu_plonk: input_form %d is neither CAPGPU_INPUT_EVALS (0) nor CAPGPU_INPUT_COEFFS (1)", form);
+  return true;
+}
+
+int capgpu_plonk_preprocess_ex(uint64_t srs_handle, size_t n, size_t num_inputs, const uint64_t* selectors,
+                               const uint64_t* sigma_evals, int input_form, uint64_t* pk_handle_out,
+                               capgpu_verifying_key* vk_out) {
   CAP_CHECK_INIT();
+  if (bad_form(input_form)) return CAPGPU_ERR_INVALID_ARG;
   Context& c = ctx();
   Entry lk(c);
   // n >= 16: the five split-quotient commitments read 5 (n + 2) coefficients of the 6n-point quotient array
@@ -906,7 +935,13 @@ int capgpu_plonk_preprocess(uint64_t srs_handle, size_t n, size_t num_inputs, co
   CAP_HIP(hipMemcpyAsync(stage.p + (size_t)NS * n, sigma_evals, sizeof(fe) * NW * n, hipMemcpyHostToDevice, s));
   CAP_HIP(hipMemcpyAsync(K->sig_eval, stage.p + (size_t)NS * n, sizeof(fe) * NW * n, hipMemcpyDeviceToDevice, s));
   pad_copy(s, K->coef, ps, 0, stage.p, n, 0, 1, 18, n, ps);
-  if ((rc = run_ntt(s, K->log_n, K->coef, ps, 18, 1, 0))) return rc;
+  if (input_form == CAPGPU_INPUT_COEFFS) {
+    // the 18 polynomials arrive as jf-relation computes them (compute_selector_polynomials /
+    // compute_extended_permutation_polynomials): nothing to interpolate; round 2 reads sigma's VALUES on the domain
+    if ((rc = run_ntt(s, K->log_n, K->sig_eval, n, NW, 0, 0))) return rc;
+  } else if ((rc = run_ntt(s, K->log_n, K->coef, ps, 18, 1, 0))) {
+    return rc;
+  }
   if ((rc = key_finish_tables(s, *K))) return rc;
   // verifying key: commitments of the 18 polynomials
   CAP_HIP(d_comms.alloc(18));
@@ -920,6 +955,12 @@ int capgpu_plonk_preprocess(uint64_t srs_handle, size_t n, size_t num_inputs, co
   if (vk_out) *vk_out = K->vk;
   *pk_handle_out = register_key(K);
   return take_launch_error();
+}
+
+int capgpu_plonk_preprocess(uint64_t srs_handle, size_t n, size_t num_inputs, const uint64_t* selectors,
+                            const uint64_t* sigma_evals, uint64_t* pk_handle_out, capgpu_verifying_key* vk_out) {
+  return capgpu_plonk_preprocess_ex(srs_handle, n, num_inputs, selectors, sigma_evals, CAPGPU_INPUT_EVALS, pk_handle_out,
+                                    vk_out);
 }
 
 // ---- ProvingKey blob (layout in include/capgpu.h) ---------------------------------------------
@@ -1173,10 +1214,11 @@ int capgpu_plonk_free_key(uint64_t pk_handle) {
   return CAPGPU_OK;
 }
 
-int capgpu_plonk_prove_batch_dev(uint64_t pk_handle, int count, const void* d_wires, const uint64_t* pub_inputs,
-                                 size_t num_inputs, const uint8_t* ext_msg, size_t ext_msg_len,
-                                 const uint64_t* blinders, capgpu_proof* proofs_out) {
+int capgpu_plonk_prove_batch_dev_ex(uint64_t pk_handle, int count, const void* d_wires, const uint64_t* pub_inputs,
+                                    size_t num_inputs, const uint8_t* ext_msg, size_t ext_msg_len,
+                                    const uint64_t* blinders, int input_form, capgpu_proof* proofs_out) {
   CAP_CHECK_INIT();
+  if (bad_form(input_form)) return CAPGPU_ERR_INVALID_ARG;
   Context& c = ctx();
   Entry lk(c);
   if (count < 0 || (count && (!d_wires || !blinders || !proofs_out || (num_inputs && !pub_inputs)))) {
@@ -1188,7 +1230,13 @@ int capgpu_plonk_prove_batch_dev(uint64_t pk_handle, int count, const void* d_wi
   int rc = lookup_key(pk_handle, &K);
   if (rc) return rc;
   return prove_batch(*K, (uint32_t)count, (const fe*)d_wires, pub_inputs, num_inputs, ext_msg, ext_msg_len, blinders,
-                     proofs_out);
+                     proofs_out, nullptr, nullptr, nullptr, nullptr, input_form);
+}
+int capgpu_plonk_prove_batch_dev(uint64_t pk_handle, int count, const void* d_wires, const uint64_t* pub_inputs,
+                                 size_t num_inputs, const uint8_t* ext_msg, size_t ext_msg_len,
+                                 const uint64_t* blinders, capgpu_proof* proofs_out) {
+  return capgpu_plonk_prove_batch_dev_ex(pk_handle, count, d_wires, pub_inputs, num_inputs, ext_msg, ext_msg_len,
+                                         blinders, CAPGPU_INPUT_EVALS, proofs_out);
 }
 
 // ---- dealing host-buffer batches over the device contexts -------------------------------------------------------
@@ -1204,7 +1252,10 @@ static int deal_min() {  // proofs a part must hold at least (smaller batches st
 static int deal(int count, const std::function<int(int first, int cnt)>& part) {
   const size_t S = num_contexts();
   const size_t parts = std::min<size_t>(S, (size_t)std::max(count / deal_min(), 1));
-  if (thread_bound_slot() >= 0 || S <= 1 || parts <= 1 || thread_entry_depth() > 0) {
+  // Mode A (capgpu_plonk_shard_msm): the ranks of the communicator prove the same batch in lock step, so the batch stays
+  // whole and on the communicator's context - cut over contexts, one part would run unsharded and which proofs meet in
+  // an exchange would depend on a cursor the ranks do not share (pick_context sends it there)
+  if (comm_shard_slot() >= 0 || thread_bound_slot() >= 0 || S <= 1 || parts <= 1 || thread_entry_depth() > 0) {
     Context& c = pick_context();
     ScopedCtx sc(c);
     return part(0, count);
@@ -1230,10 +1281,11 @@ static int deal(int count, const std::function<int(int first, int cnt)>& part) {
   return CAPGPU_OK;
 }
 
-int capgpu_plonk_prove_batch(uint64_t pk_handle, int count, const uint64_t* wires, const uint64_t* pub_inputs,
-                             size_t num_inputs, const uint8_t* ext_msg, size_t ext_msg_len, const uint64_t* blinders,
-                             capgpu_proof* proofs_out) {
+int capgpu_plonk_prove_batch_ex(uint64_t pk_handle, int count, const uint64_t* wires, const uint64_t* pub_inputs,
+                                size_t num_inputs, const uint8_t* ext_msg, size_t ext_msg_len, const uint64_t* blinders,
+                                int input_form, capgpu_proof* proofs_out) {
   CAP_CHECK_INIT();
+  if (bad_form(input_form)) return CAPGPU_ERR_INVALID_ARG;
   if (count < 0 || (count && !wires)) {
     set_error("capgpu_plonk_prove: bad argument");
     return CAPGPU_ERR_INVALID_ARG;
@@ -1260,15 +1312,23 @@ int capgpu_plonk_prove_batch(uint64_t pk_handle, int count, const uint64_t* wire
     for (int i = 0; i < cnt; i++) rows[i] = wires + (size_t)4 * (first + i) * NW * n;
     return prove_batch(*K, (uint32_t)cnt, (const fe*)c.stage_b.p, pub_inputs ? pub_inputs + (size_t)4 * first * num_inputs : nullptr,
                        num_inputs, ext_msg, ext_msg_len, blinders + (size_t)4 * 13 * first, proofs_out + first, nullptr,
-                       nullptr, nullptr, rows.data());
+                       nullptr, nullptr, rows.data(), input_form);
   });
+}
+int capgpu_plonk_prove_batch(uint64_t pk_handle, int count, const uint64_t* wires, const uint64_t* pub_inputs,
+                             size_t num_inputs, const uint8_t* ext_msg, size_t ext_msg_len, const uint64_t* blinders,
+                             capgpu_proof* proofs_out) {
+  return capgpu_plonk_prove_batch_ex(pk_handle, count, wires, pub_inputs, num_inputs, ext_msg, ext_msg_len, blinders,
+                                     CAPGPU_INPUT_EVALS, proofs_out);
 }
 
 // Proofs of several proving keys in one device batch (see prove_batch): pk_handles[i] is the key of proof i.
-int capgpu_plonk_prove_multi_dev(const uint64_t* pk_handles, int count, const void* d_wires, const uint64_t* pub_inputs,
-                                 size_t num_inputs, const uint8_t* const* ext_msgs, const size_t* ext_msg_lens,
-                                 const uint64_t* blinders, capgpu_proof* proofs_out) {
+int capgpu_plonk_prove_multi_dev_ex(const uint64_t* pk_handles, int count, const void* d_wires,
+                                    const uint64_t* pub_inputs, size_t num_inputs, const uint8_t* const* ext_msgs,
+                                    const size_t* ext_msg_lens, const uint64_t* blinders, int input_form,
+                                    capgpu_proof* proofs_out) {
   CAP_CHECK_INIT();
+  if (bad_form(input_form)) return CAPGPU_ERR_INVALID_ARG;
   Context& c = ctx();
   Entry lk(c);
   if (count < 0 || (count && (!pk_handles || !d_wires || !blinders || !proofs_out || (num_inputs && !pub_inputs) ||
@@ -1285,13 +1345,21 @@ int capgpu_plonk_prove_multi_dev(const uint64_t* pk_handles, int count, const vo
     keys[i] = hold[i].get();
   }
   return prove_batch(*keys[0], (uint32_t)count, (const fe*)d_wires, pub_inputs, num_inputs, nullptr, 0, blinders,
-                     proofs_out, ext_msgs, ext_msg_lens, &keys);
+                     proofs_out, ext_msgs, ext_msg_lens, &keys, nullptr, input_form);
+}
+int capgpu_plonk_prove_multi_dev(const uint64_t* pk_handles, int count, const void* d_wires, const uint64_t* pub_inputs,
+                                 size_t num_inputs, const uint8_t* const* ext_msgs, const size_t* ext_msg_lens,
+                                 const uint64_t* blinders, capgpu_proof* proofs_out) {
+  return capgpu_plonk_prove_multi_dev_ex(pk_handles, count, d_wires, pub_inputs, num_inputs, ext_msgs, ext_msg_lens,
+                                         blinders, CAPGPU_INPUT_EVALS, proofs_out);
 }
 
-int capgpu_plonk_prove_multi(const uint64_t* pk_handles, int count, const uint64_t* wires, const uint64_t* pub_inputs,
-                             size_t num_inputs, const uint8_t* const* ext_msgs, const size_t* ext_msg_lens,
-                             const uint64_t* blinders, capgpu_proof* proofs_out) {
+int capgpu_plonk_prove_multi_ex(const uint64_t* pk_handles, int count, const uint64_t* wires,
+                                const uint64_t* pub_inputs, size_t num_inputs, const uint8_t* const* ext_msgs,
+                                const size_t* ext_msg_lens, const uint64_t* blinders, int input_form,
+                                capgpu_proof* proofs_out) {
   CAP_CHECK_INIT();
+  if (bad_form(input_form)) return CAPGPU_ERR_INVALID_ARG;
   if (count < 0 || (count && (!wires || !pk_handles))) {
     set_error("capgpu_plonk_prove_multi: bad argument");
     return CAPGPU_ERR_INVALID_ARG;
@@ -1336,8 +1404,14 @@ int capgpu_plonk_prove_multi(const uint64_t* pk_handles, int count, const uint64
     for (int i = 0; i < cnt; i++) rows[i] = wires + (size_t)4 * (first + i) * NW * n;
     return prove_batch(*keys[0], (uint32_t)cnt, (const fe*)c.stage_b.p, pp, ni, nullptr, 0,
                        blinders + (size_t)4 * 13 * first, proofs_out + first, ext_msgs ? ext_msgs + first : nullptr,
-                       ext_msg_lens ? ext_msg_lens + first : nullptr, &keys, rows.data());
+                       ext_msg_lens ? ext_msg_lens + first : nullptr, &keys, rows.data(), input_form);
   });
+}
+int capgpu_plonk_prove_multi(const uint64_t* pk_handles, int count, const uint64_t* wires, const uint64_t* pub_inputs,
+                             size_t num_inputs, const uint8_t* const* ext_msgs, const size_t* ext_msg_lens,
+                             const uint64_t* blinders, capgpu_proof* proofs_out) {
+  return capgpu_plonk_prove_multi_ex(pk_handles, count, wires, pub_inputs, num_inputs, ext_msgs, ext_msg_lens, blinders,
+                                     CAPGPU_INPUT_EVALS, proofs_out);
 }
 
 // one gathered batch: device staging of every request's wires, per-proof messages and keys; a batch that fails because
@@ -1361,7 +1435,7 @@ static void run_coalesced(std::vector<ProveReq*>& reqs) {
     if (rc == CAPGPU_OK) {
       const uint64_t* row = r->wires;
       rc = prove_batch(*K, 1, (const fe*)c.stage_b.p, r->pubs, r->num_inputs, r->msg, r->msg_len, r->blinders, r->out,
-                       nullptr, nullptr, nullptr, &row);
+                       nullptr, nullptr, nullptr, &row, r->form);
     }
     r->rc = rc;
     if (rc) r->err = capgpu_last_error();
@@ -1417,7 +1491,7 @@ static void run_coalesced(std::vector<ProveReq*>& reqs) {
     keys[i] = hold[i].get();
   }
   rc = prove_batch(*keys[0], (uint32_t)g, (const fe*)c.stage_b.p, pubs.data(), ni, nullptr, 0, blind.data(), out.data(),
-                   msgs.data(), lens.data(), mixed ? &keys : nullptr, rows.data());
+                   msgs.data(), lens.data(), mixed ? &keys : nullptr, rows.data(), good[0]->form);
   if (rc == CAPGPU_OK) rc = take_launch_error();
   if (rc == CAPGPU_OK) {
     for (size_t i = 0; i < g; i++) *good[i]->out = out[i];
@@ -1433,22 +1507,26 @@ static void run_coalesced(std::vector<ProveReq*>& reqs) {
   coalescer().proofs += g;
 }
 
-int capgpu_plonk_prove(uint64_t pk_handle, const uint64_t* wires, const uint64_t* pub_inputs, size_t num_inputs,
-                       const uint8_t* ext_msg, size_t ext_msg_len, const uint64_t* blinders, capgpu_proof* proof_out) {
+int capgpu_plonk_prove_ex(uint64_t pk_handle, const uint64_t* wires, const uint64_t* pub_inputs, size_t num_inputs,
+                          const uint8_t* ext_msg, size_t ext_msg_len, const uint64_t* blinders, int input_form,
+                          capgpu_proof* proof_out) {
   Coalescer& co = coalescer();
   if (co.window_us == 0)
-    return capgpu_plonk_prove_batch(pk_handle, 1, wires, pub_inputs, num_inputs, ext_msg, ext_msg_len, blinders,
-                                    proof_out);
+    return capgpu_plonk_prove_batch_ex(pk_handle, 1, wires, pub_inputs, num_inputs, ext_msg, ext_msg_len, blinders,
+                                       input_form, proof_out);
   CAP_CHECK_INIT();
+  if (bad_form(input_form)) return CAPGPU_ERR_INVALID_ARG;
   if (!wires || !blinders || !proof_out || (num_inputs && !pub_inputs)) {
     set_error("capgpu_plonk_prove: bad argument");
     return CAPGPU_ERR_INVALID_ARG;
   }
-  ProveReq req{pk_handle, wires, pub_inputs, num_inputs, ext_msg, ext_msg_len, blinders, proof_out};
+  ProveReq req{pk_handle, wires, pub_inputs, num_inputs, ext_msg, ext_msg_len, blinders, proof_out, input_form};
   std::unique_lock<std::mutex> lk(co.mu);
   uint64_t group = 0;
   {
-    auto it = co.group_of.find(pk_handle);
+    // (key, form) -> group: bit 7 of the group id is the input form, the bits below it the domain size
+    const uint64_t gkey = (pk_handle << 1) | (uint64_t)(input_form == CAPGPU_INPUT_COEFFS);
+    auto it = co.group_of.find(gkey);
     if (it == co.group_of.end()) {
       // first call for this key: its domain size and SRS make the group
       lk.unlock();
@@ -1457,8 +1535,9 @@ int capgpu_plonk_prove(uint64_t pk_handle, const uint64_t* wires, const uint64_t
       int rc = capgpu_plonk_key_info(pk_handle, &kn, nullptr, &ksrs);
       if (rc) return rc;
       lk.lock();
-      group = (ksrs << 8) ^ (uint64_t)__builtin_ctzll(kn | (1ull << 63));
-      co.group_of[pk_handle] = group;
+      group = (ksrs << 8) ^ (uint64_t)__builtin_ctzll(kn | (1ull << 63)) ^
+              ((uint64_t)(input_form == CAPGPU_INPUT_COEFFS) << 7);
+      co.group_of[gkey] = group;
     } else {
       group = it->second;
     }
@@ -1490,7 +1569,8 @@ int capgpu_plonk_prove(uint64_t pk_handle, const uint64_t* wires, const uint64_t
     // this thread bound itself to.  Later arrivals join the queue meanwhile.
     Context* c = nullptr;
     for (;;) {
-      const int bound = thread_bound_slot();
+      const int ss = comm_shard_slot();  // mode A: gathered batches go to the communicator's context, whole
+      const int bound = ss >= 0 && (size_t)ss < num_contexts() ? ss : thread_bound_slot();
       if (bound >= 0) {
         Context* b = rt().ctxs[(size_t)bound].get();
         if (b->mu.try_lock()) c = b;
@@ -1509,7 +1589,7 @@ int capgpu_plonk_prove(uint64_t pk_handle, const uint64_t* wires, const uint64_t
     // overlap on the device, or run on two devices
     std::vector<ProveReq*> second;
     Context* c2 = nullptr;
-    if (reqs.size() >= 2 * (size_t)deal_min() && thread_bound_slot() < 0 && num_contexts() > 1 &&
+    if (reqs.size() >= 2 * (size_t)deal_min() && thread_bound_slot() < 0 && comm_shard_slot() < 0 && num_contexts() > 1 &&
         (c2 = try_acquire_context()) != nullptr) {
       c2->mu.unlock();  // the helper thread locks it itself (the lock belongs to the thread that takes it)
       const size_t half = reqs.size() / 2;
@@ -1536,6 +1616,12 @@ int capgpu_plonk_prove(uint64_t pk_handle, const uint64_t* wires, const uint64_t
   }
   if (req.rc != CAPGPU_OK) set_error("%s", req.err.c_str());
   return req.rc;
+}
+
+int capgpu_plonk_prove(uint64_t pk_handle, const uint64_t* wires, const uint64_t* pub_inputs, size_t num_inputs,
+                       const uint8_t* ext_msg, size_t ext_msg_len, const uint64_t* blinders, capgpu_proof* proof_out) {
+  return capgpu_plonk_prove_ex(pk_handle, wires, pub_inputs, num_inputs, ext_msg, ext_msg_len, blinders,
+                               CAPGPU_INPUT_EVALS, proof_out);
 }
 
 int capgpu_plonk_set_coalescing(uint32_t window_us, uint32_t max_batch) {

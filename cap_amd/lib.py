@@ -382,16 +382,29 @@ def profile_stats() -> dict:
 
 
 # ---- PLONK ---------------------------------------------------------------------------------------
-def plonk_preprocess(srs_handle: int, n: int, num_inputs: int, selectors: np.ndarray, sigma_evals: np.ndarray):
-    """selectors (13, n, 4), sigma_evals (5, n, 4) Montgomery -> (pk handle, VerifyingKey)."""
+INPUT_EVALS, INPUT_COEFFS = 0, 1  # CAPGPU_INPUT_* of include/capgpu.h
+
+
+def _form(input_form) -> int:
+    """'evals' / 'coeffs' / 0 / 1 -> the ABI's input_form integer (anything else is passed on for the library to refuse)"""
+    if isinstance(input_form, str):
+        return {"evals": INPUT_EVALS, "coeffs": INPUT_COEFFS}[input_form]
+    return int(input_form)
+
+
+def plonk_preprocess(srs_handle: int, n: int, num_inputs: int, selectors: np.ndarray, sigma_evals: np.ndarray,
+                     input_form=INPUT_EVALS):
+    """selectors (13, n, 4), sigma_evals (5, n, 4) Montgomery -> (pk handle, VerifyingKey).  input_form = 'coeffs':
+    the 18 columns are polynomials in coefficient form (capgpu_plonk_preprocess_ex)."""
     selectors = np.ascontiguousarray(selectors, dtype=np.uint64)
     sigma_evals = np.ascontiguousarray(sigma_evals, dtype=np.uint64)
     assert selectors.size == NUM_SELECTORS * n * 4 and sigma_evals.size == NUM_WIRE_TYPES * n * 4
     h = ctypes.c_uint64()
     vk = VerifyingKey()
-    check(load().capgpu_plonk_preprocess(ctypes.c_uint64(srs_handle), ctypes.c_size_t(n), ctypes.c_size_t(num_inputs),
-                                         _p(selectors.reshape(-1)), _p(sigma_evals.reshape(-1)), ctypes.byref(h),
-                                         ctypes.byref(vk)))
+    check(load().capgpu_plonk_preprocess_ex(ctypes.c_uint64(srs_handle), ctypes.c_size_t(n),
+                                            ctypes.c_size_t(num_inputs), _p(selectors.reshape(-1)),
+                                            _p(sigma_evals.reshape(-1)), ctypes.c_int(_form(input_form)),
+                                            ctypes.byref(h), ctypes.byref(vk)))
     return h.value, vk
 
 
@@ -431,8 +444,9 @@ def _bytes_arg(b):
 
 
 def plonk_prove_batch(pk_handle: int, wires: np.ndarray, pub_inputs: np.ndarray, blinders: np.ndarray,
-                      ext_msg: bytes | None = None, count: int = 1):
-    """wires (count, 5, n, 4), pub_inputs (count, l, 4), blinders (count, 13, 4), all Montgomery."""
+                      ext_msg: bytes | None = None, count: int = 1, input_form=INPUT_EVALS):
+    """wires (count, 5, n, 4), pub_inputs (count, l, 4), blinders (count, 13, 4), all Montgomery.  input_form =
+    'coeffs': wires are the unblinded wire polynomials in coefficient form."""
     wires = np.ascontiguousarray(wires, dtype=np.uint64)
     pub_inputs = np.ascontiguousarray(pub_inputs, dtype=np.uint64).reshape(-1)
     blinders = np.ascontiguousarray(blinders, dtype=np.uint64).reshape(-1)
@@ -441,14 +455,14 @@ def plonk_prove_batch(pk_handle: int, wires: np.ndarray, pub_inputs: np.ndarray,
     proofs = (Proof * count)()
     mbuf, mlen = _bytes_arg(ext_msg)
     pub_ptr = _p(pub_inputs) if pub_inputs.size else None
-    check(load().capgpu_plonk_prove_batch(ctypes.c_uint64(pk_handle), count, _p(wires.reshape(-1)), pub_ptr,
-                                          ctypes.c_size_t(num_inputs), mbuf, ctypes.c_size_t(mlen), _p(blinders),
-                                          proofs))
+    check(load().capgpu_plonk_prove_batch_ex(ctypes.c_uint64(pk_handle), count, _p(wires.reshape(-1)), pub_ptr,
+                                             ctypes.c_size_t(num_inputs), mbuf, ctypes.c_size_t(mlen), _p(blinders),
+                                             ctypes.c_int(_form(input_form)), proofs))
     return list(proofs)
 
 
 def plonk_prove(pk_handle: int, wires: np.ndarray, pub_inputs: np.ndarray, blinders: np.ndarray,
-                ext_msg: bytes | None = None) -> Proof:
+                ext_msg: bytes | None = None, input_form=INPUT_EVALS) -> Proof:
     """capgpu_plonk_prove: ONE proof per call - the entry point many host threads call at once (it coalesces their
     calls into device batches when plonk_set_coalescing is on).  wires (5, n, 4), pub_inputs (l, 4), blinders (13, 4)."""
     wires = np.ascontiguousarray(wires, dtype=np.uint64)
@@ -457,9 +471,10 @@ def plonk_prove(pk_handle: int, wires: np.ndarray, pub_inputs: np.ndarray, blind
     num_inputs = _check_prove_shapes(pk_handle, 1, wires.size // 4 if wires.size % 4 == 0 else -1, pub_inputs, blinders)
     proof = Proof()
     mbuf, mlen = _bytes_arg(ext_msg)
-    check(load().capgpu_plonk_prove(ctypes.c_uint64(pk_handle), _p(wires.reshape(-1)),
-                                    _p(pub_inputs) if pub_inputs.size else None, ctypes.c_size_t(num_inputs), mbuf,
-                                    ctypes.c_size_t(mlen), _p(blinders), ctypes.byref(proof)))
+    check(load().capgpu_plonk_prove_ex(ctypes.c_uint64(pk_handle), _p(wires.reshape(-1)),
+                                       _p(pub_inputs) if pub_inputs.size else None, ctypes.c_size_t(num_inputs), mbuf,
+                                       ctypes.c_size_t(mlen), _p(blinders), ctypes.c_int(_form(input_form)),
+                                       ctypes.byref(proof)))
     return proof
 
 
@@ -474,7 +489,7 @@ def plonk_coalescing_stats():
 
 
 def plonk_prove_batch_dev(pk_handle: int, d_wires: DevBuf, pub_inputs: np.ndarray, blinders: np.ndarray,
-                          ext_msg: bytes | None = None, count: int = 1):
+                          ext_msg: bytes | None = None, count: int = 1, input_form=INPUT_EVALS):
     pub_inputs = np.ascontiguousarray(pub_inputs, dtype=np.uint64).reshape(-1)
     blinders = np.ascontiguousarray(blinders, dtype=np.uint64).reshape(-1)
     num_inputs = _check_prove_shapes(pk_handle, count, d_wires.nbytes // 32 if d_wires.nbytes % 32 == 0 else -1,
@@ -482,13 +497,14 @@ def plonk_prove_batch_dev(pk_handle: int, d_wires: DevBuf, pub_inputs: np.ndarra
     proofs = (Proof * count)()
     mbuf, mlen = _bytes_arg(ext_msg)
     pub_ptr = _p(pub_inputs) if pub_inputs.size else None
-    check(load().capgpu_plonk_prove_batch_dev(ctypes.c_uint64(pk_handle), count, d_wires.ptr, pub_ptr,
-                                              ctypes.c_size_t(num_inputs), mbuf, ctypes.c_size_t(mlen), _p(blinders),
-                                              proofs))
+    check(load().capgpu_plonk_prove_batch_dev_ex(ctypes.c_uint64(pk_handle), count, d_wires.ptr, pub_ptr,
+                                                 ctypes.c_size_t(num_inputs), mbuf, ctypes.c_size_t(mlen),
+                                                 _p(blinders), ctypes.c_int(_form(input_form)), proofs))
     return list(proofs)
 
 
-def plonk_prove_multi(pk_handles, wires, pub_rows: np.ndarray, blinders: np.ndarray, ext_msgs=None):
+def plonk_prove_multi(pk_handles, wires, pub_rows: np.ndarray, blinders: np.ndarray, ext_msgs=None,
+                      input_form=INPUT_EVALS):
     """Proofs of several proving keys (one domain size, one SRS) in one device batch: pk_handles[i] is proof i's key.
     wires: (count, 5, n, 4) numpy array or a DevBuf of that content; pub_rows: (count, max_inputs, 4) - a key with fewer
     public inputs uses the first of its row; ext_msgs: one bytes object per proof, or None."""
@@ -519,14 +535,15 @@ def plonk_prove_multi(pk_handles, wires, pub_rows: np.ndarray, blinders: np.ndar
     if isinstance(wires, DevBuf):
         if wires.nbytes != count * NUM_WIRE_TYPES * n * 32:
             raise ValueError("plonk_prove_multi: the wire buffer does not hold count x 5 x n elements")
-        check(load().capgpu_plonk_prove_multi_dev(handles, count, wires.ptr, pub_ptr, ctypes.c_size_t(max_in), msgs_arg,
-                                                  lens_arg, _p(blinders), proofs))
+        check(load().capgpu_plonk_prove_multi_dev_ex(handles, count, wires.ptr, pub_ptr, ctypes.c_size_t(max_in),
+                                                     msgs_arg, lens_arg, _p(blinders), ctypes.c_int(_form(input_form)),
+                                                     proofs))
     else:
         wires = np.ascontiguousarray(wires, dtype=np.uint64).reshape(-1)
         if wires.size != count * NUM_WIRE_TYPES * n * 4:
             raise ValueError("plonk_prove_multi: wires must hold count x 5 x n elements")
-        check(load().capgpu_plonk_prove_multi(handles, count, _p(wires), pub_ptr, ctypes.c_size_t(max_in), msgs_arg,
-                                              lens_arg, _p(blinders), proofs))
+        check(load().capgpu_plonk_prove_multi_ex(handles, count, _p(wires), pub_ptr, ctypes.c_size_t(max_in), msgs_arg,
+                                                 lens_arg, _p(blinders), ctypes.c_int(_form(input_form)), proofs))
     return list(proofs)
 
 

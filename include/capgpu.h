@@ -71,6 +71,20 @@ extern "C" {
 #define CAPGPU_NUM_WIRE_TYPES 5
 #define CAPGPU_NUM_SELECTORS 13
 
+/* Form in which the *_ex PLONK entry points take a circuit's columns (wires, selectors, sigmas):
+ *   CAPGPU_INPUT_EVALS   values on the evaluation domain - n per column, row j = the value at omega^j: the finalised
+ *                        circuit's tables (what the entry points without _ex take);
+ *   CAPGPU_INPUT_COEFFS  polynomials in coefficient form - n coefficients per column, zero-padded: exactly what
+ *                        jf-relation's `Arithmetization` trait hands the prover (`compute_wire_polynomials`,
+ *                        `compute_selector_polynomials`, `compute_extended_permutation_polynomials`; the reference
+ *                        holds that circuit object at src/proof/transfer.rs:181-186 and :124-155, mint.rs:76/113,
+ *                        freeze.rs:102/151).  The device then skips its own interpolation and runs one forward
+ *                        transform where the permutation product needs the values; a Rust binding passes the trait's
+ *                        output straight through instead of undoing its interpolation on the CPU.
+ * Both forms give the same proof and the same keys, byte for byte. */
+#define CAPGPU_INPUT_EVALS 0
+#define CAPGPU_INPUT_COEFFS 1
+
 /* ---- lifecycle ------------------------------------------------------------------------- */
 /* Binds this process to the n_devices GPUs listed in device_ids (NULL / 0 selects HIP device 0): one device context
  * - stream, resident tables, scratch, lock - per id, numbered 0 .. n_devices - 1 in the order given ("slots").  The
@@ -104,6 +118,11 @@ const char* capgpu_last_error(void);
 const char* capgpu_version(void);
 /* name (<= 255 chars + NUL), compute units, HBM bytes of the bound device */
 int capgpu_device_info(char* name_out, int* cu_count_out, uint64_t* hbm_bytes_out);
+/* Memory path between the devices of two contexts, settled by capgpu_init (hipDeviceCanAccessPeer +
+ * hipDeviceEnablePeerAccess for every bound pair): *access_out = 1 direct peer access (xGMI / PCIe P2P: replication of
+ * keys and SRS tables, scalar slices and partials of sharded MSMs travel device to device), 0 none (the runtime stages
+ * such copies through host memory; everything still works), 2 the two contexts share one device. */
+int capgpu_device_peer_info(int slot_a, int slot_b, int* access_out);
 /* free / total device memory of the calling thread's device, in bytes (hipMemGetInfo) */
 int capgpu_mem_info(uint64_t* free_bytes_out, uint64_t* total_bytes_out);
 
@@ -154,6 +173,28 @@ int capgpu_msm_g1_batch(uint64_t srs_handle, const size_t* offsets, const uint64
  * d_out_xyz = count * 96 bytes on device. */
 int capgpu_msm_g1_dev(uint64_t srs_handle, size_t offset, const void* d_scalars, size_t scalar_stride, size_t n,
                       int count, int scalars_montgomery, void* d_out_xyz);
+
+/* ---- scalars resident with their points ("GPU g holds its bases resident and receives the matching scalar
+ * slice") ------------------------------------------------------------------------------------------------------------
+ * capgpu_msm_g1_dev on a sharded SRS has to scatter the caller's scalars over the devices on EVERY call (32 B x n leaving
+ * one GPU: 448 MB of a 2^24-point MSM).  A caller that runs more than one MSM on the same scalars - or that can place
+ * them once, ahead of time - makes them resident instead: `count` arrays over points [offset, offset + n) are cut by
+ * the SRS's point ranges, each slice stored on the device that holds its points (host memory goes to each device
+ * directly; device memory of the calling thread's context by one peer copy per slice).  capgpu_msm_g1_resident then
+ * exchanges nothing but the 96-byte partials.  Works on an unsharded SRS too (one slice, on the calling thread's
+ * context).  The set is immutable; free it with capgpu_msm_scalars_free (capgpu_shutdown frees what is left). */
+int capgpu_msm_scalars_upload(uint64_t srs_handle, size_t offset, const uint64_t* scalars, size_t scalar_stride,
+                              size_t n, int count, uint64_t* scalars_handle_out);
+int capgpu_msm_scalars_scatter_dev(uint64_t srs_handle, size_t offset, const void* d_scalars, size_t scalar_stride,
+                                   size_t n, int count, uint64_t* scalars_handle_out);
+int capgpu_msm_scalars_free(uint64_t scalars_handle);
+/* d_out_xyz: count * 96 bytes on the calling thread's device, as capgpu_msm_g1_dev */
+int capgpu_msm_g1_resident(uint64_t srs_handle, uint64_t scalars_handle, int scalars_montgomery, void* d_out_xyz);
+/* Bytes moved between device contexts (or from the host) by sharded MSMs since capgpu_init - scalar slices and
+ * 96-byte partials -, the number of sharded MSM calls, and how many times an SRS or proving key was replicated onto
+ * another context.  Any out pointer may be NULL. */
+int capgpu_msm_shard_stats(uint64_t* scalar_bytes_out, uint64_t* partial_bytes_out, uint64_t* calls_out,
+                           uint64_t* replications_out);
 
 /* Diagnostic: which window table, sort and split `count` MSMs of n points on this SRS would take, as text
  * ("c=15 windows=18 sort=two-level parts=256 n_sub=65536 slice=1").  Tests pin the plan of the BASELINE sizes with
@@ -238,6 +279,12 @@ typedef struct capgpu_verifying_key {
  * coefficients and the 5 (n + 2) the split-quotient commitments read), n + 3 <= SRS size. */
 int capgpu_plonk_preprocess(uint64_t srs_handle, size_t n, size_t num_inputs, const uint64_t* selectors,
                             const uint64_t* sigma_evals, uint64_t* pk_handle_out, capgpu_verifying_key* vk_out);
+/* The same with the columns in `input_form` (above): CAPGPU_INPUT_COEFFS takes the 13 selector polynomials and the 5
+ * extended-permutation polynomials, n coefficients each (a DensePolynomial shorter than n is zero-padded by the
+ * caller), in the same column order. */
+int capgpu_plonk_preprocess_ex(uint64_t srs_handle, size_t n, size_t num_inputs, const uint64_t* selectors,
+                               const uint64_t* sigmas, int input_form, uint64_t* pk_handle_out,
+                               capgpu_verifying_key* vk_out);
 int capgpu_plonk_free_key(uint64_t pk_handle);
 /* Shape of a resident proving key: the sizes every prove call's arrays must have (wires: count * 5 * domain_size
  * field elements, pub_inputs: count * num_inputs, blinders: count * 13) and the SRS it commits with.  Any out
@@ -288,6 +335,28 @@ int capgpu_plonk_prove_multi_dev(const uint64_t* pk_handles, int count, const vo
 int capgpu_plonk_prove_batch_dev(uint64_t pk_handle, int count, const void* d_wires, const uint64_t* pub_inputs,
                                  size_t num_inputs, const uint8_t* ext_msg, size_t ext_msg_len,
                                  const uint64_t* blinders, capgpu_proof* proofs_out);
+
+/* The prove entry points with the wire columns in `input_form` (above).  CAPGPU_INPUT_COEFFS: `wires` holds, per proof,
+ * the 5 UNBLINDED wire polynomials of n coefficients (jf-relation's compute_wire_polynomials; the blinders are added on
+ * the device as before).  Everything else - layouts, batching over contexts, coalescing (calls of different forms are
+ * gathered separately), errors - is that of the entry point without _ex, which is the _ex one with CAPGPU_INPUT_EVALS. */
+int capgpu_plonk_prove_ex(uint64_t pk_handle, const uint64_t* wires, const uint64_t* pub_inputs, size_t num_inputs,
+                          const uint8_t* ext_msg, size_t ext_msg_len, const uint64_t* blinders, int input_form,
+                          capgpu_proof* proof_out);
+int capgpu_plonk_prove_batch_ex(uint64_t pk_handle, int count, const uint64_t* wires, const uint64_t* pub_inputs,
+                                size_t num_inputs, const uint8_t* ext_msg, size_t ext_msg_len,
+                                const uint64_t* blinders, int input_form, capgpu_proof* proofs_out);
+int capgpu_plonk_prove_multi_ex(const uint64_t* pk_handles, int count, const uint64_t* wires,
+                                const uint64_t* pub_inputs, size_t num_inputs, const uint8_t* const* ext_msgs,
+                                const size_t* ext_msg_lens, const uint64_t* blinders, int input_form,
+                                capgpu_proof* proofs_out);
+int capgpu_plonk_prove_multi_dev_ex(const uint64_t* pk_handles, int count, const void* d_wires,
+                                    const uint64_t* pub_inputs, size_t num_inputs, const uint8_t* const* ext_msgs,
+                                    const size_t* ext_msg_lens, const uint64_t* blinders, int input_form,
+                                    capgpu_proof* proofs_out);
+int capgpu_plonk_prove_batch_dev_ex(uint64_t pk_handle, int count, const void* d_wires, const uint64_t* pub_inputs,
+                                    size_t num_inputs, const uint8_t* ext_msg, size_t ext_msg_len,
+                                    const uint64_t* blinders, int input_form, capgpu_proof* proofs_out);
 
 /* ---- verification (host only: needs neither a GPU nor capgpu_init) ---------------------------------------- */
 /* G2 elements: x.c0, x.c1, y.c0, y.c1 of the twist point (Fq2 = Fq[u]/(u^2+1)), Montgomery, 16 words;

@@ -9,7 +9,8 @@
  * sigma[5][n][4], wires[5][n][4], pub_inputs[l][4], blinders[13][4], ext_msg bytes.
  *
  * It runs: init -> SRS of powers of tau -> NTT round trip (bit-exact) -> preprocess -> prove -> serialize -> verify
- * (accept) -> verify with a flipped public input (reject) -> a batch of two proofs equals two single proofs.
+ * (accept) -> verify with a flipped public input (reject) -> a batch of two proofs equals two single proofs -> the same
+ * key and proofs from COEFFICIENT-form columns (CAPGPU_INPUT_COEFFS, what a jf-relation caller holds) are the same bytes.
  * Output: "PROOF <hex of the 769 ark-serialize bytes>" and "OK"; tests/test_c_harness.py compares the bytes with the
  * golden proof.  Exit codes: 0 ok, 2 no usable GPU (capgpu_init failed: the library has no CPU fallback), 1 anything else. */
 #include <stdint.h>
@@ -144,6 +145,45 @@ int main(int argc, char** argv) {
   if (memcmp(&two[0], &proof, sizeof(proof)) != 0 || memcmp(&two[1], &proof, sizeof(proof)) != 0) {
     fprintf(stderr, "batched proofs differ from the single proof\n");
     return 1;
+  }
+
+  /* The other input form.  A jf-relation caller holds polynomials in coefficient form; here they are made from the
+   * columns with the library's own inverse transform.  Key and proofs must be the same bytes as from the columns. */
+  {
+    uint64_t* selc = (uint64_t*)malloc(13 * n * 32);
+    uint64_t* sigc = (uint64_t*)malloc(5 * n * 32);
+    uint64_t* wc = (uint64_t*)malloc(2 * 5 * n * 32);
+    memcpy(selc, selectors, 13 * n * 32);
+    memcpy(sigc, sigma, 5 * n * 32);
+    memcpy(wc, wires, 5 * n * 32);
+    for (int c = 0; c < 13; c++) CHECK(capgpu_ntt_fr(selc + (size_t)c * n * 4, log_n, 1, 0));
+    for (int c = 0; c < 5; c++) CHECK(capgpu_ntt_fr(sigc + (size_t)c * n * 4, log_n, 1, 0));
+    for (int c = 0; c < 5; c++) CHECK(capgpu_ntt_fr(wc + (size_t)c * n * 4, log_n, 1, 0));
+    memcpy(wc + 5 * n * 4, wc, 5 * n * 32);
+    uint64_t pk2 = 0;
+    capgpu_verifying_key vk2;
+    CHECK(capgpu_plonk_preprocess_ex(srs, n, num_inputs, selc, sigc, CAPGPU_INPUT_COEFFS, &pk2, &vk2));
+    if (memcmp(&vk, &vk2, sizeof(vk)) != 0) {
+      fprintf(stderr, "verifying key from coefficient-form columns differs\n");
+      return 1;
+    }
+    capgpu_proof pc, pc2[2];
+    CHECK(capgpu_plonk_prove_ex(pk2, wc, pubs, num_inputs, msg, msg_len, blinders, CAPGPU_INPUT_COEFFS, &pc));
+    CHECK(capgpu_plonk_prove_batch_ex(pk, 2, wc, p2, num_inputs, msg, msg_len, b2, CAPGPU_INPUT_COEFFS, pc2));
+    if (memcmp(&pc, &proof, sizeof(proof)) != 0 || memcmp(&pc2[0], &proof, sizeof(proof)) != 0 ||
+        memcmp(&pc2[1], &proof, sizeof(proof)) != 0) {
+      fprintf(stderr, "proofs from coefficient-form wires differ from the evaluation-form proof\n");
+      return 1;
+    }
+    if (capgpu_plonk_prove_ex(pk, wires, pubs, num_inputs, msg, msg_len, blinders, 2, &pc) != CAPGPU_ERR_INVALID_ARG) {
+      fprintf(stderr, "an unknown input form was not refused\n");
+      return 1;
+    }
+    printf("COEFFS same bytes\n");
+    CHECK(capgpu_plonk_free_key(pk2));
+    free(selc);
+    free(sigc);
+    free(wc);
   }
   CHECK(capgpu_plonk_free_key(pk));
   CHECK(capgpu_srs_free(srs));
