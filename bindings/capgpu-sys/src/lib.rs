@@ -69,6 +69,7 @@ extern "C" {
     pub fn capgpu_set_device(slot: c_int) -> c_int;
     pub fn capgpu_get_device(slot_out: *mut c_int, hip_device_out: *mut c_int) -> c_int;
     pub fn capgpu_device_info(name_out: *mut c_char, cu_count_out: *mut c_int, hbm_bytes_out: *mut u64) -> c_int;
+    pub fn capgpu_device_peer_info(slot_a: c_int, slot_b: c_int, access_out: *mut c_int) -> c_int;
     pub fn capgpu_mem_info(free_bytes_out: *mut u64, total_bytes_out: *mut u64) -> c_int;
     // ---- device memory / stream
     pub fn capgpu_malloc(dev_ptr_out: *mut *mut c_void, bytes: usize) -> c_int;
@@ -93,6 +94,15 @@ extern "C" {
                                count: c_int, out_xyz: *mut u64) -> c_int;
     pub fn capgpu_msm_g1_dev(srs_handle: u64, offset: usize, d_scalars: *const c_void, scalar_stride: usize, n: usize,
                              count: c_int, scalars_montgomery: c_int, d_out_xyz: *mut c_void) -> c_int;
+    pub fn capgpu_msm_scalars_upload(srs_handle: u64, offset: usize, scalars: *const u64, scalar_stride: usize, n: usize,
+                                     count: c_int, scalars_handle_out: *mut u64) -> c_int;
+    pub fn capgpu_msm_scalars_scatter_dev(srs_handle: u64, offset: usize, d_scalars: *const c_void, scalar_stride: usize,
+                                          n: usize, count: c_int, scalars_handle_out: *mut u64) -> c_int;
+    pub fn capgpu_msm_scalars_free(scalars_handle: u64) -> c_int;
+    pub fn capgpu_msm_g1_resident(srs_handle: u64, scalars_handle: u64, scalars_montgomery: c_int,
+                                  d_out_xyz: *mut c_void) -> c_int;
+    pub fn capgpu_msm_shard_stats(scalar_bytes_out: *mut u64, partial_bytes_out: *mut u64, calls_out: *mut u64,
+                                  replications_out: *mut u64) -> c_int;
     pub fn capgpu_msm_plan(srs_handle: u64, n: usize, count: c_int, buf: *mut c_char, cap: usize) -> c_int;
     pub fn capgpu_g1_sum(points_xyz: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
     // ---- one process per GPU: the RCCL exchange

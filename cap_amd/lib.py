@@ -247,6 +247,56 @@ def msm_g1_dev(handle: int, d_scalars: DevBuf, n: int, count: int = 1, stride: i
     return d_out
 
 
+def msm_scalars_upload(handle: int, scalars: np.ndarray, offset: int = 0) -> int:
+    """scalars (count, n, 4) or (n, 4) in host memory -> a scalar set resident with the SRS's point ranges
+    (capgpu_msm_scalars_upload: each slice goes to the device that holds its points)."""
+    scalars = np.ascontiguousarray(scalars, dtype=np.uint64)
+    scalars = scalars.reshape(1, -1, 4) if scalars.ndim == 2 else scalars
+    count, n = scalars.shape[0], scalars.shape[1]
+    h = ctypes.c_uint64(0)
+    check(load().capgpu_msm_scalars_upload(ctypes.c_uint64(handle), ctypes.c_size_t(offset), _p(scalars.reshape(-1)),
+                                           ctypes.c_size_t(n), ctypes.c_size_t(n), count, ctypes.byref(h)))
+    return h.value
+
+
+def msm_scalars_scatter_dev(handle: int, d_scalars: DevBuf, n: int, count: int = 1, stride: int | None = None,
+                            offset: int = 0) -> int:
+    """the same from device memory of the calling thread's context (one peer copy per slice, once)"""
+    h = ctypes.c_uint64(0)
+    check(load().capgpu_msm_scalars_scatter_dev(ctypes.c_uint64(handle), ctypes.c_size_t(offset), d_scalars.ptr,
+                                                ctypes.c_size_t(n if stride is None else stride), ctypes.c_size_t(n),
+                                                count, ctypes.byref(h)))
+    return h.value
+
+
+def msm_scalars_free(scalars_handle: int):
+    check(load().capgpu_msm_scalars_free(ctypes.c_uint64(scalars_handle)))
+
+
+def msm_g1_resident(handle: int, scalars_handle: int, count: int = 1, montgomery: bool = False,
+                    d_out: DevBuf | None = None) -> DevBuf:
+    """MSM(s) on a resident scalar set: only the 96-byte partials move between devices."""
+    if d_out is None:
+        d_out = DevBuf(96 * count)
+    check(load().capgpu_msm_g1_resident(ctypes.c_uint64(handle), ctypes.c_uint64(scalars_handle), int(montgomery),
+                                        d_out.ptr))
+    return d_out
+
+
+def msm_shard_stats() -> dict:
+    """bytes moved between device contexts (or from the host) by sharded MSMs since init, sharded calls, replications"""
+    a, b, c, d = ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0), ctypes.c_uint64(0)
+    check(load().capgpu_msm_shard_stats(ctypes.byref(a), ctypes.byref(b), ctypes.byref(c), ctypes.byref(d)))
+    return {"scalar_bytes": a.value, "partial_bytes": b.value, "sharded_calls": c.value, "replications": d.value}
+
+
+def device_peer_info(slot_a: int, slot_b: int) -> int:
+    """1: direct peer access between the two contexts' devices, 0: none (copies staged by the runtime), 2: same device"""
+    x = ctypes.c_int(-1)
+    check(load().capgpu_device_peer_info(slot_a, slot_b, ctypes.byref(x)))
+    return x.value
+
+
 def msm_plan(handle: int, n: int, count: int = 1) -> dict:
     """Which table / sort / split `count` MSMs of n points would take: {'c': 15, 'windows': 18, 'sort': 'two-level',
     'parts': 256, 'n_sub': 65536, 'slice': 1}."""

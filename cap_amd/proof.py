@@ -138,29 +138,31 @@ def load_srs(max_degree: int, crs_bytes: bytes, expected_sha256: bytes = AZTEC_C
         raise TxnApiError.FailedSnark(f"Failed to load SRS: {e}") from e
 
 
-def preprocess(srs: UniversalSrs, n: int, num_inputs: int, selectors: np.ndarray, sigma_evals: np.ndarray):
-    """-> (ProvingKey, VerifyingKey, n_constraints).  selectors (13, n, 4) / sigma_evals (5, n, 4), Montgomery."""
+def preprocess(srs: UniversalSrs, n: int, num_inputs: int, selectors: np.ndarray, sigma_evals: np.ndarray,
+               input_form="evals"):
+    """-> (ProvingKey, VerifyingKey, n_constraints).  selectors (13, n, 4) / sigma_evals (5, n, 4), Montgomery;
+    input_form 'coeffs': the columns are the polynomials jf-relation's Arithmetization trait returns."""
     try:
-        h, vk = _lib.plonk_preprocess(srs.handle, n, num_inputs, selectors, sigma_evals)
+        h, vk = _lib.plonk_preprocess(srs.handle, n, num_inputs, selectors, sigma_evals, input_form)
     except _lib.CapGpuError as e:
         raise TxnApiError.FailedSnark(f"Preprocessing circuit of domain size {n} failed: {e}") from e
     return ProvingKey(h, n, num_inputs, srs), VerifyingKey(vk, n, num_inputs, srs.h, srs.beta_h), n
 
 
 def prove(proving_key: ProvingKey, wires: np.ndarray, public_inputs: np.ndarray, blinders: np.ndarray,
-          ext_msg: bytes | None = None):
+          ext_msg: bytes | None = None, input_form="evals"):
     """One proof.  wires (5, n, 4), public_inputs (l, 4), blinders (13, 4): Montgomery words."""
     return prove_batch(proving_key, np.asarray(wires)[None], np.asarray(public_inputs)[None],
-                       np.asarray(blinders)[None], ext_msg)[0]
+                       np.asarray(blinders)[None], ext_msg, input_form)[0]
 
 
 def prove_batch(proving_key: ProvingKey, wires: np.ndarray, public_inputs: np.ndarray, blinders: np.ndarray,
-                ext_msg: bytes | None = None):
+                ext_msg: bytes | None = None, input_form="evals"):
     """`count` independent proofs under one key (the rayon par_iter of
     src/utils/params_builder.rs:194-226 becomes one device batch)."""
     count = int(np.asarray(wires).shape[0])
     try:
-        return _lib.plonk_prove_batch(proving_key.handle, wires, public_inputs, blinders, ext_msg, count)
+        return _lib.plonk_prove_batch(proving_key.handle, wires, public_inputs, blinders, ext_msg, count, input_form)
     except _lib.CapGpuError as e:
         raise TxnApiError.FailedSnark(f"Proof Creation failure: {e}") from e
 

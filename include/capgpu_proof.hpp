@@ -137,10 +137,15 @@ struct FinalisedCircuit {
   const uint64_t* selectors = nullptr;  // 13 x n x 4 words, gate order of capgpu.h
   const uint64_t* sigma = nullptr;      // 5 x n x 4 words: the extended permutation as field elements
   size_t num_gates = 0;              // constraints before padding (preprocess returns it, transfer.rs:155)
+  // CAPGPU_INPUT_EVALS: the columns are tables of values on the domain; CAPGPU_INPUT_COEFFS: they are the polynomials
+  // jf-relation's Arithmetization trait returns (compute_selector_polynomials / compute_extended_permutation_polynomials),
+  // n coefficients each, passed through untransformed
+  int input_form = CAPGPU_INPUT_EVALS;
 };
 struct Assignment {
   const uint64_t* wires = nullptr;       // 5 x n x 4 words
   const uint64_t* pub_inputs = nullptr;  // num_inputs x 4 words  (PublicInput::to_scalars())
+  int input_form = CAPGPU_INPUT_EVALS;   // CAPGPU_INPUT_COEFFS: wires = compute_wire_polynomials(), unblinded
 };
 
 namespace proof {
@@ -249,7 +254,8 @@ inline Result<std::pair<ProvingKey, VerifyingKey>> preprocess(const UniversalSrs
   if (!c.selectors || !c.sigma) return TxnApiError::failed_snark(what + ": circuit not finalised");
   ProvingKey pk;
   uint64_t h = 0;
-  int rc = capgpu_plonk_preprocess(srs.handle(), c.domain_size, c.num_inputs, c.selectors, c.sigma, &h, &pk.vk.raw);
+  int rc = capgpu_plonk_preprocess_ex(srs.handle(), c.domain_size, c.num_inputs, c.selectors, c.sigma, c.input_form, &h,
+                                      &pk.vk.raw);
   if (rc != CAPGPU_OK) return detail::map_error(rc, what);
   pk.key = std::make_shared<detail::KeyHandle>(h);
   pk.srs = srs;
@@ -268,8 +274,9 @@ Result<Proof> prove(Rng& rng, const ProvingKey& pk, const Assignment& a, const s
     std::memcpy(&blinders[4 * i], b.data(), 32);
   }
   Proof p;
-  int rc = capgpu_plonk_prove(pk.handle(), a.wires, a.pub_inputs, pk.num_inputs(), ext_msg ? ext_msg->data() : nullptr,
-                              ext_msg ? ext_msg->size() : 0, blinders.data(), &p);
+  int rc = capgpu_plonk_prove_ex(pk.handle(), a.wires, a.pub_inputs, pk.num_inputs(),
+                                 ext_msg ? ext_msg->data() : nullptr, ext_msg ? ext_msg->size() : 0, blinders.data(),
+                                 a.input_form, &p);
   if (rc != CAPGPU_OK) return detail::map_error(rc, what);
   return p;
 }

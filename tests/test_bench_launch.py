@@ -1,0 +1,58 @@
+"""bench.py must never measure one GPU and report N (round-3 VERDICT "silent N = 1"): `--gpus N` without a launcher
+starts the N ranks itself - or refuses when the GPUs are not there - and the JSON line says what the library bound
+(`devices_bound`, `rccl_world`)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--steps", "1", "--warmup", "1", "--batch", "8", "--log-n", "10", "--no-extras", "--no-cpu-baseline",
+         "--no-reference-schedule", "--no-mixed"]
+
+
+def run_bench(extra, env_extra=None, timeout=900):
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + extra, env=env, capture_output=True,
+                          text=True, timeout=timeout, cwd=ROOT)
+
+
+def test_more_gpus_than_visible_is_refused_not_downsized():
+    """(CPU runner: no GPU at all; on the GPU box: one GPU, two asked for)"""
+    r = run_bench(["--gpus", "2"] + SMALL)
+    assert r.returncode == 3, (r.returncode, r.stderr[-400:])
+    assert "refusing" in r.stderr and r.stdout.strip() == ""
+
+
+@pytest.mark.gpu
+def test_gpus_2_without_a_launcher_runs_two_ranks():
+    """fresh subprocess, no WORLD_SIZE: bench.py spawns torch.distributed.run itself before touching the GPU; on this
+    one-GPU box the two ranks share device 0 (CAPGPU_ALLOW_DUPLICATE_DEVICES=1, gloo) - what matters is that the line
+    says n_gpus 2 and names what was bound"""
+    r = run_bench(["--gpus", "2", "--msm-log-n", "14"] + SMALL, {"CAPGPU_ALLOW_DUPLICATE_DEVICES": "1"})
+    assert r.returncode == 0, r.stderr[-1500:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["devices_bound"] == [0, 0] and out["devices_shared_by_ranks"] is True
+    assert out["rccl_world"] == 0                      # gloo run: the library has no communicator, and says so
+    assert out["value"] > 0 and out["scaling"] == "weak"
+    assert out["msm"][-1]["identity_check"] is True and "x2" in out["msm"][-1]["sharding"]
+
+
+@pytest.mark.gpu
+def test_single_process_model_reports_its_devices():
+    r = run_bench(["--single-process", "--devices", "0,0", "--msm-log-n", "15"] + SMALL,
+                  {"CAPGPU_ALLOW_DUPLICATE_DEVICES": "1", "CAPGPU_SHARD_MIN_POINTS": "4096"})
+    assert r.returncode == 0, r.stderr[-1500:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert out["n_gpus"] == 2 and out["devices_bound"] == [0, 0] and out["peer_access"] == [[2, 2], [2, 2]]
+    assert out["every_device_made_the_same_proofs"] is True
+    m = out["msm"][0]
+    assert m["shards"] == 2 and m["identity_check"] is True
+    assert m["bytes_between_devices_per_call"] == {"scalars": 0, "partials": 96}

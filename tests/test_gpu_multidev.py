@@ -373,3 +373,149 @@ def test_two_contexts_under_concurrent_mixed_load(cg2, tau):
     cg.plonk_free_key(pkh)
     cg.srs_free(h)
     cg.srs_free(hs)
+
+
+def test_scalars_resident_with_their_point_ranges(cg2, tau):
+    """"GPU g holds its bases resident and receives the matching scalar slice".  capgpu_msm_g1_dev on a sharded
+    SRS scatters the caller's scalars over the devices on every call; a scalar set (capgpu_msm_scalars_upload /
+    _scatter_dev) places them once, and capgpu_msm_g1_resident then moves nothing but the 96-byte partials - asserted on
+    the library's own byte counters."""
+    cg = cg2
+    n = 20011
+    h = cg.srs_generate_affine_seq(A_SEQ, B_SEQ, n)
+    assert cg.srs_shards(h) == 2
+    scs = np.stack([bu.random_canonical_scalars(70 + i, n) for i in range(3)])
+
+    def expect(s, lo=0):
+        s0, s1 = bu.weighted_scalar_sums(s, lo)
+        return bn.g1_mul(bn.G1_GEN, (A_SEQ * s0 + B_SEQ * s1) % bn.R)
+
+    def aff(j):
+        return cr.affine_to_ints(cr.g1_to_affine(j))
+
+    cg.set_device(0)
+    d = cg.DevBuf.from_numpy(scs)
+    # the fallback form: every call scatters the slice of the other context again
+    s0 = cg.msm_shard_stats()
+    cg.msm_g1_dev(h, d, n, count=3)
+    s1 = cg.msm_shard_stats()
+    cg.msm_g1_dev(h, d, n, count=3)
+    s2 = cg.msm_shard_stats()
+    per_call = s1["scalar_bytes"] - s0["scalar_bytes"]
+    assert per_call == 3 * 32 * (n // 2) and s2["scalar_bytes"] - s1["scalar_bytes"] == per_call
+    # resident: scattered once ...
+    hs = cg.msm_scalars_scatter_dev(h, d, n, count=3)
+    s3 = cg.msm_shard_stats()
+    assert s3["scalar_bytes"] - s2["scalar_bytes"] == per_call
+    # ... and not again, call after call
+    for _ in range(2):
+        out = cg.msm_g1_resident(h, hs, count=3).to_numpy().reshape(3, 12)
+        assert [aff(o) for o in out] == [expect(scs[i]) for i in range(3)]
+    s4 = cg.msm_shard_stats()
+    assert s4["scalar_bytes"] == s3["scalar_bytes"], "resident scalar slices were copied again"
+    assert s4["partial_bytes"] - s3["partial_bytes"] == 2 * 3 * 96          # one partial per MSM from the other context
+    assert s4["sharded_calls"] - s3["sharded_calls"] == 2
+    # from host memory, a sub-range across the cut, Montgomery form
+    sub = scs[1, 4000:17000]
+    hu = cg.msm_scalars_upload(h, cr.vec_to_mont(1, sub).reshape(-1, 4), offset=4000)
+    assert aff(cg.msm_g1_resident(h, hu, montgomery=True).to_numpy()) == expect(sub, 4000)
+    # the same API on an unsharded SRS: one slice on the caller's context
+    os.environ["CAPGPU_SHARD_MIN_POINTS"] = str(1 << 20)
+    h1 = cg.srs_generate(tau, 3000)
+    os.environ["CAPGPU_SHARD_MIN_POINTS"] = "4096"
+    f = bu.random_canonical_scalars(77, 3000)
+    h1s = cg.msm_scalars_upload(h1, f)
+    ftau = bn.from_mont(cr.poly_eval_fr(cr.vec_to_mont(1, f), bn.to_mont(tau, bn.R)), bn.R)
+    assert aff(cg.msm_g1_resident(h1, h1s).to_numpy()) == bn.g1_mul(bn.G1_GEN, ftau)
+    # a set belongs to its SRS; a freed set is gone
+    with pytest.raises(cg.CapGpuError) as e:
+        cg.msm_g1_resident(h1, hs, count=3)
+    assert e.value.code == -1
+    for x in (hs, hu, h1s):
+        cg.msm_scalars_free(x)
+    with pytest.raises(cg.CapGpuError) as e:
+        cg.msm_g1_resident(h, hs, count=3)
+    assert e.value.code == -4
+    d.free()
+    cg.set_device(-1)
+    cg.srs_free(h)
+    cg.srs_free(h1)
+
+
+def test_peer_info_and_callers_hip_device(cg2):
+    """capgpu_init settles the memory path of every bound device pair (here: one device bound twice = 2); and a call that
+    the library places on a context must leave the CALLER's HIP current device alone (an integration next to torch)."""
+    import ctypes
+    cg = cg2
+    assert cg.device_peer_info(0, 1) == 2 and cg.device_peer_info(0, 0) == 2
+    with pytest.raises(cg.CapGpuError):
+        cg.device_peer_info(0, 2)
+    hip = ctypes.CDLL("libamdhip64.so")
+    dev = ctypes.c_int(-1)
+    assert hip.hipGetDevice(ctypes.byref(dev)) == 0
+    before = dev.value
+    x = cr.random_field(6, 1, 1 << 10, True)
+    cg.set_device(-1)
+    cg.ntt_fr(x, 10, False, True)                                   # unbound host-buffer call: dealt to a context
+    assert hip.hipGetDevice(ctypes.byref(dev)) == 0 and dev.value == before
+
+
+@pytest.fixture()
+def cg_replicas(cg):
+    """device 0 bound twice with CAPGPU_FORCE_REPLICATE=1: the second context COPIES the SRS and key tables instead of
+    sharing them, so that clone_srs_to_current / clone_key_to_current - and proofs made from the copies - run on the one
+    GPU of a test box"""
+    cg.shutdown()
+    env = {"CAPGPU_ALLOW_DUPLICATE_DEVICES": "1", "CAPGPU_FORCE_REPLICATE": "1", "CAPGPU_CONTEXTS_PER_DEVICE": "1"}
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
+    try:
+        cg.init(devices=[0, 0])
+        yield cg
+    finally:
+        cg.shutdown()
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        cg.init(0)
+
+
+def test_replicated_tables_give_the_same_results(cg_replicas, tau):
+    cg = cg_replicas
+    sc = bu.synthetic_circuit(10, 4, seed=33)
+    cg.set_device(0)
+    h = cg.srs_generate(tau, sc.n + 3)
+    pkh, vk = cg.plonk_preprocess(h, sc.n, 4, sc.selectors_mont(), sc.sigma_mont())
+    ws, ps, bls = _witnesses(sc, 5, 90)
+    want = [bytes(p) for p in cg.plonk_prove_batch(pkh, ws, ps, bls, b"r", 5)]
+    k = cr.random_field(12, 1, sc.n, False)
+    want_msm = cr.g1_to_affine(cg.msm_g1(h, k))
+    r0 = cg.msm_shard_stats()["replications"]
+    out = {}
+
+    def other():
+        try:
+            cg.set_device(1)
+            out["proofs"] = [bytes(p) for p in cg.plonk_prove_batch(pkh, ws, ps, bls, b"r", 5)]
+            out["msm"] = cr.g1_to_affine(cg.msm_g1(h, k))
+            out["srs"] = cg.srs_download(h, 0, 64)
+            out["key"] = cg.plonk_key_serialize(pkh, cg.g2_generator(), cg.g2_mul(cg.g2_generator(), tau))
+        except Exception as ex:                                      # noqa: BLE001
+            out["error"] = ex
+
+    t = threading.Thread(target=other)
+    t.start()
+    t.join()
+    assert "error" not in out, out.get("error")
+    assert cg.msm_shard_stats()["replications"] - r0 == 2           # the SRS tables and the key, once each
+    assert out["proofs"] == want and np.array_equal(out["msm"], want_msm)
+    assert np.array_equal(out["srs"], cg.srs_download(h, 0, 64))
+    assert out["key"] == cg.plonk_key_serialize(pkh, cg.g2_generator(), cg.g2_mul(cg.g2_generator(), tau))
+    # the replica stays valid for later calls and is released with the handle
+    cg.set_device(-1)
+    assert [bytes(p) for p in cg.plonk_prove_batch(pkh, np.concatenate([ws] * 4), np.concatenate([ps] * 4),
+                                                   np.concatenate([bls] * 4), b"r", 20)] == want * 4
+    cg.plonk_free_key(pkh)
+    cg.srs_free(h)
