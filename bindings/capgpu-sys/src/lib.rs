@@ -137,6 +137,7 @@ extern "C" {
                               ext_msg: *const u8, ext_msg_len: usize, blinders: *const u64,
                               proof_out: *mut capgpu_proof) -> c_int;
     pub fn capgpu_plonk_set_coalescing(window_us: u32, max_batch: u32) -> c_int;
+    pub fn capgpu_plonk_graph_stats(segments_captured_out: *mut u64, segments_replayed_out: *mut u64) -> c_int;
     pub fn capgpu_plonk_coalescing_stats(batches_out: *mut u64, proofs_out: *mut u64) -> c_int;
     pub fn capgpu_plonk_prove_batch(pk_handle: u64, count: c_int, wires: *const u64, pub_inputs: *const u64,
                                     num_inputs: usize, ext_msg: *const u8, ext_msg_len: usize, blinders: *const u64,

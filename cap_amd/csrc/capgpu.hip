@@ -100,6 +100,10 @@ int take_launch_error() {
 int scratch_reserve(Scratch& s, size_t bytes) {
   if (bytes <= s.cap) return CAPGPU_OK;
   Context& c = ctx();
+  if (c.capturing) {  // (the capture is abandoned and the work enqueued directly: plonk.hip, GraphRun)
+    set_error("capgpu: scratch growth during stream capture");
+    return CAPGPU_ERR_HIP;
+  }
   if (s.p) {
     CAP_HIP(hipStreamSynchronize(c.stream));
     CAP_HIP(hipFree(s.p));
@@ -808,6 +812,7 @@ void capgpu_shutdown(void) {
         s->cap = 0;
       }
       c.pool.reset();
+      c.prove_graphs.reset();
       if (c.own_stream) hipStreamDestroy(c.own_stream);
       if (c.copy_stream) hipStreamDestroy(c.copy_stream);
       c.own_stream = c.stream = c.copy_stream = nullptr;

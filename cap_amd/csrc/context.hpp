@@ -65,6 +65,7 @@ struct SrsRecord {
 };
 
 struct ProvingKey;  // plonk.hip
+struct ProveGraphCache;  // plonk.hip: instantiated hipGraphs of small-batch prover schedules
 
 // Scalars of MSMs on a (possibly sharded) SRS, resident where their points are ("GPU g holds its bases
 // resident and receives the matching scalar slice"): `count` arrays over logical points [offset, offset + n), cut by the
@@ -99,6 +100,8 @@ struct Context {
   std::map<uint64_t, std::shared_ptr<SrsEntry>> srs;  // logical handle -> the table resident HERE (full or shard)
   std::map<uint64_t, std::shared_ptr<ProvingKey>> keys;
   Scratch ntt_scratch, msm_ws, stage_a, stage_b, prove_ws, gather;
+  std::shared_ptr<ProveGraphCache> prove_graphs;  // created on first use; dropped before the stream at shutdown
+  bool capturing = false;  // a stream capture is open on `stream`: scratch buffers must not grow (scratch_reserve refuses)
   std::unique_ptr<HostPool> pool;  // created on first use
   Profiler prof;
   LaunchError lerr;

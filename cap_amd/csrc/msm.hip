@@ -1182,6 +1182,83 @@ __global__ __launch_bounds__(256) void msm_reduce_bits_final(const g1_xyzz* __re
   }
 }
 
+// ---- K6 for small batches, second form: the bucket index as a 2-D grid -------------------------------------------------
+// sum_j (j + 1) B_j with j = hi * 2^lo_bits + lo:
+//     = 2^lo_bits * sum_hi hi * R_hi  +  sum_lo (lo + 1) * C_lo,      R_hi = sum_lo B[hi][lo],  C_lo = sum_hi B[hi][lo].
+// The bit-plane form above adds every bucket into (c - 1) / 2 plane sums on average - 13 x 2048 additions for 4096
+// buckets, through trees in which half of a wave's lanes idle at every level - and finishes with c - 1 dependent doublings.
+// Here every bucket enters TWO sums (its row and its column: 2 x 4096 additions, 8 of them serial per lane, then a
+// 3-level tree over 8 lanes), and the two weighted sums of 64 terms that remain take no doublings at all: with the terms
+// in the lanes of a wave, sum_k k X_k = sum_{l >= 1} suffix_l - a suffix scan across the lanes and one wave sum; only
+// the factor 2^lo_bits costs lo_bits = 6 doublings.  A single proof's four MSM launches (1, 2 and 5 MSMs of 4096 buckets):
+// see DESIGN.md round-4 log for the measured times.
+// grid: (ceil(sb * 2 * (R_hi + R_lo)... one thread per (entry, sum, slice)
+constexpr uint32_t kGridSlices = 8;  // lanes per row / column sum (each adds dim / 8 buckets serially, then a 3-level tree)
+__global__ __launch_bounds__(kThreads) void msm_reduce_grid(const g1_xyzz* __restrict__ buckets, uint32_t half,
+                                                            uint32_t lo_bits, uint32_t sb,
+                                                            g1_xyzz* __restrict__ sums /* [sb][rows + cols] */) {
+  const uint32_t cols = 1u << lo_bits, rows = half >> lo_bits, nsum = rows + cols;
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t g = t / kGridSlices, q = t % kGridSlices;  // g: (entry, sum); whole groups leave together
+  if (g >= sb * nsum) return;
+  const uint32_t b = g / nsum, sidx = g - b * nsum;
+  const g1_xyzz* bk = buckets + (size_t)b * half;
+  g1x acc = G1L::inf();
+  if (sidx < rows) {  // row sum R_hi: buckets hi * cols + lo, lo in this lane's slice (consecutive 128-byte entries)
+    const uint32_t per = (cols + kGridSlices - 1) / kGridSlices, l0 = q * per;
+    for (uint32_t l = l0; l < l0 + per && l < cols; l++) add_tree<G1L>(acc, G1L::load(bk[(size_t)sidx * cols + l]));
+  } else {  // column sum C_lo: buckets hi * cols + lo, hi in this lane's slice
+    const uint32_t lo = sidx - rows;
+    const uint32_t per = (rows + kGridSlices - 1) / kGridSlices, h0 = q * per;
+    for (uint32_t h = h0; h < h0 + per && h < rows; h++) add_tree<G1L>(acc, G1L::load(bk[(size_t)h * cols + lo]));
+  }
+  for (int d = kGridSlices / 2; d >= 1; d >>= 1) {
+    g1x o = shfl_down_pt(acc, d);
+    if (q < (uint32_t)d) add_tree<G1L>(acc, o);
+  }
+  if (q == 0) sums[g] = G1L::store(acc);
+}
+
+// One workgroup of two waves per entry: wave 0 takes the row sums (weights hi = 0 .. rows - 1), wave 1 the column sums
+// (weights lo + 1 = 1 .. cols); rows, cols <= 64.  Inclusive suffix scan over the lanes, then the wave sum of the
+// suffixes - from lane 1 on for the rows, from lane 0 on for the columns.  A chain of 6 + 6 additions, lo_bits doublings
+// and one addition; G1S: the row-wise multiplication schedule of the one-wave finishing kernels.
+__global__ __launch_bounds__(128) void msm_reduce_grid_final(const g1_xyzz* __restrict__ sums, uint32_t half,
+                                                             uint32_t lo_bits, g1_jac* __restrict__ out,
+                                                             g1_xyzz* __restrict__ out_part) {
+  __shared__ g1_xyzz row_part;
+  const uint32_t cols = 1u << lo_bits, rows = half >> lo_bits;
+  const uint32_t b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const g1_xyzz* sp = sums + (size_t)b * (rows + cols) + (wave ? rows : 0);
+  const uint32_t cnt = wave ? cols : rows;
+  g1x suf = lane < cnt ? G1S::load(sp[lane]) : G1S::inf();
+  for (int d = 1; d < 64; d <<= 1) {  // suf_l = X_l + X_{l+1} + ... (lanes beyond cnt hold infinity)
+    g1x o = shfl_down_pt(suf, d);
+    if (lane + d < 64) add_tree<G1S>(suf, o);
+  }
+  if (wave == 0 && lane == 0) suf = G1S::inf();  // rows: weight hi starts at 0, so the full sum (lane 0) is left out
+  g1x r = wave_sum<G1S>(suf);
+  if (wave == 0) {
+    for (uint32_t k = 0; k < lo_bits; k++)
+      if (!G1S::is_inf(r)) r = G1S::dbl(r);
+    if (lane == 0) row_part = G1S::store(r);
+  }
+  __syncthreads();
+  if (wave == 1 && lane == 0) {
+    add_tree<G1S>(r, G1S::load(row_part));
+    if (out_part) out_part[b] = G1S::store(r);
+    else out[b] = G1S::to_jac_ext(r);
+  }
+}
+// bucket sets the grid form takes: 2^k buckets, 2 <= k <= 12, both grid dimensions <= 64 (CAPGPU_MSM_GRID_REDUCE=0: off)
+bool use_grid_reduce(uint32_t half) {
+  static const bool on = [] {
+    const char* e = getenv("CAPGPU_MSM_GRID_REDUCE");
+    return !e || atoi(e) != 0;
+  }();
+  return on && half >= 4 && half <= 4096 && (half & (half - 1)) == 0;
+}
+
 // out[b] = sum of the `parts` sub-MSM results of MSM b (one wavefront per MSM)
 __global__ __launch_bounds__(64) void msm_sum_parts(const g1_xyzz* __restrict__ part_pts, uint32_t parts,
                                                     g1_jac* __restrict__ out) {
@@ -1649,6 +1726,17 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
     launch("msm_combine", kern, dim3((unsigned)(((size_t)total_buckets * G + kThreads - 1) / kThreads)), dim3(kThreads),
            0, stream, (const g1_xyzz*)t.item_pts, (const uint32_t*)t.counts, (const uint32_t*)t.item_off,
            (const uint32_t*)t.item_base, half, total_buckets, item_len, t.buckets);
+    if (!out_pair && use_grid_reduce(half)) {
+      uint32_t k = 0;
+      while ((1u << k) < half) k++;
+      const uint32_t lo_bits = k / 2, nsum = (half >> lo_bits) + (1u << lo_bits);
+      launch("msm_reduce_grid", msm_reduce_grid,
+             dim3((unsigned)(((size_t)sb * nsum * kGridSlices + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
+             (const g1_xyzz*)t.buckets, half, lo_bits, sb, t.partial);
+      launch("msm_reduce_grid_final", msm_reduce_grid_final, dim3(sb), dim3(128), 0, stream, (const g1_xyzz*)t.partial,
+             half, lo_bits, out, out_part);
+      return;
+    }
     const uint32_t nplanes = t.planes + (out_pair ? 1u : 0u);
     const uint32_t chunks = reduce_chunks(half, nplanes, sb);
     launch("msm_reduce_bits", msm_reduce_bits, dim3(chunks, nplanes, sb), dim3(kReduceThreads), 0, stream,

@@ -56,6 +56,11 @@ struct ProvingKey {
   std::vector<uint8_t> vk_bytes;
   bool recompute = false;
   int device = 0;  // HIP device the tables live on
+  uint64_t uid = next_uid();  // never reused: identifies the key's tables in the signature of a captured graph
+  static uint64_t next_uid() {
+    static std::atomic<uint64_t> n{1};
+    return n.fetch_add(1);
+  }
   // Immutable once published: contexts on the same device share the object, other devices get a peer copy
   // (clone_key_to_current).  The batch workspace lives in the context (Context::prove_ws).
   ProvingKey() = default;
@@ -67,7 +72,136 @@ struct ProvingKey {
   }
 };
 
+// ---- hipGraph replay of the small-batch schedule -------------------------------------------------------------------
+// One proof is ~100 kernel launches in five Fiat-Shamir rounds, most of them a few microseconds long: at batch 1 .. 16 the
+// gaps between dependent launches and the host's launch calls are a visible part of the proof's latency (the reference's
+// criterion bench times ONE note per iteration, benches/transfer.rs:103-105; rayon callers arrive one note at a time).
+// The kernels between two host synchronisations (the transcript needs the commitments of a round before it can hand out
+// the next challenge) form a SEGMENT whose launches depend on nothing but the call's signature - key, batch size, buffers:
+// every per-call value (challenges, descriptors, blinders) travels through device memory written by copies that stay
+// outside the segments.  The first call of a signature runs directly (it sizes the scratch buffers), the second is
+// captured segment by segment (hipStreamBeginCapture ... hipGraphInstantiate), later ones replay seven hipGraphLaunch
+// calls.  CAPGPU_GRAPH_MAX_BATCH (default 16; 0 = off) bounds the batch sizes that take this path.
+constexpr int kGraphSegs = 8;
+struct ProveGraphSig {
+  uint64_t key_uid = 0, srs = 0;
+  uint32_t P = 0;
+  size_t num_inputs = 0;
+  int form = 0;
+  bool multi = false;
+  const void *d_wires = nullptr, *ws = nullptr, *msm_ws = nullptr, *ntt_scratch = nullptr, *bases = nullptr;
+  hipStream_t stream = nullptr;
+  bool operator==(const ProveGraphSig& o) const {
+    return key_uid == o.key_uid && srs == o.srs && P == o.P && num_inputs == o.num_inputs && form == o.form &&
+           multi == o.multi && d_wires == o.d_wires && ws == o.ws && msm_ws == o.msm_ws && ntt_scratch == o.ntt_scratch &&
+           bases == o.bases && stream == o.stream;
+  }
+};
+struct ProveGraphSet {
+  ProveGraphSig sig;
+  hipGraphExec_t exec[kGraphSegs] = {};
+  uint32_t seen = 0;    // calls with this signature so far
+  bool broken = false;  // a capture failed: this signature stays on direct launches
+  uint64_t stamp = 0;
+  ProveGraphSet() = default;
+  ProveGraphSet(const ProveGraphSet&) = delete;
+  ProveGraphSet& operator=(const ProveGraphSet&) = delete;
+  ~ProveGraphSet() { drop(); }
+  void drop() {
+    for (auto& e : exec)
+      if (e) {
+        (void)hipGraphExecDestroy(e);
+        e = nullptr;
+      }
+  }
+};
+struct ProveGraphCache {
+  std::vector<std::unique_ptr<ProveGraphSet>> sets;
+  uint64_t clock = 0;
+};
+static std::atomic<uint64_t> g_graph_captured{0}, g_graph_replayed{0};
+
 namespace {
+
+uint32_t graph_max_batch() {
+  const char* e = getenv("CAPGPU_GRAPH_MAX_BATCH");
+  const int x = e ? atoi(e) : 16;
+  return (uint32_t)(x < 0 ? 0 : (x > 64 ? 64 : x));
+}
+// the graph set of this call's signature, or nullptr when the call launches directly (first sighting, failed capture)
+ProveGraphSet* graph_set_for(Context& c, const ProveGraphSig& sig) {
+  if (!c.prove_graphs) c.prove_graphs = std::make_shared<ProveGraphCache>();
+  ProveGraphCache& gc = *c.prove_graphs;
+  gc.clock++;
+  for (auto& sp : gc.sets)
+    if (sp->sig == sig) {
+      sp->stamp = gc.clock;
+      sp->seen++;
+      return sp->broken ? nullptr : sp.get();
+    }
+  // a new signature: it replaces a stale one of the same (key, batch, form) - a scratch buffer moved - or the least
+  // recently used of 8
+  ProveGraphSet* slot = nullptr;
+  for (auto& sp : gc.sets)
+    if (sp->sig.key_uid == sig.key_uid && sp->sig.P == sig.P && sp->sig.form == sig.form && sp->sig.multi == sig.multi &&
+        sp->sig.d_wires == sig.d_wires)
+      slot = sp.get();
+  if (!slot && gc.sets.size() >= 8) {
+    slot = gc.sets[0].get();
+    for (auto& sp : gc.sets)
+      if (sp->stamp < slot->stamp) slot = sp.get();
+  }
+  if (!slot) {
+    gc.sets.emplace_back(new ProveGraphSet);
+    slot = gc.sets.back().get();
+  }
+  if (slot->exec[0] || slot->seen) (void)hipStreamSynchronize(c.stream);  // an instantiated graph may still be running
+  slot->drop();
+  slot->sig = sig;
+  slot->seen = 1;
+  slot->broken = false;
+  slot->stamp = gc.clock;
+  return nullptr;  // first call with this signature: direct launches (they size every scratch buffer)
+}
+// runs one segment: replay, or capture + instantiate + launch, or - without a graph set - the launches themselves
+template <class F>
+int run_segment(Context& c, ProveGraphSet* g, int id, F&& enqueue) {
+  if (!g || g->broken) return enqueue();
+  hipStream_t s = c.stream;
+  if (g->exec[id]) {
+    CAP_HIP(hipGraphLaunch(g->exec[id], s));
+    g_graph_replayed++;
+    return CAPGPU_OK;
+  }
+  if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+    (void)hipGetLastError();
+    g->broken = true;
+    return enqueue();
+  }
+  c.capturing = true;
+  int rc = enqueue();
+  c.capturing = false;
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(s, &graph);
+  if (rc == CAPGPU_OK && e == hipSuccess && graph && launch_error().code == hipSuccess) {
+    hipGraphExec_t ex = nullptr;
+    e = hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e == hipSuccess && ex) {
+      g->exec[id] = ex;
+      g_graph_captured++;
+      CAP_HIP(hipGraphLaunch(ex, s));
+      return CAPGPU_OK;
+    }
+  } else if (graph) {
+    (void)hipGraphDestroy(graph);
+  }
+  // nothing of the captured attempt has run: abandon graphs for this signature and enqueue the segment directly
+  (void)hipGetLastError();
+  launch_error() = LaunchError{};
+  g->broken = true;
+  return enqueue();
+}
 
 // The per-proof host work between rounds runs on the context's own pool (host_pool.hpp).
 HostPool& host_pool() {
@@ -360,6 +494,30 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   const Ntt3Domain* dom_q = nullptr;
   if ((rc = get_domain(K.log_n, &dom_n))) return rc;
   if ((rc = get_domain3(K.log_m, &dom_q))) return rc;
+  // small batches replay their kernel segments as hipGraphs (see ProveGraphSet)
+  const uint32_t chunks = h_wires ? h2d_chunks(P) : 1;
+  ProveGraphSet* gs = nullptr;
+  if (P <= graph_max_batch() && chunks == 1 && !c.prof.on && comm_shard_slot() < 0) {
+    ProveGraphSig sig;
+    sig.key_uid = K.uid;
+    sig.srs = K.srs_handle;
+    sig.P = P;
+    sig.num_inputs = num_inputs;
+    sig.form = form;
+    sig.multi = keys != nullptr;
+    sig.d_wires = d_wires;
+    sig.ws = c.prove_ws.p;
+    sig.msm_ws = c.msm_ws.p;
+    sig.ntt_scratch = c.ntt_scratch.p;
+    sig.bases = B->ext;
+    sig.stream = s;
+    gs = graph_set_for(c, sig);
+  }
+  auto seg = [&](int id, const std::function<int()>& enqueue) -> int { return run_segment(c, gs, id, enqueue); };
+  static const bool inv_on_device = [] {  // the round-2 inversion as a device kernel (the pre-round-4 schedule)
+    const char* e = getenv("CAPGPU_PERM_INV_ON_DEVICE");
+    return e && atoi(e) != 0;
+  }();
 
   // ---- transcripts (host) --------------------------------------------------------------------------------
   std::vector<SolidityTranscript> tr(P);
@@ -428,11 +586,35 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   // ---- round 1: wire polynomials, public-input polynomial, 5 commitments ------------------------------
   // the interpolations read the witness columns / public inputs where they are and write the coefficient arrays (no
   // padded copies); k_blind sets the 8-element tail of every wire polynomial (two blinders, six zeros)
-  const uint32_t chunks = h_wires ? h2d_chunks(P) : 1;
+  // kernels of one chunk of proofs [p0, p0 + cnt): interpolation (or, from coefficient-form input, the copy into place
+  // and the forward transform round 2 reads), blinding, and - when the batch is chunked - the chunk's commitments
+  auto r1_chunk_kernels = [&](uint32_t p0, uint32_t cnt, bool commit) -> int {
+    const size_t wo = (size_t)p0 * NW * n;
+    fe* wp = w.wpoly + (size_t)p0 * NW * ps;
+    int r;
+    if (coeffs) {
+      pad_copy(s, wp, ps, 0, d_wires + wo, n, 0, 1, cnt * NW, n, n);
+      if ((r = run_ntt_from(s, K.log_n, d_wires + wo, n, n, w.wev + wo, n, cnt * NW, 0, 0))) return r;
+    } else if ((r = run_ntt_from(s, K.log_n, d_wires + wo, n, n, wp, ps, cnt * NW, 1, 0))) {
+      return r;
+    }
+    launch("k_blind", k_blind<1>, dim3(cnt * NW), dim3(64), 0, s, wp, ps, n, (const fe*)(w.d_blind + (size_t)p0 * 13),
+           (uint32_t)NW, 0u, 2u, cnt * NW);
+    if (commit && (r = run_msm(s, *B, wp, ps, 1, 0, n + 2, cnt * NW, w.comms + (size_t)p0 * NW))) return r;
+    return CAPGPU_OK;
+  };
+  auto r1_tail_kernels = [&]() -> int {
+    int r;
+    if (num_inputs) {
+      if ((r = run_ntt_from(s, K.log_n, w.d_pub, num_inputs, num_inputs, w.pi, n, P, 1, 0))) return r;
+    } else {
+      CAP_HIP(hipMemsetAsync(w.pi, 0, sizeof(fe) * (size_t)P * n, s));
+    }
+    if (chunks == 1 && (r = run_msm(s, *B, w.wpoly, ps, 1, 0, n + 2, P * NW, w.comms))) return r;
+    return CAPGPU_OK;
+  };
   for (uint32_t ck = 0; ck < chunks; ck++) {
     const uint32_t p0 = (uint32_t)((uint64_t)P * ck / chunks), p1 = (uint32_t)((uint64_t)P * (ck + 1) / chunks);
-    const uint32_t cnt = p1 - p0;
-    const size_t wo = (size_t)p0 * NW * n;
     if (h_wires) {
       hipStream_t cs = chunks > 1 ? h2d_stream() : nullptr;
       if (!cs) cs = s;
@@ -459,29 +641,21 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
         CAP_HIP(e2);
       }
     }
-    fe* wp = w.wpoly + (size_t)p0 * NW * ps;
-    if (coeffs) {
-      pad_copy(s, wp, ps, 0, d_wires + wo, n, 0, 1, cnt * NW, n, n);
-      if ((rc = run_ntt_from(s, K.log_n, d_wires + wo, n, n, w.wev + wo, n, cnt * NW, 0, 0))) return rc;
-    } else if ((rc = run_ntt_from(s, K.log_n, d_wires + wo, n, n, wp, ps, cnt * NW, 1, 0))) {
-      return rc;
-    }
-    launch("k_blind", k_blind<1>, dim3(cnt * NW), dim3(64), 0, s, wp, ps, n, (const fe*)(w.d_blind + (size_t)p0 * 13),
-           (uint32_t)NW, 0u, 2u, cnt * NW);
-    if (chunks > 1 && (rc = run_msm(s, *B, wp, ps, 1, 0, n + 2, cnt * NW, w.comms + (size_t)p0 * NW))) return rc;
+    if (chunks > 1 && (rc = r1_chunk_kernels(p0, p1 - p0, true))) return rc;
   }
-  if (num_inputs) {
-    if ((rc = run_ntt_from(s, K.log_n, w.d_pub, num_inputs, num_inputs, w.pi, n, P, 1, 0))) return rc;
-  } else {
-    CAP_HIP(hipMemsetAsync(w.pi, 0, sizeof(fe) * (size_t)P * n, s));
-  }
-  if (chunks == 1 && (rc = run_msm(s, *B, w.wpoly, ps, 1, 0, n + 2, P * NW, w.comms))) return rc;
+  if ((rc = seg(0, [&]() -> int {
+         int r = chunks == 1 ? r1_chunk_kernels(0, P, false) : CAPGPU_OK;
+         return r ? r : r1_tail_kernels();
+       })))
+    return rc;
   // round 3's coset evaluations of the wire and public-input polynomials (on the 6n quotient domain, straight from
   // their coefficient arrays: the transform zero-extends them) depend on nothing the transcript still has to produce
   if ((rc = fetch_comms(P * NW, [&]() -> int {
-         int r = run_ntt3_fwd(s, K.log_m, w.coset, P * NW, NttIo{w.wpoly, NW * ps, ps, n + 2, NW, 7 * m, m, NW});
-         if (r) return r;
-         return run_ntt3_fwd(s, K.log_m, w.coset + 6 * m, P, NttIo{w.pi, n, 0, n, 1, 7 * m, 0, 1});
+         return seg(1, [&]() -> int {
+           int r = run_ntt3_fwd(s, K.log_m, w.coset, P * NW, NttIo{w.wpoly, NW * ps, ps, n + 2, NW, 7 * m, m, NW});
+           if (r) return r;
+           return run_ntt3_fwd(s, K.log_m, w.coset + 6 * m, P, NttIo{w.pi, n, 0, n, 1, 7 * m, 0, 1});
+         });
        })))
     return rc;
   std::vector<Chal> chal(P);
@@ -499,23 +673,66 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   CAP_HIP(hipMemcpyAsync(w.chal, chal.data(), sizeof(Chal) * P, hipMemcpyHostToDevice, s));
 
   // ---- round 2: permutation grand product --------------------------------------------------------------
-  launch("k_perm_numden", k_perm_numden, dim3(cdiv(n, kThreads), P), dim3(kThreads), 0, s,
-         coeffs ? (const fe*)w.wev : d_wires,
-         (const fe*)K.sig_eval, sig_of, (const fe*)dom_n->tw_fwd, (const Chal*)w.chal, K.qc29, n, w.num, w.den);
-  {
-    uint32_t nb = cdiv(n, kScanBlock);
-    scan_exclusive<0, 0>(s, w.num, w.pre, n, n, P, w.scan_tot);
-    scan_exclusive<0, 1>(s, w.den, w.sfx, n, n, P, w.scan_tot + (size_t)P * nb);
+  if ((rc = seg(2, [&]() -> int {
+         int r;
+         launch("k_perm_numden", k_perm_numden, dim3(cdiv(n, kThreads), P), dim3(kThreads), 0, s,
+                coeffs ? (const fe*)w.wev : d_wires, (const fe*)K.sig_eval, sig_of, (const fe*)dom_n->tw_fwd,
+                (const Chal*)w.chal, K.qc29, n, w.num, w.den);
+         {
+           uint32_t nb = cdiv(n, kScanBlock);
+           scan_exclusive<0, 0>(s, w.num, w.pre, n, n, P, w.scan_tot);
+           scan_exclusive<0, 1>(s, w.den, w.sfx, n, n, P, w.scan_tot + (size_t)P * nb);
+         }
+         if (inv_on_device) {
+           launch("k_perm_inv_total", k_perm_inv_total, dim3(cdiv(P, 64)), dim3(64), 0, s, (const fe*)w.sfx,
+                  (const fe*)w.den, n, w.inv_total, P);
+         } else {
+           launch("k_perm_total", k_perm_total, dim3(cdiv(P, 64)), dim3(64), 0, s, (const fe*)w.sfx, (const fe*)w.den, n,
+                  w.inv_total, P);
+           return CAPGPU_OK;  // the segment ends here: the host inverts the totals (below)
+         }
+         launch("k_perm_finish", k_perm_finish, dim3(cdiv(ps, kThreads), P), dim3(kThreads), 0, s, (const fe*)w.pre,
+                (const fe*)w.sfx, (const fe*)w.den, (const fe*)w.inv_total, n, w.zpoly, ps);
+         if ((r = run_ntt(s, K.log_n, w.zpoly, ps, P, 1, 0))) return r;
+         launch("k_blind", k_blind<0>, dim3(P), dim3(64), 0, s, w.zpoly, ps, n, (const fe*)w.d_blind, 1u, 10u, 3u, P);
+         return run_msm(s, *B, w.zpoly, ps, 1, 0, n + 3, P, w.comms);
+       })))
+    return rc;
+  if (!inv_on_device) {
+    // 1 / prod(den) per proof on the host: P products come back (32 B each), one shared inversion (Montgomery's trick),
+    // P inverses go out - a round trip of tens of microseconds against 0.17 ms of a single device thread
+    std::vector<fe> tot(P), pref(P);
+    CAP_HIP(hipMemcpyAsync(tot.data(), w.inv_total, sizeof(fe) * P, hipMemcpyDeviceToHost, s));
+    CAP_HIP(hipStreamSynchronize(s));
+    // (a proof whose product is zero - one of its denominators vanished, probability ~ 2^-236 - must not poison the
+    // shared inversion: it is left out of the chain and gets the inverse 0, as the per-proof device inversion gave it)
+    fe acc = Fr::one();
+    for (uint32_t p = 0; p < P; p++) {
+      pref[p] = acc;
+      if (!Fr::is_zero(tot[p])) acc = Fr::mul(acc, tot[p]);
+    }
+    acc = Fr::inv(acc);
+    for (uint32_t p = P; p-- > 0;) {
+      if (Fr::is_zero(tot[p])) continue;
+      const fe inv_p = Fr::mul(acc, pref[p]);
+      acc = Fr::mul(acc, tot[p]);
+      tot[p] = inv_p;
+    }
+    CAP_HIP(hipMemcpyAsync(w.inv_total, tot.data(), sizeof(fe) * P, hipMemcpyHostToDevice, s));
+    if ((rc = seg(7, [&]() -> int {
+           int r;
+           launch("k_perm_finish", k_perm_finish, dim3(cdiv(ps, kThreads), P), dim3(kThreads), 0, s, (const fe*)w.pre,
+                  (const fe*)w.sfx, (const fe*)w.den, (const fe*)w.inv_total, n, w.zpoly, ps);
+           if ((r = run_ntt(s, K.log_n, w.zpoly, ps, P, 1, 0))) return r;
+           launch("k_blind", k_blind<0>, dim3(P), dim3(64), 0, s, w.zpoly, ps, n, (const fe*)w.d_blind, 1u, 10u, 3u, P);
+           return run_msm(s, *B, w.zpoly, ps, 1, 0, n + 3, P, w.comms);
+         })))
+      return rc;
   }
-  launch("k_perm_inv_total", k_perm_inv_total, dim3(cdiv(P, 64)), dim3(64), 0, s, (const fe*)w.sfx, (const fe*)w.den,
-         n, w.inv_total, P);
-  launch("k_perm_finish", k_perm_finish, dim3(cdiv(ps, kThreads), P), dim3(kThreads), 0, s, (const fe*)w.pre,
-         (const fe*)w.sfx, (const fe*)w.den, (const fe*)w.inv_total, n, w.zpoly, ps);
-  if ((rc = run_ntt(s, K.log_n, w.zpoly, ps, P, 1, 0))) return rc;
-  launch("k_blind", k_blind<0>, dim3(P), dim3(64), 0, s, w.zpoly, ps, n, (const fe*)w.d_blind, 1u, 10u, 3u, P);
-  if ((rc = run_msm(s, *B, w.zpoly, ps, 1, 0, n + 3, P, w.comms))) return rc;
   if ((rc = fetch_comms(P, [&]() -> int {  // likewise the coset evaluations of z
-         return run_ntt3_fwd(s, K.log_m, w.coset + 5 * m, P, NttIo{w.zpoly, ps, 0, n + 3, 1, 7 * m, 0, 1});
+         return seg(3, [&]() -> int {
+           return run_ntt3_fwd(s, K.log_m, w.coset + 5 * m, P, NttIo{w.zpoly, ps, 0, n + 3, 1, 7 * m, 0, 1});
+         });
        })))
     return rc;
   parallel_for(P, [&](uint32_t p) {
@@ -536,22 +753,26 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   CAP_HIP(hipMemcpyAsync(w.chal29, chal29.data(), sizeof(Chal) * P, hipMemcpyHostToDevice, s));
 
   // ---- round 3: quotient polynomial (its seven coset transforms were enqueued behind the round 1 and 2 MSMs) ------
-  const fe* pkc = K.pk_coset;
-  if (K.recompute) {
-    // reference schedule: the 18 selector / sigma polynomials are re-transformed for every proof
-    for (uint32_t p = 0; p < P; p++)
-      if ((rc = compute_pk_coset(s, K, w.pkc))) return rc;
-    pkc = w.pkc;
-  }
-  launch("k_quotient", k_quotient, dim3(P, cdiv(m, kThreads)), dim3(kThreads), 0, s, pkc, pkc_of, (const fe*)w.coset,
-         (const fe*)dom_q->xs29, (const fe*)K.inv_nx1, (const Chal*)w.chal29, K.qc29, m, w.t);
-  if ((rc = run_ntt3_inv(s, K.log_m, w.t, P))) return rc;
-  {
-    size_t lo = NW * (n + 1) + 3;  // first index that must be zero: degree is exactly 5(n+1)+2
-    launch("k_check_degree", k_check_degree, dim3(cdiv(m - (lo - 1), kThreads), P), dim3(kThreads), 0, s,
-           (const fe*)w.t, m, lo, w.flags);
-  }
-  if ((rc = run_msm(s, *B, w.t, m, NW, n + 2, n + 2, P * NW, w.comms))) return rc;
+  if ((rc = seg(4, [&]() -> int {
+         int r;
+         const fe* pkc = K.pk_coset;
+         if (K.recompute) {
+           // reference schedule: the 18 selector / sigma polynomials are re-transformed for every proof
+           for (uint32_t p = 0; p < P; p++)
+             if ((r = compute_pk_coset(s, K, w.pkc))) return r;
+           pkc = w.pkc;
+         }
+         launch("k_quotient", k_quotient, dim3(P, cdiv(m, kThreads)), dim3(kThreads), 0, s, pkc, pkc_of,
+                (const fe*)w.coset, (const fe*)dom_q->xs29, (const fe*)K.inv_nx1, (const Chal*)w.chal29, K.qc29, m, w.t);
+         if ((r = run_ntt3_inv(s, K.log_m, w.t, P))) return r;
+         {
+           size_t lo = NW * (n + 1) + 3;  // first index that must be zero: degree is exactly 5(n+1)+2
+           launch("k_check_degree", k_check_degree, dim3(cdiv(m - (lo - 1), kThreads), P), dim3(kThreads), 0, s,
+                  (const fe*)w.t, m, lo, w.flags);
+         }
+         return run_msm(s, *B, w.t, m, NW, n + 2, n + 2, P * NW, w.comms);
+       })))
+    return rc;
   std::vector<uint32_t> flags(P);
   CAP_HIP(hipMemcpyAsync(flags.data(), w.flags, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, s));
   if ((rc = fetch_comms(P * NW))) return rc;
@@ -586,13 +807,6 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
 
   // ---- round 4: evaluations -------------------------------------------------------------------------------
   CAP_HIP(hipMemcpyAsync(w.pw, pw.data(), sizeof(fe) * pw.size(), hipMemcpyHostToDevice, s));
-  {
-    const uint32_t small_len = kPowLow + cdiv(ps, kPowLow);
-    launch("k_powers_small", k_powers_small, dim3(cdiv(small_len, kThreads), P * 4), dim3(kThreads), 0, s, w.pows_small,
-           small_len, (const fe*)w.pw);
-    launch("k_powers", k_powers, dim3(cdiv(ps, kThreads), P * 4), dim3(kThreads), 0, s, w.pows, ps, ps,
-           (const fe*)w.pows_small, small_len);
-  }
   std::vector<EvalDesc> ed((size_t)P * 10);
   for (uint32_t p = 0; p < P; p++) {
     const fe* pz = w.pows + ((size_t)p * 4 + 0) * ps;
@@ -603,12 +817,20 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
     ed[p * 10 + 9] = EvalDesc{w.zpoly + (size_t)p * ps, pzw, (uint32_t)(n + 3), 0};
   }
   CAP_HIP(hipMemcpyAsync(w.edesc, ed.data(), sizeof(EvalDesc) * ed.size(), hipMemcpyHostToDevice, s));
-  {
-    uint32_t per_chunk = cdiv(n + 3, kEvalChunks);
-    launch("k_eval_partial", k_eval_partial, dim3(kEvalChunks, P * 10), dim3(kThreads), 0, s, (const EvalDesc*)w.edesc,
-           w.eval_partial, kEvalChunks, per_chunk);
-    launch("k_eval_final", k_eval_final, dim3(P * 10), dim3(64), 0, s, (const fe*)w.eval_partial, kEvalChunks, w.evals);
-  }
+  if ((rc = seg(5, [&]() -> int {
+         const uint32_t small_len = kPowLow + cdiv(ps, kPowLow);
+         launch("k_powers_small", k_powers_small, dim3(cdiv(small_len, kThreads), P * 4), dim3(kThreads), 0, s,
+                w.pows_small, small_len, (const fe*)w.pw);
+         launch("k_powers", k_powers, dim3(cdiv(ps, kThreads), P * 4), dim3(kThreads), 0, s, w.pows, ps, ps,
+                (const fe*)w.pows_small, small_len);
+         uint32_t per_chunk = cdiv(n + 3, kEvalChunks);
+         launch("k_eval_partial", k_eval_partial, dim3(kEvalChunks, P * 10), dim3(kThreads), 0, s,
+                (const EvalDesc*)w.edesc, w.eval_partial, kEvalChunks, per_chunk);
+         launch("k_eval_final", k_eval_final, dim3(P * 10), dim3(64), 0, s, (const fe*)w.eval_partial, kEvalChunks,
+                w.evals);
+         return CAPGPU_OK;
+       })))
+    return rc;
   std::vector<fe> evals((size_t)P * 10);
   CAP_HIP(hipMemcpyAsync(evals.data(), w.evals, sizeof(fe) * evals.size(), hipMemcpyDeviceToHost, s));
   CAP_HIP(hipStreamSynchronize(s));
@@ -690,16 +912,19 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   }
   CAP_HIP(hipMemcpyAsync(w.terms, terms.data(), sizeof(LinTerm) * terms.size(), hipMemcpyHostToDevice, s));
   // batchpoly[p][0] = linear combination, batchpoly[p][1] = z polynomial
-  launch("k_lincomb", k_lincomb, dim3(cdiv(ps, kThreads), P), dim3(kThreads), 0, s, (const LinTerm*)w.terms, kLinTerms,
-         w.batchpoly, 2 * ps, ps);
-  pad_copy(s, w.batchpoly + ps, 2 * ps, 0, w.zpoly, ps, 0, 1, P, n + 3, ps);
-  launch("k_div_prepare", k_div_prepare, dim3(cdiv(n + 3, kThreads), P * 2), dim3(kThreads), 0, s,
-         (const fe*)w.batchpoly, (const fe*)w.pows, ps, n + 3, w.hbuf);
-  // the suffix sums go to batchpoly (its contents are dead once h is formed)
-  scan_exclusive<1, 1>(s, w.hbuf, w.batchpoly, n + 3, ps, P * 2, w.scan_tot);
-  launch("k_div_finish", k_div_finish, dim3(cdiv(ps, kThreads), P * 2), dim3(kThreads), 0, s, (const fe*)w.batchpoly,
-         (const fe*)w.pows, ps, n + 3, w.quot);
-  if ((rc = run_msm(s, *B, w.quot, ps, 1, 0, n + 2, P * 2, w.comms))) return rc;
+  if ((rc = seg(6, [&]() -> int {
+         launch("k_lincomb", k_lincomb, dim3(cdiv(ps, kThreads), P), dim3(kThreads), 0, s, (const LinTerm*)w.terms,
+                kLinTerms, w.batchpoly, 2 * ps, ps);
+         pad_copy(s, w.batchpoly + ps, 2 * ps, 0, w.zpoly, ps, 0, 1, P, n + 3, ps);
+         launch("k_div_prepare", k_div_prepare, dim3(cdiv(n + 3, kThreads), P * 2), dim3(kThreads), 0, s,
+                (const fe*)w.batchpoly, (const fe*)w.pows, ps, n + 3, w.hbuf);
+         // the suffix sums go to batchpoly (its contents are dead once h is formed)
+         scan_exclusive<1, 1>(s, w.hbuf, w.batchpoly, n + 3, ps, P * 2, w.scan_tot);
+         launch("k_div_finish", k_div_finish, dim3(cdiv(ps, kThreads), P * 2), dim3(kThreads), 0, s,
+                (const fe*)w.batchpoly, (const fe*)w.pows, ps, n + 3, w.quot);
+         return run_msm(s, *B, w.quot, ps, 1, 0, n + 2, P * 2, w.comms);
+       })))
+    return rc;
   if ((rc = fetch_comms(P * 2))) return rc;
   for (uint32_t p = 0; p < P; p++) {
     affine_to_words(ha[p * 2], proofs[p].opening_proof);
@@ -1629,6 +1854,12 @@ int capgpu_plonk_set_coalescing(uint32_t window_us, uint32_t max_batch) {
   std::lock_guard<std::mutex> lk(co.mu);
   co.window_us = window_us;
   co.max_batch = max_batch ? max_batch : 256;
+  return CAPGPU_OK;
+}
+
+int capgpu_plonk_graph_stats(uint64_t* segments_captured_out, uint64_t* segments_replayed_out) {
+  if (segments_captured_out) *segments_captured_out = g_graph_captured.load();
+  if (segments_replayed_out) *segments_replayed_out = g_graph_replayed.load();
   return CAPGPU_OK;
 }
 

@@ -137,6 +137,12 @@ class DevBuf:
         check(load().capgpu_memcpy_h2d(b.ptr, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(a.nbytes)))
         return b
 
+    def upload(self, a: np.ndarray):
+        """overwrite the buffer's first a.nbytes bytes (same device address: resident inputs of a replayed schedule)"""
+        a = np.ascontiguousarray(a)
+        assert a.nbytes <= self.nbytes
+        check(load().capgpu_memcpy_h2d(self.ptr, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(a.nbytes)))
+
     def to_numpy(self, dtype=np.uint64, count: int | None = None, offset_bytes: int = 0) -> np.ndarray:
         itemsize = np.dtype(dtype).itemsize
         n = (self.nbytes - offset_bytes) // itemsize if count is None else count
@@ -530,6 +536,13 @@ def plonk_prove(pk_handle: int, wires: np.ndarray, pub_inputs: np.ndarray, blind
 
 def plonk_set_coalescing(window_us: int, max_batch: int = 0):
     check(load().capgpu_plonk_set_coalescing(ctypes.c_uint32(window_us), ctypes.c_uint32(max_batch)))
+
+
+def plonk_graph_stats():
+    """(segments captured, segments replayed) of the small-batch hipGraph path since process start"""
+    a, b = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    check(load().capgpu_plonk_graph_stats(ctypes.byref(a), ctypes.byref(b)))
+    return a.value, b.value
 
 
 def plonk_coalescing_stats():

@@ -309,6 +309,11 @@ int capgpu_plonk_prove(uint64_t pk_handle, const uint64_t* wires, const uint64_t
 int capgpu_plonk_set_coalescing(uint32_t window_us, uint32_t max_batch);
 /* device batches run and proofs made through the coalescer so far */
 int capgpu_plonk_coalescing_stats(uint64_t* batches_out, uint64_t* proofs_out);
+/* Small batches (count <= CAPGPU_GRAPH_MAX_BATCH, default 16; 0 switches it off) replay their kernel schedule as
+ * hipGraphs: the ~100 launches of a proof fall into seven segments between the host's transcript steps; the second call
+ * with the same key, batch size and buffers captures them, later calls launch seven graphs instead.  Proofs are the same
+ * bytes either way.  Counters since process start: segments captured (instantiated) and segments replayed. */
+int capgpu_plonk_graph_stats(uint64_t* segments_captured_out, uint64_t* segments_replayed_out);
 /* Same, `count` independent proofs under one key pipelined on the device; per-proof arrays are
  * consecutive (wires: count * 5 * n, pub_inputs: count * num_inputs, blinders: count * 13).  With several device
  * contexts bound (capgpu_init) and a calling thread that did not bind itself to one, the batch is cut into contiguous
