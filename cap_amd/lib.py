@@ -137,6 +137,15 @@ class DevBuf:
         check(load().capgpu_memcpy_h2d(b.ptr, a.ctypes.data_as(ctypes.c_void_p), ctypes.c_size_t(a.nbytes)))
         return b
 
+    def view(self, offset_bytes: int, nbytes: int) -> "DevBuf":
+        """a non-owning window of this buffer (the parent must outlive it)"""
+        assert 0 <= offset_bytes and offset_bytes + nbytes <= self.nbytes
+        v = DevBuf.__new__(DevBuf)
+        v.ptr = ctypes.c_void_p(self.ptr.value + offset_bytes)
+        v.nbytes = nbytes
+        v._view = True
+        return v
+
     def upload(self, a: np.ndarray):
         """overwrite the buffer's first a.nbytes bytes (same device address: resident inputs of a replayed schedule)"""
         a = np.ascontiguousarray(a)
@@ -152,6 +161,9 @@ class DevBuf:
         return out
 
     def free(self):
+        if getattr(self, "_view", False):
+            self.ptr = ctypes.c_void_p()
+            return
         if self.ptr and self.ptr.value:
             check(load().capgpu_free(self.ptr))
             self.ptr = ctypes.c_void_p()
