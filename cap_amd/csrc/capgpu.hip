@@ -417,6 +417,12 @@ int clone_srs_to_current(const SrsEntry& src, std::shared_ptr<SrsEntry>* out) {
     CAP_HIP(hipMalloc(&b.ext3, sizeof(g1_affine) * n1 * b.windows3));
     CAP_HIP(copy_between(b.ext3, c.device, src.bases.ext3, src.device, sizeof(g1_affine) * n1 * b.windows3, c.stream));
   }
+  if (src.bases.ext0) {
+    b.c0 = src.bases.c0;
+    b.windows0 = src.bases.windows0;
+    CAP_HIP(hipMalloc(&b.ext0, sizeof(g1_affine) * n1 * b.windows0));
+    CAP_HIP(copy_between(b.ext0, c.device, src.bases.ext0, src.device, sizeof(g1_affine) * n1 * b.windows0, c.stream));
+  }
   CAP_HIP(hipStreamSynchronize(c.stream));
   *out = e;
   return CAPGPU_OK;

@@ -1282,6 +1282,30 @@ struct WsLayout {
 };
 
 // which table / sort a launch uses
+// window bits of the small-launch table (CAPGPU_MSM_SMALL_C: 9 .. 12, 0 = no such table) and the largest launch, in MSMs,
+// that takes it (CAPGPU_MSM_SMALL_MAX)
+// OFF by default: measured in round 4 (tools/gpu_latency_ab.py, profiles/latency_ab_r04.jsonl) the c = 11 table makes a
+// single proof SLOWER, 3.33 -> 4.15 ms, and a lone 2^17-point MSM 0.63 -> 0.82 ms.  The chain through the bucket reduction
+// does shrink (msm_reduce_grid 93 -> 63 us per launch), but a bucket of 768 entries is cut into 64 work items instead of
+// 16 and their per-bucket combine tree costs three times what the reduction saves (msm_combine_wave 60 -> 155-215 us per
+// launch; the 24-entry runs of msm_scatter_runs and the item lists of msm_sort_items grow likewise).  The knob stays for
+// experiments.
+uint32_t small_c() {
+  static const uint32_t v = [] {
+    const char* e = getenv("CAPGPU_MSM_SMALL_C");
+    const int x = e ? atoi(e) : 0;
+    return (uint32_t)(x >= 9 && x <= 12 ? x : 0);
+  }();
+  return v;
+}
+uint32_t small_max_batch() {
+  static const uint32_t v = [] {
+    const char* e = getenv("CAPGPU_MSM_SMALL_MAX");
+    const int x = e ? atoi(e) : 8;
+    return (uint32_t)(x >= 1 && x <= 64 ? x : 8);
+  }();
+  return v;
+}
 constexpr uint32_t kWideCDefault = 15;  // window bits of the large-batch table
 uint32_t wide_c() {
   static uint32_t v = [] {
@@ -1412,6 +1436,11 @@ Plan choose_plan(const MsmBases& bases, size_t n, uint32_t batch) {
       pl = Plan{bases.c2, bases.windows2, pick_sub_bits(n_sub, bases.c2, bases.windows2), bases.ext2, parts, n_sub};
       return pl;
     }
+  }
+  // a handful of MSMs: the small-launch table (fewer buckets: a shorter chain through the bucket reduction)
+  if (bases.ext0 && batch <= small_max_batch() && n >= 1024) {
+    pl = Plan{bases.c0, bases.windows0, 0, bases.ext0, 1, n};
+    return pl;
   }
   return pl;  // one-level sort on the narrow table: n <= 2^18 here, whole MSMs
 }
@@ -1606,6 +1635,22 @@ int msm_precompute(MsmBases* out, const g1_affine* d_bases, size_t n, uint32_t c
     launch("msm_precompute_kernel", msm_precompute_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, out->ext2,
            d_bases, n, kWideC, w2);
   }
+  // the small-launch table (the primary table is the c = 13 one: 1024 < n <= 2^18)
+  if (!getenv("CAPGPU_MSM_C") && small_c() && c == 13 && n >= 1024) {
+    const uint32_t c0 = small_c(), w0 = msm_num_windows(c0);
+    if (w0 <= 31 && (size_t)w0 * n < ((size_t)1 << 31)) {
+      e = hipMalloc(&out->ext0, sizeof(g1_affine) * n * w0);
+      if (e != hipSuccess) {
+        (void)hipStreamSynchronize(stream);
+        msm_free_bases(out);
+        return (int)e;
+      }
+      out->c0 = c0;
+      out->windows0 = w0;
+      launch("msm_precompute_kernel", msm_precompute_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, out->ext0,
+             d_bases, n, c0, w0);
+    }
+  }
   // the deep-window table for long single MSMs (tables of more than 2^18 points)
   if (!getenv("CAPGPU_MSM_C") && deep_enabled() && n > ((size_t)1 << 18) && n >= deep_min_points()) {
     const uint32_t c3 = deep_c(n), w3 = msm_num_windows(c3);
@@ -1630,7 +1675,8 @@ void msm_free_bases(MsmBases* b) {
   if (b->ext) hipFree(b->ext);
   if (b->ext2) hipFree(b->ext2);
   if (b->ext3) hipFree(b->ext3);
-  b->ext = b->ext2 = b->ext3 = nullptr;
+  if (b->ext0) hipFree(b->ext0);
+  b->ext = b->ext2 = b->ext3 = b->ext0 = nullptr;
   b->n = 0;
 }
 
@@ -1886,12 +1932,16 @@ int msm_run_slice(const MsmBases& bases, const Plan& pl, size_t offset, const fe
     (void)hipGetDevice(&dev);
     if (!(attr_set.load() >> (dev & 63) & 1)) {
       for (const void* f : {reinterpret_cast<const void*>(msm_digits_local<0>),
+                            reinterpret_cast<const void*>(msm_digits_local<11>),
                             reinterpret_cast<const void*>(msm_digits_local<13>),
                             reinterpret_cast<const void*>(msm_digits_local<15>)})
         hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
       attr_set.fetch_or(1ull << (dev & 63));
     }
-    auto digits_kernel = c == 13 ? msm_digits_local<13> : (c == 15 ? msm_digits_local<15> : msm_digits_local<0>);
+    auto digits_kernel = c == 13   ? msm_digits_local<13>
+                         : c == 15 ? msm_digits_local<15>
+                         : c == 11 ? msm_digits_local<11>
+                                   : msm_digits_local<0>;
     launch("msm_digits_local", digits_kernel, dim3(sb == 1 ? nblk : nblk * ((sb + 7) / 8) * 8), dim3(kDigitThreads),
            lds_bytes, stream,
            sc0, outer_stride, inner, inner_stride, n, n_sub, parts, montgomery, c, W, nblk, sb, pl.sub_bits, table, tloc,

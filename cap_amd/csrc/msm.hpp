@@ -48,6 +48,11 @@ struct MsmBases {
   // (fewer than 4096 points, or c itself is already the wide window: tables of more than 2^18 points).
   uint32_t c2 = 0, windows2 = 0;
   g1_affine* ext2 = nullptr;
+  // Small-launch table (experiment, CAPGPU_MSM_SMALL_C = 9 .. 12; not built by default): narrower windows - c = 11: 1024
+  // buckets, 24 digits - for launches of a handful of MSMs.  Measured slower than the c = 13 table in round 4 (the
+  // per-bucket combine of four times as many work items outweighs the shorter bucket reduction; msm.hip: small_c).
+  uint32_t c0 = 0, windows0 = 0;
+  g1_affine* ext0 = nullptr;
   // Third table for long single MSMs (>= 2^20 points, see msm.hip "deep sort"): windows of 18-22 bits on ONE bucket set
   // shared by all points - 12-15 digits per scalar instead of 17.  Null when not built.
   uint32_t c3 = 0, windows3 = 0;

@@ -1817,9 +1817,19 @@ int capgpu_plonk_prove_ex(uint64_t pk_handle, const uint64_t* wires, const uint6
     if (reqs.size() >= 2 * (size_t)deal_min() && thread_bound_slot() < 0 && comm_shard_slot() < 0 && num_contexts() > 1 &&
         (c2 = try_acquire_context()) != nullptr) {
       c2->mu.unlock();  // the helper thread locks it itself (the lock belongs to the thread that takes it)
-      const size_t half = reqs.size() / 2;
-      second.assign(reqs.begin() + half, reqs.end());
-      reqs.resize(half);
+      // The cut is UNEVEN (3/8 : 5/8 by default, CAPGPU_COALESCE_SPLIT = eighths of the first part): callers that come
+      // straight back for their next proof (a rayon loop over notes) would otherwise return together, queue together and
+      // leave the device idle while every next batch is gathered and copied.  Two parts of different size end at
+      // different times; from then on each context runs its own group's batches and one is in flight while the other
+      // is being gathered.
+      static const size_t eighths = [] {
+        const char* e = getenv("CAPGPU_COALESCE_SPLIT");
+        const int x = e ? atoi(e) : 3;
+        return (size_t)(x >= 1 && x <= 4 ? x : 3);
+      }();
+      const size_t first = std::max<size_t>((size_t)deal_min(), reqs.size() * eighths / 8);
+      second.assign(reqs.begin() + first, reqs.end());
+      reqs.resize(first);
     }
     std::thread helper;
     if (c2)

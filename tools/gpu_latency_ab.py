@@ -4,6 +4,7 @@ benches/transfer.rs:103-105), small batches, and single MSMs, with the round-4 m
   CAPGPU_GRAPH_MAX_BATCH     hipGraph replay of the prover's kernel segments (0 = direct launches)
   CAPGPU_MSM_GRID_REDUCE     2-D grid bucket reduction for small batches (0 = bit planes)
   CAPGPU_PERM_INV_ON_DEVICE  round 2's inversion on a device thread (1) instead of the host (0)
+  CAPGPU_MSM_SMALL_C / _MAX  window bits of the small-launch table (0 = none) and the largest launch, in MSMs, that takes it
 Every configuration runs in a process of its own (the switches are read once).  One JSON line per configuration.
 
     python tools/gpu_latency_ab.py [--quick]          (driver)
@@ -19,12 +20,19 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 CONFIGS = [
-    ("round3", {"CAPGPU_GRAPH_MAX_BATCH": "0", "CAPGPU_MSM_GRID_REDUCE": "0", "CAPGPU_PERM_INV_ON_DEVICE": "1"}),
-    ("graphs_only", {"CAPGPU_GRAPH_MAX_BATCH": "16", "CAPGPU_MSM_GRID_REDUCE": "0", "CAPGPU_PERM_INV_ON_DEVICE": "1"}),
-    ("grid_only", {"CAPGPU_GRAPH_MAX_BATCH": "0", "CAPGPU_MSM_GRID_REDUCE": "1", "CAPGPU_PERM_INV_ON_DEVICE": "1"}),
-    ("hostinv_only", {"CAPGPU_GRAPH_MAX_BATCH": "0", "CAPGPU_MSM_GRID_REDUCE": "0", "CAPGPU_PERM_INV_ON_DEVICE": "0"}),
-    ("round4", {"CAPGPU_GRAPH_MAX_BATCH": "16", "CAPGPU_MSM_GRID_REDUCE": "1", "CAPGPU_PERM_INV_ON_DEVICE": "0"}),
+    ("round3", {"CAPGPU_GRAPH_MAX_BATCH": "0", "CAPGPU_MSM_GRID_REDUCE": "0", "CAPGPU_PERM_INV_ON_DEVICE": "1",
+                "CAPGPU_MSM_SMALL_C": "0"}),
+    ("graphs_only", {"CAPGPU_GRAPH_MAX_BATCH": "16", "CAPGPU_MSM_GRID_REDUCE": "0", "CAPGPU_PERM_INV_ON_DEVICE": "1",
+                     "CAPGPU_MSM_SMALL_C": "0"}),
+    ("grid_only", {"CAPGPU_GRAPH_MAX_BATCH": "0", "CAPGPU_MSM_GRID_REDUCE": "1", "CAPGPU_PERM_INV_ON_DEVICE": "1",
+                   "CAPGPU_MSM_SMALL_C": "0"}),
+    ("hostinv_only", {"CAPGPU_GRAPH_MAX_BATCH": "0", "CAPGPU_MSM_GRID_REDUCE": "0", "CAPGPU_PERM_INV_ON_DEVICE": "0",
+                      "CAPGPU_MSM_SMALL_C": "0"}),
+    ("round4_small_table_c11", {"CAPGPU_MSM_SMALL_C": "11"}),
+    ("round4_small_table_c12", {"CAPGPU_MSM_SMALL_C": "12"}),
+    ("round4", {}),
 ]
+R3 = {"CAPGPU_GRAPH_MAX_BATCH": "0", "CAPGPU_MSM_GRID_REDUCE": "0", "CAPGPU_PERM_INV_ON_DEVICE": "1", "CAPGPU_MSM_SMALL_C": "0"}
 
 
 def child():
@@ -85,7 +93,7 @@ def main():
     if "--child" in sys.argv:
         return child()
     quick = "--quick" in sys.argv
-    for name, env in (CONFIGS[:1] + CONFIGS[-1:] if quick else CONFIGS):
+    for name, env in ([CONFIGS[0], CONFIGS[4]] + CONFIGS[-1:] if quick else CONFIGS):
         e = dict(os.environ)
         e.update(env)
         e["CAPGPU_AB_NAME"] = name
