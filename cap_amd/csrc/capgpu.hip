@@ -406,6 +406,7 @@ int clone_srs_to_current(const SrsEntry& src, std::shared_ptr<SrsEntry>* out) {
   b.windows2 = src.bases.windows2;
   b.c3 = src.bases.c3;
   b.windows3 = src.bases.windows3;
+  b.top_shift3 = src.bases.top_shift3;
   const size_t n1 = b.n ? b.n : 1;
   CAP_HIP(hipMalloc(&b.ext, sizeof(g1_affine) * n1 * b.windows));
   CAP_HIP(copy_between(b.ext, c.device, src.bases.ext, src.device, sizeof(g1_affine) * n1 * b.windows, c.stream));

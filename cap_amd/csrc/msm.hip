@@ -58,9 +58,10 @@ __device__ __forceinline__ g1x shfl_down_pt(const g1x& a, int d) {
 }
 
 // ---- setup: window multiples of every base -----------------------------------------------
+// top_shift: the last window's points are 2^(c (W - 1) - top_shift) P instead of 2^(c (W - 1)) P (deep table, see MsmBases)
 __global__ __launch_bounds__(kThreads) void msm_precompute_kernel(g1_affine* __restrict__ ext,
                                                                   const g1_affine* __restrict__ bases, size_t n,
-                                                                  uint32_t c, uint32_t windows) {
+                                                                  uint32_t c, uint32_t windows, uint32_t top_shift) {
   size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   // caller bases are in arkworks' Montgomery form (x * 2^256); the table is kept in the internal form
@@ -77,7 +78,8 @@ __global__ __launch_bounds__(kThreads) void msm_precompute_kernel(g1_affine* __r
   ext[i] = G1L::store_affine(p);
   g1x acc = G1L::from_affine(p);
   for (uint32_t w = 1; w < windows; w++) {
-    for (uint32_t k = 0; k < c; k++) acc = G1L::dbl(acc);
+    const uint32_t steps = w + 1 == windows ? c - top_shift : c;
+    for (uint32_t k = 0; k < steps; k++) acc = G1L::dbl(acc);
     ext[(size_t)w * n + i] = G1L::store_affine(G1L::to_affine(acc));
   }
 }
@@ -153,6 +155,7 @@ __global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __re
                                                              size_t n_sub, uint32_t parts,
                                                              int montgomery, uint32_t c, uint32_t windows,
                                                              uint32_t nblk, uint32_t batch, uint32_t sub_bits,
+                                                             uint32_t top_shift,
                                                              uint32_t* __restrict__ table,
                                                              uint32_t* __restrict__ tloc,
                                                              uint32_t* __restrict__ chunks) {
@@ -188,10 +191,17 @@ __global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __re
   if (i < n) {
     k = sc[i];
     if (montgomery) k = Fr::from_mont(k);
+    if constexpr (DEEP) {
+      // the shifted top window (MsmBases::top_shift3) needs scalars below 2^254: a larger one - never what arkworks hands
+      // over, but the ABI takes any 256-bit integer - is folded by the group order first (k P = (k - r) P)
+      if (top_shift)
+        while (k.v[7] >> 30) (void)Fr::sub_mod_raw(k, k);
+    }
     // pass A: histogram
     uint32_t carry = 0;
     if constexpr (CT != 0) {
       all_digits<CT, 0, NWIN>(k, carry, dg);
+      if constexpr (DEEP) dg[NWIN - 1] <<= top_shift;  // never negative: the top digit is far below 2^(c-1)
 #pragma unroll
       for (uint32_t w = 0; w < NWIN; w++) {
         const uint32_t d = dg[w] & 0x7FFFFFFFu;
@@ -1345,6 +1355,25 @@ struct Plan {
 // 254 - c (W - 1) bits, and when those are few, all n of its digits fall into a handful of buckets (c = 18: 2 bits - four
 // buckets of n / 4 entries each; c = 19: 7 bits; c = 21: 2; c = 22: 12).  c = 17 (16 of 17 bits, W = 15) and c = 20 (14 of
 // 20, W = 13) have nearly full top windows, like the c = 15 table (14 of 15).
+// Scalars are < 2^254 (canonical; msm_digits_local folds larger inputs by r first), so the top window of the deep table
+// holds top_bits = 254 - c (W - 1) of its c bits and its digit is at most 2^top_bits (with the carry from below).
+// Shifted left by (c - 1) - top_bits it still fits the 2^(c-1) buckets and lands on every 2^shift-th of them.
+// OFF by default (CAPGPU_MSM_DEEP_SHIFT=1 switches it on): measured in round 4 at 2^24 points (tools/gpujob_deepshift.sh,
+// profiles/deepshift_r04.jsonl) the shift does what it was meant to - msm_deep_sort<1> 2.21 -> 1.08 ms at c = 22, the
+// crowded bins gone - and c = 22 does shorten the accumulation (15.34 -> 14.38 ms: 12 digits instead of 13), but the
+// 4096 buckets that hold the top window's n / 4096 entries each are now one in every 512 instead of 4096 in a row, and
+// msm_combine - one thread per bucket, serial over the bucket's ~66 work items - runs one long lane per wave: 0.2 -> 5.7
+// ms.  With a lane-parallel combine for those buckets the total would be ~18.0 ms against 18.3 ms for c = 20 unshifted
+// (2^21 buckets cost +0.5 ms in sorts and reductions): not pursued.  c = 20 with the shift: 18.87 against 18.33 ms.
+uint32_t deep_top_shift(uint32_t c, uint32_t windows) {
+  static const bool on = [] {
+    const char* e = getenv("CAPGPU_MSM_DEEP_SHIFT");
+    return e && atoi(e) != 0;
+  }();
+  const int top_bits = 254 - (int)c * ((int)windows - 1);
+  if (!on || top_bits <= 0 || top_bits >= (int)c - 1) return 0;
+  return (uint32_t)((int)c - 1 - top_bits);
+}
 uint32_t deep_c(size_t n) {
   if (const char* e = getenv("CAPGPU_MSM_DEEP_C")) {
     const int x = atoi(e);
@@ -1618,7 +1647,7 @@ int msm_precompute(MsmBases* out, const g1_affine* d_bases, size_t n, uint32_t c
   if (n == 0) return 0;
   size_t blocks = (n + kThreads - 1) / kThreads;
   launch("msm_precompute_kernel", msm_precompute_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, out->ext, d_bases, n, c,
-                     out->windows);
+                     out->windows, 0u);
   // the wide-window table for large batches
   const char* env = getenv("CAPGPU_MSM_WIDE");
   const uint32_t kWideC = wide_c();
@@ -1633,7 +1662,7 @@ int msm_precompute(MsmBases* out, const g1_affine* d_bases, size_t n, uint32_t c
     out->c2 = kWideC;
     out->windows2 = w2;
     launch("msm_precompute_kernel", msm_precompute_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, out->ext2,
-           d_bases, n, kWideC, w2);
+           d_bases, n, kWideC, w2, 0u);
   }
   // the small-launch table (the primary table is the c = 13 one: 1024 < n <= 2^18)
   if (!getenv("CAPGPU_MSM_C") && small_c() && c == 13 && n >= 1024) {
@@ -1648,7 +1677,7 @@ int msm_precompute(MsmBases* out, const g1_affine* d_bases, size_t n, uint32_t c
       out->c0 = c0;
       out->windows0 = w0;
       launch("msm_precompute_kernel", msm_precompute_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, out->ext0,
-             d_bases, n, c0, w0);
+             d_bases, n, c0, w0, 0u);
     }
   }
   // the deep-window table for long single MSMs (tables of more than 2^18 points)
@@ -1664,8 +1693,9 @@ int msm_precompute(MsmBases* out, const g1_affine* d_bases, size_t n, uint32_t c
       }
       out->c3 = c3;
       out->windows3 = w3;
+      out->top_shift3 = deep_top_shift(c3, w3);
       launch("msm_precompute_kernel", msm_precompute_kernel, dim3((unsigned)blocks), dim3(kThreads), 0, stream, out->ext3,
-             d_bases, n, c3, w3);
+             d_bases, n, c3, w3, out->top_shift3);
     }
   }
   return 0;  // launch failures are latched by launch() and reported by take_launch_error()
@@ -1842,7 +1872,7 @@ int msm_run_deep(const MsmBases& bases, const Plan& pl, size_t offset, const fe*
                           : msm_digits_local<22, true>;
     const size_t lds_bytes = sizeof(uint32_t) * (2 * (size_t)S1 + (size_t)kDigitTile * W);
     launch("msm_digits_local", kern, dim3(nblk), dim3(kDigitThreads), lds_bytes, stream, d_scalars, (size_t)0, 1u,
-           (size_t)0, n, n, 1u, montgomery, c, W, nblk, 1u, pl.sub_bits, table, tloc, chunks);
+           (size_t)0, n, n, 1u, montgomery, c, W, nblk, 1u, pl.sub_bits, bases.top_shift3, table, tloc, chunks);
   }
   scan(table, off2, (size_t)S1 * nblk);
   // level 2: (super-bin, group of tiles) sorted by the middle key bits, written back in super-bin-major order
@@ -1944,8 +1974,8 @@ int msm_run_slice(const MsmBases& bases, const Plan& pl, size_t offset, const fe
                                    : msm_digits_local<0>;
     launch("msm_digits_local", digits_kernel, dim3(sb == 1 ? nblk : nblk * ((sb + 7) / 8) * 8), dim3(kDigitThreads),
            lds_bytes, stream,
-           sc0, outer_stride, inner, inner_stride, n, n_sub, parts, montgomery, c, W, nblk, sb, pl.sub_bits, table, tloc,
-           chunk_buf);
+           sc0, outer_stride, inner, inner_stride, n, n_sub, parts, montgomery, c, W, nblk, sb, pl.sub_bits, 0u, table,
+           tloc, chunk_buf);
     scan_counts(table, off2, bins * nblk);
     if (pl.sub_bits) {
       // two-level sort: bins are finished per workgroup straight from the tile chunks

@@ -57,6 +57,11 @@ struct MsmBases {
   // shared by all points - 12-15 digits per scalar instead of 17.  Null when not built.
   uint32_t c3 = 0, windows3 = 0;
   g1_affine* ext3 = nullptr;
+  // Experiment (CAPGPU_MSM_DEEP_SHIFT=1; 0 by default): the top window of the deep table holds only 254 - c3 (W3 - 1)
+  // scalar bits, so its digits all fall into the lowest 2^top_bits buckets - 32 of the 16384 sort bins at c3 = 22.  With
+  // the shift the table stores the top window's points 2^top_shift3 times smaller and the digit is multiplied by
+  // 2^top_shift3: the same multiples, spread over the whole bucket range (msm.hip: deep_top_shift, with the measurement).
+  uint32_t top_shift3 = 0;
 };
 
 struct MsmWorkspace {
