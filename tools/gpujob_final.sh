@@ -12,6 +12,7 @@ timeout 600 python bench.py --workload mixed64 --steps 12 --warmup 3 --no-msm > 
 CAPGPU_ALLOW_DUPLICATE_DEVICES=1 timeout 600 python bench.py --single-process --devices 0,0 --batch 128 --steps 4 --warmup 1 --msm-log-n 22 > $O/bench_single_process.json 2>/dev/null
 MINLOG=21 timeout 300 python tools/gpu_msm_deep_ab.py 24 > $O/msm_deep_ab.jsonl 2>/dev/null
 timeout 300 python tools/gpu_two_ctx.py 15 256 2>/dev/null | tail -1 > $O/two_ctx.json
+timeout 600 python tools/gpu_latency_ab.py --quick > $O/latency_ab.jsonl 2>/dev/null
 MSM_LOGS=15,17,20,22,24 timeout 600 python tools/gpu_msm_profile.py > $O/msm_single_profile.json 2>/dev/null
 bash tools/gpuprof.sh $tag > $O/gpuprof.log 2>&1
 python tools/make_traffic.py gpurun_out/prof_$tag 256 $O/traffic.json > $O/traffic.log 2>&1

@@ -8,7 +8,7 @@ R=$GRAFT_REPO_ROOT
 cd $R
 mkdir -p gpurun_out/clock_$tag
 for ctr in GRBM_GUI_ACTIVE GRBM_COUNT SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY; do
-  timeout 240 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/clock_$tag/$ctr -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-reference-schedule --no-msm --no-extras > /dev/null 2> gpurun_out/clock_$tag/$ctr.err
+  timeout 240 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/clock_$tag/$ctr -- python3 bench.py --one-context --steps 1 --warmup 1 --no-cpu-baseline --no-reference-schedule --no-msm --no-extras > /dev/null 2> gpurun_out/clock_$tag/$ctr.err
 done
 python3 - <<PY
 import csv, glob, collections, json

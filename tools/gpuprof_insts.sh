@@ -8,7 +8,7 @@ cd $R
 mkdir -p gpurun_out/insts_$tag
 for ctr in "SQ_INSTS_VALU SQ_INSTS_SALU" "SQ_WAVES SQ_INSTS_VMEM" "SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES" "SQ_BUSY_CYCLES SQ_INSTS_LDS"; do
   name=$(echo $ctr | tr ' ' '_')
-  rocprofv3 --pmc $ctr --output-format csv -d gpurun_out/insts_$tag/$name -- python3 bench.py --steps 1 --warmup 1 --no-cpu-baseline --no-reference-schedule --no-msm --no-extras > /dev/null 2> gpurun_out/insts_$tag/$name.err
+  rocprofv3 --pmc $ctr --output-format csv -d gpurun_out/insts_$tag/$name -- python3 bench.py --one-context --steps 1 --warmup 1 --no-cpu-baseline --no-reference-schedule --no-msm --no-extras > /dev/null 2> gpurun_out/insts_$tag/$name.err
 done
 python3 - <<PY
 import csv, glob, collections

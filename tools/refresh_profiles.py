@@ -8,7 +8,7 @@ import shutil
 import sys
 
 tag = sys.argv[1]
-rnd = sys.argv[2] if len(sys.argv) > 2 else "r03"
+rnd = sys.argv[2] if len(sys.argv) > 2 else "r04"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, prof, dst = (os.path.join(root, "gpurun_out", "final_" + tag), os.path.join(root, "gpurun_out", "prof_" + tag),
                   os.path.join(root, "profiles"))
@@ -26,7 +26,8 @@ b20 = one_line_json(os.path.join(src, "bench_20steps.json"), os.path.join(dst, f
 bm = one_line_json(os.path.join(src, "bench_mixed64.json"), os.path.join(dst, f"bench_mixed64_{rnd}.json"))
 shutil.copy(os.path.join(src, "msm_single_profile.json"), os.path.join(dst, f"msm_single_profile_{rnd}.json"))
 for name, out_name in (("bench_single_process.json", f"bench_single_process_dev0x2_{rnd}.json"),
-                       ("msm_deep_ab.jsonl", f"msm_deep_ab_{rnd}.jsonl"), ("two_ctx.json", f"two_contexts_ab_{rnd}.json")):
+                       ("msm_deep_ab.jsonl", f"msm_deep_ab_{rnd}.jsonl"), ("two_ctx.json", f"two_contexts_ab_{rnd}.json"),
+                       ("clock.json", f"clock_{rnd}.json"), ("latency_ab.jsonl", f"latency_ab_final_{rnd}.jsonl")):
     if os.path.exists(os.path.join(src, name)) and os.path.getsize(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, out_name))
 shutil.copy(os.path.join(src, "traffic.json"), os.path.join(dst, f"traffic_{rnd}.json"))
@@ -48,7 +49,7 @@ for ln in open(os.path.join(src, "insts.txt")):
     launches = max(v[1] for v in d.values())
     kern[name.strip()] = dict(launches=launches, **{k: round(v[0] / v[1]) if isinstance(v[0], float) else v[0] for k, v in d.items()})
 prev = os.path.join(dst, f"inst_counters_{rnd}.json")
-old = json.load(open(prev if os.path.exists(prev) else os.path.join(dst, "inst_counters_r02.json")))
+old = json.load(open(prev if os.path.exists(prev) else os.path.join(dst, "inst_counters_r03.json")))
 adds = b["alu_roofline"]["mixed_adds_per_step"] / 4           # four large msm_accumulate launches per step
 acc = kern["msm_accumulate"]
 # the PMC run has 8 large launches and the small one of preprocess; its counters are per-launch averages over all 9
