@@ -291,3 +291,20 @@ def test_unpinned_status_is_reported():
     for n in missing:
         with pytest.raises(pytest.skip.Exception, match="parity unpinned"):
             ref(n)
+
+
+def test_the_pin_is_one_command():
+    """tools/rust_vectors/run.sh: cargo build + emit + copy + the exact pytest line (round-3 VERDICT item 8).  Here - no
+    cargo, no reference checkout - it must at least name the files these tests read and refuse cleanly."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sh = os.path.join(root, "tools", "rust_vectors", "run.sh")
+    assert os.access(sh, os.X_OK)
+    txt = open(sh).read()
+    for f in ("ref_msm.json", "ref_ntt.json", "ref_proof.json", "ref_params.json"):
+        assert f in txt
+    assert 'pytest tests/test_ref_vectors.py -q -m "not gpu"' in txt and "cargo run --release" in txt
+    r = subprocess.run(["bash", sh], capture_output=True, text=True)
+    assert r.returncode == 2 and "usage" in r.stderr
+    readme = open(os.path.join(root, "README.md")).read()
+    assert "tools/rust_vectors/run.sh" in readme[:3000]
