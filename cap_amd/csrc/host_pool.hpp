@@ -35,12 +35,17 @@ class HostPool {
   HostPool& operator=(const HostPool&) = delete;
   unsigned size() const { return nt_; }
   // threads a context's pool gets when `contexts` of them share the host: CAPGPU_HOST_THREADS (per context) or the
-  // hardware threads divided among the contexts, 32 at most (more does not shorten the 256-transcript phases)
+  // hardware threads divided among the contexts - of ALL the processes a launcher put on this host (one process per
+  // GPU: LOCAL_WORLD_SIZE as torchrun and its kin export it; eight ranks must not each size their pools for the whole
+  // machine) -, 32 at most (more does not shorten the 256-transcript phases)
   static unsigned default_threads(unsigned contexts) {
     const char* e = getenv("CAPGPU_HOST_THREADS");
+    const char* lw = getenv("LOCAL_WORLD_SIZE");
+    const unsigned procs = lw && atoi(lw) > 0 ? (unsigned)atoi(lw) : 1u;
+    const unsigned sharers = std::max(contexts, 1u) * procs;
     unsigned hw = std::thread::hardware_concurrency();
-    unsigned v = e ? (unsigned)atoi(e) : (hw + contexts - 1) / std::max(contexts, 1u);
-    return std::min(std::max(v, 1u), 32u);
+    unsigned v = e ? (unsigned)atoi(e) : (hw + sharers - 1) / sharers;
+    return std::min(std::max(v, 2u), 32u);
   }
   // runs job(i) for i in [0, count); the caller takes part
   void run(uint32_t count, const std::function<void(uint32_t)>& job) {

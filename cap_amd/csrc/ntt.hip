@@ -24,6 +24,15 @@ namespace cap {
 namespace {
 
 constexpr int kThreads = 256;
+#ifndef CAP_NTT_IO_BATCH
+#define CAP_NTT_IO_BATCH 4
+#endif
+constexpr int kIoBatch = CAP_NTT_IO_BATCH;
+#ifdef CAP_NTT_WAVES4  // experiment: hold the passes to the 128 VGPRs of four waves per SIMD (the LDS tile allows no more)
+#define CAP_NTT_ATTR __attribute__((amdgpu_waves_per_eu(4, 4)))
+#else
+#define CAP_NTT_ATTR
+#endif  // elements per thread whose global loads are issued together (a 1024-element tile: all 4)
 constexpr uint32_t kMaxTileLogDefault = 10;  // 1024 elements * 36 B = 36 KiB of LDS (4 workgroups per CU)
 uint32_t max_tile_log() {
   static uint32_t v = [] {
@@ -157,7 +166,7 @@ __device__ __forceinline__ void lds_ntt(fl* sh, const fl* __restrict__ tw_small,
 }
 
 // column pass: len rows at stride S = M/len, C adjacent columns per tile
-__global__ __launch_bounds__(kThreads) void ntt_col_pass(PassParams p) {
+__global__ __launch_bounds__(kThreads) CAP_NTT_ATTR void ntt_col_pass(PassParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   fl* sh = reinterpret_cast<fl*>(smem);
   const uint32_t log_s = p.log_m - p.log_len;           // columns per segment (log)
@@ -174,40 +183,75 @@ __global__ __launch_bounds__(kThreads) void ntt_col_pass(PassParams p) {
   const size_t base = (seg << p.log_m) + col0;
   const uint32_t tile = 1u << (p.log_len + p.log_c);
   const uint32_t cmask = (1u << p.log_c) - 1;
-  for (uint32_t e = threadIdx.x; e < tile; e += kThreads) {
-    uint32_t c = e & cmask, j = e >> p.log_c;
-    size_t g = base + ((size_t)j << log_s) + c;
-    fe raw;
-    uint32_t any = 0;
-    // position inside the source array (decimated input: every in_es-th element, starting at the group offset)
-    const size_t sg = p.in_es == 1 ? g : g * p.in_es + (size_t)(blockIdx.y % p.in_group) * p.in_inner;
-    if (sg < p.in_len) {
-      raw = p.in_es == 1 ? in[g] : in[g * p.in_es];
+  // Four elements per thread and round, their global loads (and the loads of their coset factors) issued together before
+  // any of them is used: the loop used to be load - wait - multiply - store, one element at a time, and a wave sat
+  // through four memory latencies per tile where it now sits through one (CAP_NTT_BATCHED_IO=0: the old loop).
+  for (uint32_t e0 = threadIdx.x; e0 < tile; e0 += kIoBatch * kThreads) {
+    fe raw[kIoBatch], pre[kIoBatch];
+    uint32_t any[kIoBatch];
+    size_t sgs[kIoBatch];
 #pragma unroll
-      for (int k = 0; k < 8; k++) any |= raw.v[k];
-    } else {
+    for (int u = 0; u < kIoBatch; u++) {
+      const uint32_t e = e0 + u * kThreads;
+      const uint32_t c = e & cmask, j = e >> p.log_c;
+      const size_t g = base + ((size_t)j << log_s) + c;
+      // position inside the source array (decimated input: every in_es-th element, starting at the group offset)
+      const size_t sg = p.in_es == 1 ? g : g * p.in_es + (size_t)(blockIdx.y % p.in_group) * p.in_inner;
+      sgs[u] = sg;
+      any[u] = 0;
+      if (e < tile && sg < p.in_len) {
+        raw[u] = p.in_es == 1 ? in[g] : in[g * p.in_es];
+        any[u] = 1;
+      } else {
 #pragma unroll
-      for (int k = 0; k < 8; k++) raw.v[k] = 0;
+        for (int k = 0; k < 8; k++) raw[u].v[k] = 0;
+      }
     }
-    fl v = Fr29::load(raw);
-    if (p.pre_scale && any)  // zero padding needs no coset scaling
-      v = Fr29::mul(v, Fr29::load(p.pre_scale[sg + (size_t)(blockIdx.y % p.in_group) * p.pre_inner]));
-    sh[(bitrev32(j, p.log_len) << p.log_c) + c] = v;
+    if (p.pre_scale) {
+#pragma unroll
+      for (int u = 0; u < kIoBatch; u++)
+        if (any[u]) pre[u] = p.pre_scale[sgs[u] + (size_t)(blockIdx.y % p.in_group) * p.pre_inner];
+    }
+#pragma unroll
+    for (int u = 0; u < kIoBatch; u++) {
+      const uint32_t e = e0 + u * kThreads;
+      if (e >= tile) break;
+      const uint32_t c = e & cmask, j = e >> p.log_c;
+      uint32_t nz = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) nz |= raw[u].v[k];
+      fl v = Fr29::load(raw[u]);
+      if (p.pre_scale && any[u] && nz) v = Fr29::mul(v, Fr29::load(pre[u]));  // zero padding needs no coset scaling
+      sh[(bitrev32(j, p.log_len) << p.log_c) + c] = v;
+    }
   }
   __syncthreads();
   lds_ntt(sh, p.tw_small, p.log_len, p.log_c);
   const uint32_t tw_shift = p.log_n - p.log_m;  // omega_M^x = omega_N^(x << tw_shift)
-  for (uint32_t e = threadIdx.x; e < tile; e += kThreads) {
-    uint32_t c = e & cmask, k = e >> p.log_c;
-    fl v = sh[e];
-    size_t ex = ((size_t)(col0 + c) * k) << tw_shift;
-    v = ex ? Fr29::mul(v, Fr29::load(p.tw_full[ex])) : Fr29::weak_reduce(v);
-    out[base + ((size_t)k << log_s) + c] = Fr29::pack(v);   // < 2p: fits the 32-byte image
+  for (uint32_t e0 = threadIdx.x; e0 < tile; e0 += kIoBatch * kThreads) {
+    fe tw[kIoBatch];
+    size_t exs[kIoBatch];
+#pragma unroll
+    for (int u = 0; u < kIoBatch; u++) {  // the inter-pass twiddles of the batch: gathers from a 2 MB table, in flight together
+      const uint32_t e = e0 + u * kThreads;
+      const uint32_t c = e & cmask, k = e >> p.log_c;
+      exs[u] = e < tile ? ((size_t)(col0 + c) * k) << tw_shift : 0;
+      if (exs[u]) tw[u] = p.tw_full[exs[u]];
+    }
+#pragma unroll
+    for (int u = 0; u < kIoBatch; u++) {
+      const uint32_t e = e0 + u * kThreads;
+      if (e >= tile) break;
+      const uint32_t c = e & cmask, k = e >> p.log_c;
+      fl v = sh[e];
+      v = exs[u] ? Fr29::mul(v, Fr29::load(tw[u])) : Fr29::weak_reduce(v);
+      out[base + ((size_t)k << log_s) + c] = Fr29::pack(v);   // < 2p: fits the 32-byte image
+    }
   }
 }
 
 // row pass: contiguous rows of len elements; C rows with adjacent k1 per tile; digit-reversed store
-__global__ __launch_bounds__(kThreads) void ntt_row_pass(PassParams p) {
+__global__ __launch_bounds__(kThreads) CAP_NTT_ATTR void ntt_row_pass(PassParams p) {
   extern __shared__ __align__(16) unsigned char smem[];
   fl* sh = reinterpret_cast<fl*>(smem);
   const uint32_t t = blockIdx.x;
@@ -222,25 +266,43 @@ __global__ __launch_bounds__(kThreads) void ntt_row_pass(PassParams p) {
   const uint32_t tile = 1u << (p.log_len + p.log_c);
   const uint32_t lmask = (1u << p.log_len) - 1;
   const uint32_t cmask = (1u << p.log_c) - 1;
-  for (uint32_t e = threadIdx.x; e < tile; e += kThreads) {
-    uint32_t j = e & lmask, c = e >> p.log_len;
-    size_t g = ((((size_t)(r0 + c) << p.log_n2) + k2) << p.log_len) + j;
-    fe raw;
-    uint32_t any = 0;
-    // position inside the source array (decimated input: every in_es-th element, starting at the group offset)
-    const size_t sg = p.in_es == 1 ? g : g * p.in_es + (size_t)(blockIdx.y % p.in_group) * p.in_inner;
-    if (sg < p.in_len) {
-      raw = p.in_es == 1 ? in[g] : in[g * p.in_es];
+  for (uint32_t e0 = threadIdx.x; e0 < tile; e0 += kIoBatch * kThreads) {  // batched loads: see ntt_col_pass
+    fe raw[kIoBatch], pre[kIoBatch];
+    uint32_t any[kIoBatch];
+    size_t sgs[kIoBatch];
 #pragma unroll
-      for (int k = 0; k < 8; k++) any |= raw.v[k];
-    } else {
+    for (int u = 0; u < kIoBatch; u++) {
+      const uint32_t e = e0 + u * kThreads;
+      const uint32_t j = e & lmask, c = e >> p.log_len;
+      const size_t g = ((((size_t)(r0 + c) << p.log_n2) + k2) << p.log_len) + j;
+      const size_t sg = p.in_es == 1 ? g : g * p.in_es + (size_t)(blockIdx.y % p.in_group) * p.in_inner;
+      sgs[u] = sg;
+      any[u] = 0;
+      if (e < tile && sg < p.in_len) {
+        raw[u] = p.in_es == 1 ? in[g] : in[g * p.in_es];
+        any[u] = 1;
+      } else {
 #pragma unroll
-      for (int k = 0; k < 8; k++) raw.v[k] = 0;
+        for (int k = 0; k < 8; k++) raw[u].v[k] = 0;
+      }
     }
-    fl v = Fr29::load(raw);
-    if (p.pre_scale && any)  // zero padding needs no coset scaling
-      v = Fr29::mul(v, Fr29::load(p.pre_scale[sg + (size_t)(blockIdx.y % p.in_group) * p.pre_inner]));
-    sh[(bitrev32(j, p.log_len) << p.log_c) + c] = v;
+    if (p.pre_scale) {
+#pragma unroll
+      for (int u = 0; u < kIoBatch; u++)
+        if (any[u]) pre[u] = p.pre_scale[sgs[u] + (size_t)(blockIdx.y % p.in_group) * p.pre_inner];
+    }
+#pragma unroll
+    for (int u = 0; u < kIoBatch; u++) {
+      const uint32_t e = e0 + u * kThreads;
+      if (e >= tile) break;
+      const uint32_t j = e & lmask, c = e >> p.log_len;
+      uint32_t nz = 0;
+#pragma unroll
+      for (int k = 0; k < 8; k++) nz |= raw[u].v[k];
+      fl v = Fr29::load(raw[u]);
+      if (p.pre_scale && any[u] && nz) v = Fr29::mul(v, Fr29::load(pre[u]));  // zero padding needs no coset scaling
+      sh[(bitrev32(j, p.log_len) << p.log_c) + c] = v;
+    }
   }
   __syncthreads();
   lds_ntt(sh, p.tw_small, p.log_len, p.log_c);
