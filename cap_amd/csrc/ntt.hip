@@ -24,8 +24,12 @@ namespace cap {
 namespace {
 
 constexpr int kThreads = 256;
+// Elements per thread whose global loads are issued together.  Measured in round 4 (tools/gpujob_ntt_io.sh, same box,
+// col + row pass per step): 1 (the old element-by-element loop) 37.2-37.6 ms, 2: 36.7 ms, 4: 38.1-38.4 ms (135 VGPRs: three
+// waves per SIMD instead of four; held to 128 VGPRs with 52 B of scratch: 37.9 ms).  The passes are not waiting for
+// memory - they are issue-bound butterflies with a barrier per radix-4 round - so 2 stays, for what it is worth.
 #ifndef CAP_NTT_IO_BATCH
-#define CAP_NTT_IO_BATCH 4
+#define CAP_NTT_IO_BATCH 2
 #endif
 constexpr int kIoBatch = CAP_NTT_IO_BATCH;
 #ifdef CAP_NTT_WAVES4  // experiment: hold the passes to the 128 VGPRs of four waves per SIMD (the LDS tile allows no more)
@@ -183,9 +187,8 @@ __global__ __launch_bounds__(kThreads) CAP_NTT_ATTR void ntt_col_pass(PassParams
   const size_t base = (seg << p.log_m) + col0;
   const uint32_t tile = 1u << (p.log_len + p.log_c);
   const uint32_t cmask = (1u << p.log_c) - 1;
-  // Four elements per thread and round, their global loads (and the loads of their coset factors) issued together before
-  // any of them is used: the loop used to be load - wait - multiply - store, one element at a time, and a wave sat
-  // through four memory latencies per tile where it now sits through one (CAP_NTT_BATCHED_IO=0: the old loop).
+  // kIoBatch elements per thread and round, their global loads (and the loads of their coset factors) issued together
+  // before any of them is used (the loop used to be load - wait - multiply - store, one element at a time)
   for (uint32_t e0 = threadIdx.x; e0 < tile; e0 += kIoBatch * kThreads) {
     fe raw[kIoBatch], pre[kIoBatch];
     uint32_t any[kIoBatch];
