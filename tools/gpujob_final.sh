@@ -4,7 +4,7 @@
 tag=$1
 O=gpurun_out/final_$tag
 mkdir -p $O
-timeout 1500 python -m pytest tests -m gpu -q --durations=10 --timeout=600 > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
+timeout 2400 python -m pytest tests -m gpu -q --durations=10 --timeout=600 > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
 python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
 timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err
 timeout 600 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-reference-schedule --no-msm > $O/bench_20steps.json 2>/dev/null
