@@ -24,7 +24,7 @@ def test_isa_mix_classes_are_priced():
         sh = mix["other_kernels"][name]["class_share"]
         assert set(sh) <= set(cg.ISSUE_CLASSES) and abs(sum(sh.values()) - 1.0) < 1e-9
         assert 0.6 < sh["v_mad_u64_u32"] < 0.8, name
-    clock = json.load(open(os.path.join(ROOT, "profiles", "clock_r03.json")))["derived"]
+    clock = json.load(open(os.path.join(ROOT, "profiles", "clock_r04.json")))["derived"]
     assert 1.5 < clock["msm_accumulate"]["clock_GHz"] < 2.5 and 0.5 < clock["msm_accumulate"]["cu_busy_frac"] <= 1.02
 
 

@@ -1,5 +1,7 @@
 """Differential fuzz of the device prover against the C restatement: random domain sizes, public-input counts,
-batch sizes, messages, single- and mixed-key batches.  python tools/gpu_fuzz_prover.py [rounds] [seed] [big]
+batch sizes, messages, single- and mixed-key batches, both input forms of the ABI (tables of values / polynomials in
+coefficient form, for the keys and for the wires independently), and every batch proved three times (small batches are
+captured as hipGraphs on the second call and replayed on the third: all three must be the same bytes).  python tools/gpu_fuzz_prover.py [rounds] [seed] [big]
 (also run, bounded, by tests/test_gpu_fuzz.py)"""
 import random
 import sys
@@ -33,11 +35,21 @@ def run(rounds=30, seed=1, big=False, max_checked=None, log=print):
         # (a C-side key costs 18 CPU MSMs: the threshold shapes keep to one or two keys)
         nkeys = (1 if log_n >= 13 else rng.choice([1, 2])) if big else rng.choice([1, 1, 2, 3])
         circuits, keys, ckeys = [], [], []
+
+        def coeffs(cols):     # columns of values -> coefficient form, by the CPU restatement's inverse NTT
+            flat = np.ascontiguousarray(cols, dtype=np.uint64).reshape(-1, n, 4)
+            return np.stack([cr.ntt_fr(c, log_n, True, False).reshape(-1, 4) for c in flat]).reshape(np.shape(cols))
+
+        key_coeffs, wire_coeffs = rng.random() < 0.5, rng.random() < 0.5
         for k in range(nkeys):
             ni = rng.randint(0, min(30, n // 2 - 1))
             sc = bu.synthetic_circuit(log_n, ni, seed=rng.randint(1, 10 ** 6))
             circuits.append(sc)
-            keys.append(cg.plonk_preprocess(srs, n, ni, sc.selectors_mont(), sc.sigma_mont())[0])
+            if key_coeffs:
+                keys.append(cg.plonk_preprocess(srs, n, ni, coeffs(sc.selectors_mont()), coeffs(sc.sigma_mont()),
+                                                input_form="coeffs")[0])
+            else:
+                keys.append(cg.plonk_preprocess(srs, n, ni, sc.selectors_mont(), sc.sigma_mont())[0])
             ckeys.append(cr.PlonkKey(srs_host, n, ni, sc.selectors_mont(), sc.sigma_mont()))
         P = BIG[r][1] if big else (rng.choice([1, 2, 3, 5, 8, 13, 40]) if log_n <= 10 else rng.randint(1, 4))
         order = [rng.randrange(nkeys) for _ in range(P)]
@@ -58,14 +70,21 @@ def run(rounds=30, seed=1, big=False, max_checked=None, log=print):
                 rc, comms, evals = ckeys[k].prove(sc.wires_mont(w), pm, bl, msg or None)
                 assert rc == 0
                 exp[i] = H.cref_proof_points(comms, evals)
-        got = cg.plonk_prove_multi([keys[k] for k in order], np.stack(wires), np.stack(rows), np.stack(blinds), msgs)
+        w_in = coeffs(np.stack(wires)) if wire_coeffs else np.stack(wires)
+        form = "coeffs" if wire_coeffs else "evals"
+        got = cg.plonk_prove_multi([keys[k] for k in order], w_in, np.stack(rows), np.stack(blinds), msgs, input_form=form)
         ok = all(H.proof_points(got[i]) == exp[i] for i in checked)
+        for _ in range(2):    # the second call captures the schedule of a small batch, the third replays it
+            again = cg.plonk_prove_multi([keys[k] for k in order], w_in, np.stack(rows), np.stack(blinds), msgs,
+                                         input_form=form)
+            ok = ok and [bytes(p) for p in again] == [bytes(p) for p in got]
         if nkeys == 1:
             pm = np.stack(rows)[:, :circuits[0].num_inputs]
             for i in range(P):        # the single-key entry point too (per-proof message)
                 one = cg.plonk_prove_batch(keys[0], wires[i][None], pm[i][None], blinds[i][None], msgs[i] or None, 1)[0]
                 ok = ok and bytes(one) == bytes(got[i])
-        log(f"round {r}: log_n={log_n} keys={nkeys} P={P} inputs={[c.num_inputs for c in circuits]} {'ok' if ok else 'MISMATCH'}")
+        log(f"round {r}: log_n={log_n} keys={nkeys} P={P} inputs={[c.num_inputs for c in circuits]} "
+            f"key_form={'coeffs' if key_coeffs else 'evals'} wire_form={form} {'ok' if ok else 'MISMATCH'}")
         bad += 0 if ok else 1
         for k in keys:
             cg.plonk_free_key(k)
