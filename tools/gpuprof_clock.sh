@@ -10,11 +10,37 @@ mkdir -p gpurun_out/clock_$tag
 for ctr in GRBM_GUI_ACTIVE GRBM_COUNT SQ_BUSY_CU_CYCLES SQ_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY; do
   timeout 240 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d gpurun_out/clock_$tag/$ctr -- python3 bench.py --one-context --steps 1 --warmup 1 --no-cpu-baseline --no-reference-schedule --no-msm --no-extras > /dev/null 2> gpurun_out/clock_$tag/$ctr.err
 done
+# the two counters of the busy share in ONE pass (the same dispatches, the same clock)
+timeout 240 rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_BUSY_CU_CYCLES --kernel-trace --output-format csv -d gpurun_out/clock_$tag/PAIR -- python3 bench.py --one-context --steps 1 --warmup 1 --no-cpu-baseline --no-reference-schedule --no-msm --no-extras > /dev/null 2> gpurun_out/clock_$tag/PAIR.err
 python3 - <<PY
 import csv, glob, collections, json
 out = {}
+def short(name):
+    return name.replace("(anonymous namespace)::", "").replace("void ", "").replace("cap::pk::", "").replace("cap::", "").split("(")[0]
+pd = "gpurun_out/clock_$tag/PAIR/"
+dur = {}
+for f in glob.glob(pd + "**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        dur[r["Dispatch_Id"]] = int(r["End_Timestamp"]) - int(r["Start_Timestamp"])
+pagg = collections.defaultdict(lambda: collections.defaultdict(float))
+for f in glob.glob(pd + "**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        t = dur.get(r["Dispatch_Id"])
+        if t is None or t < 200000:
+            continue
+        a = pagg[short(r["Kernel_Name"])]
+        a[r["Counter_Name"]] += float(r["Counter_Value"])
+        if r["Counter_Name"] == "GRBM_GUI_ACTIVE":
+            a["ns"] += t
+            a["launches"] += 1
+out["PAIR"] = {k: {"launches": int(v["launches"]), "GRBM_GUI_ACTIVE": v["GRBM_GUI_ACTIVE"], "SQ_BUSY_CU_CYCLES": v["SQ_BUSY_CU_CYCLES"],
+                   "GRBM_GUI_ACTIVE_per_ns": round(v["GRBM_GUI_ACTIVE"] / v["ns"], 4)}
+               for k, v in pagg.items() if v["ns"] and v["GRBM_GUI_ACTIVE"] and v["SQ_BUSY_CU_CYCLES"]}
+print("PAIR", {k[:24]: (round(v["GRBM_GUI_ACTIVE_per_ns"] / 8, 3), round(v["SQ_BUSY_CU_CYCLES"] / 256 / (v["GRBM_GUI_ACTIVE"] / 8), 3)) for k, v in list(out["PAIR"].items())[:12]})
 for d in sorted(glob.glob("gpurun_out/clock_$tag/*/")):
     ctr = d.rstrip("/").split("/")[-1]
+    if ctr == "PAIR":
+        continue
     dur = {}
     for f in glob.glob(d + "**/*kernel_trace.csv", recursive=True):
         for r in csv.DictReader(open(f)):

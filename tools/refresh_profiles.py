@@ -27,7 +27,7 @@ bm = one_line_json(os.path.join(src, "bench_mixed64.json"), os.path.join(dst, f"
 shutil.copy(os.path.join(src, "msm_single_profile.json"), os.path.join(dst, f"msm_single_profile_{rnd}.json"))
 for name, out_name in (("bench_single_process.json", f"bench_single_process_dev0x2_{rnd}.json"),
                        ("msm_deep_ab.jsonl", f"msm_deep_ab_{rnd}.jsonl"), ("two_ctx.json", f"two_contexts_ab_{rnd}.json"),
-                       ("clock.json", f"clock_{rnd}.json"), ("latency_ab.jsonl", f"latency_ab_final_{rnd}.jsonl")):
+                       ("latency_ab.jsonl", f"latency_ab_final_{rnd}.jsonl")):
     if os.path.exists(os.path.join(src, name)) and os.path.getsize(os.path.join(src, name)):
         shutil.copy(os.path.join(src, name), os.path.join(dst, out_name))
 shutil.copy(os.path.join(src, "traffic.json"), os.path.join(dst, f"traffic_{rnd}.json"))
@@ -38,6 +38,34 @@ os.makedirs(os.path.join(dst, "rocprof_" + rnd), exist_ok=True)
 shutil.copy(os.path.join(prof, "summary.txt"), os.path.join(dst, "rocprof_" + rnd, "summary.txt"))
 stats = glob.glob(os.path.join(prof, "trace", "**", "*kernel_stats.csv"), recursive=True)
 shutil.copy(stats[0], os.path.join(dst, "rocprof_" + rnd, "kernel_stats.csv"))
+
+# clock / busy-CU pass (tools/gpuprof_clock.sh): counter per nanosecond of the same dispatch -> clock and busy share.
+# "PAIR" (round 4): GRBM_GUI_ACTIVE and SQ_BUSY_CU_CYCLES collected in ONE pass, so that the busy share is a ratio of two
+# counters of the same dispatches (separate passes may run at different clocks: round 4's gave 1.04 for msm_accumulate).
+if os.path.exists(os.path.join(src, "clock.json")):
+    raw = json.load(open(os.path.join(src, "clock.json")))
+    pair = raw.get("PAIR", {})
+    derived = {}
+    for k, v in raw.get("GRBM_GUI_ACTIVE", {}).items():
+        ghz = v["counter_per_ns"] / 8.0                       # the counter sums over the 8 XCDs
+        e = {"clock_GHz": round(ghz, 3)}
+        if k in pair:
+            e = {"clock_GHz": round(pair[k]["GRBM_GUI_ACTIVE_per_ns"] / 8.0, 3),
+                 "cu_busy_frac": round(pair[k]["SQ_BUSY_CU_CYCLES"] / 256.0 / (pair[k]["GRBM_GUI_ACTIVE"] / 8.0), 3),
+                 "same_pass": True}
+        else:
+            bc = raw.get("SQ_BUSY_CU_CYCLES", {}).get(k)
+            if bc and ghz > 0:
+                e["cu_busy_frac"] = round(bc["counter_per_ns"] / 256.0 / ghz, 3)   # ... over the 256 CUs
+        derived[k] = e
+    json.dump({"source": "tools/gpuprof_clock.sh: rocprofv3 --pmc <counter(s)> --kernel-trace (no other trace domain) on "
+                         "bench.py --one-context --steps 1 --warmup 1 --no-msm --no-extras, batch 256; counter value / "
+                         "duration of the same dispatch, launches >= 0.2 ms only; entries marked same_pass come from the "
+                         "pass that collected GRBM_GUI_ACTIVE and SQ_BUSY_CU_CYCLES together",
+               "how_to_read": "GRBM_GUI_ACTIVE and GRBM_COUNT sum over the 8 XCDs: / 8 = clock in GHz.  SQ_BUSY_CU_CYCLES sums "
+                              "over 256 CUs: / 256 against GRBM_GUI_ACTIVE / 8 = fraction of the launch a CU is busy.",
+               "derived": derived, "raw_counter_per_ns": {k: v for k, v in raw.items() if k != "PAIR"}, "pair_pass": pair},
+              open(os.path.join(dst, f"clock_{rnd}.json"), "w"), indent=1)
 
 # instruction counters: tools/gpuprof_insts.sh prints  name {counter: (sum, launches), ...}  per kernel
 kern = {}
