@@ -1229,44 +1229,76 @@ __global__ __launch_bounds__(kThreads) void msm_reduce_grid(const g1_xyzz* __res
   if (q == 0) sums[g] = G1L::store(acc);
 }
 
-// One workgroup of two waves per entry: wave 0 takes the row sums (weights hi = 0 .. rows - 1), wave 1 the column sums
-// (weights lo + 1 = 1 .. cols); rows, cols <= 64.  Inclusive suffix scan over the lanes, then the wave sum of the
-// suffixes - from lane 1 on for the rows, from lane 0 on for the columns.  A chain of 6 + 6 additions, lo_bits doublings
-// and one addition; G1S: the row-wise multiplication schedule of the one-wave finishing kernels.
-__global__ __launch_bounds__(128) void msm_reduce_grid_final(const g1_xyzz* __restrict__ sums, uint32_t half,
+// One workgroup of four waves per entry: waves 0-1 take the row sums (weights hi = 0 .. rows - 1), waves 2-3 the column
+// sums (weights lo + 1 = 1 .. cols); rows, cols <= 128: lane l of the second wave of a pair holds term 64 + l.  Per wave:
+// inclusive suffix scan over the lanes, then the wave sum of the suffixes (from lane 1 on: sum_k k X_k over the wave's own
+// 64 terms; lane 0 of the scan is the wave's plain sum).  The high wave's terms weigh 64 more each:
+//   sum_{k < 128} k X_k = W_lo + W_hi + 64 S_hi.
+// A chain of 6 + 6 additions, then 6 doublings + 2 additions (pairs of waves), lo_bits doublings and one addition;
+// G1S: the row-wise multiplication schedule of the finishing kernels.
+__global__ __launch_bounds__(256) void msm_reduce_grid_final(const g1_xyzz* __restrict__ sums, uint32_t half,
                                                              uint32_t lo_bits, g1_jac* __restrict__ out,
                                                              g1_xyzz* __restrict__ out_part) {
-  __shared__ g1_xyzz row_part;
+  __shared__ g1_xyzz part[4][2];  // [wave][weighted sum, plain sum]
   const uint32_t cols = 1u << lo_bits, rows = half >> lo_bits;
   const uint32_t b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const g1_xyzz* sp = sums + (size_t)b * (rows + cols) + (wave ? rows : 0);
-  const uint32_t cnt = wave ? cols : rows;
-  g1x suf = lane < cnt ? G1S::load(sp[lane]) : G1S::inf();
-  for (int d = 1; d < 64; d <<= 1) {  // suf_l = X_l + X_{l+1} + ... (lanes beyond cnt hold infinity)
-    g1x o = shfl_down_pt(suf, d);
-    if (lane + d < 64) add_tree<G1S>(suf, o);
+  const bool is_col = wave >= 2;
+  const uint32_t cnt = is_col ? cols : rows;
+  const uint32_t k = (wave & 1) * 64 + lane;  // the term this lane holds
+  const g1_xyzz* sp = sums + (size_t)b * (rows + cols) + (is_col ? rows : 0);
+  g1x suf = k < cnt ? G1S::load(sp[k]) : G1S::inf();
+  // nothing to do for a wave whose terms do not exist (dimensions <= 64): its sums are infinity
+  const bool live = (wave & 1) * 64 < cnt;
+  g1x w = G1S::inf(), plain = G1S::inf();
+  if (live) {
+    for (int d = 1; d < 64; d <<= 1) {  // suf_l = X_l + X_{l+1} + ... within the wave (lanes beyond cnt hold infinity)
+      g1x o = shfl_down_pt(suf, d);
+      if (lane + d < 64) add_tree<G1S>(suf, o);
+    }
+    plain = suf;  // lane 0: the wave's plain sum
+    if (lane == 0) suf = G1S::inf();  // sum_{l >= 1} suf_l = sum_l l X_l
+    w = wave_sum<G1S>(suf);
   }
-  if (wave == 0 && lane == 0) suf = G1S::inf();  // rows: weight hi starts at 0, so the full sum (lane 0) is left out
-  g1x r = wave_sum<G1S>(suf);
-  if (wave == 0) {
-    for (uint32_t k = 0; k < lo_bits; k++)
-      if (!G1S::is_inf(r)) r = G1S::dbl(r);
-    if (lane == 0) row_part = G1S::store(r);
+  if (lane == 0) {
+    part[wave][0] = G1S::store(w);
+    part[wave][1] = G1S::store(plain);
   }
   __syncthreads();
-  if (wave == 1 && lane == 0) {
-    add_tree<G1S>(r, G1S::load(row_part));
+  const bool finisher = lane == 0 && !(wave & 1);  // lane 0 of waves 0 and 2 finish their dimension
+  if (finisher) {
+    g1x tot = G1S::load(part[wave][0]);
+    if (cnt > 64) {
+      g1x hi = G1S::load(part[wave + 1][1]);  // 64 * S_hi
+      for (int d = 0; d < 6; d++)
+        if (!G1S::is_inf(hi)) hi = G1S::dbl(hi);
+      add_tree<G1S>(tot, hi);
+      add_tree<G1S>(tot, G1S::load(part[wave + 1][0]));
+    }
+    if (is_col) {
+      // columns weigh lo + 1: one more plain sum of every column
+      add_tree<G1S>(tot, G1S::load(part[2][1]));
+      if (cnt > 64) add_tree<G1S>(tot, G1S::load(part[3][1]));
+    } else {
+      for (uint32_t d = 0; d < lo_bits; d++)
+        if (!G1S::is_inf(tot)) tot = G1S::dbl(tot);
+    }
+    part[wave][0] = G1S::store(tot);  // (read above by this lane only)
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    g1x r = G1S::load(part[0][0]);
+    add_tree<G1S>(r, G1S::load(part[2][0]));
     if (out_part) out_part[b] = G1S::store(r);
     else out[b] = G1S::to_jac_ext(r);
   }
 }
-// bucket sets the grid form takes: 2^k buckets, 2 <= k <= 12, both grid dimensions <= 64 (CAPGPU_MSM_GRID_REDUCE=0: off)
+// bucket sets the grid form takes: 2^k buckets, 2 <= k <= 14, both grid dimensions <= 128 (CAPGPU_MSM_GRID_REDUCE=0: off)
 bool use_grid_reduce(uint32_t half) {
   static const bool on = [] {
     const char* e = getenv("CAPGPU_MSM_GRID_REDUCE");
     return !e || atoi(e) != 0;
   }();
-  return on && half >= 4 && half <= 4096 && (half & (half - 1)) == 0;
+  return on && half >= 4 && half <= 16384 && (half & (half - 1)) == 0;
 }
 
 // out[b] = sum of the `parts` sub-MSM results of MSM b (one wavefront per MSM)
@@ -1532,6 +1564,11 @@ WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t sb, uint32_t
   {
     size_t chunks = kReduceMaxChunks;  // room for any choice of reduce_chunks
     size_t npart = use_segment_reduce((uint32_t)half, sb) ? 2 * nseg : c * chunks;
+    {  // the grid reduction's row and column sums (msm_reduce_grid): 2^ceil(k/2) + 2^floor(k/2) per entry
+      uint32_t k = 0;
+      while (((size_t)1 << k) < half) k++;
+      npart = std::max(npart, ((size_t)half >> (k / 2)) + ((size_t)1 << (k / 2)));
+    }
     L.buckets = o; o = align_up(o + sizeof(g1_xyzz) * half * sb, 256);
     L.partial = o; o = align_up(o + sizeof(g1_xyzz) * npart * sb, 256);
   }
@@ -1796,12 +1833,21 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
     // bucket sizes (a bucket with more items than lanes loops), so that the shuffle tree is no deeper than needed
     const size_t avg_items = (t.entries / total_buckets + item_len - 1) / item_len;
     const size_t want = avg_items * 3 / 2;
-    const uint32_t G = want <= 8 ? 8u : (want <= 16 ? 16u : (want <= 32 ? 32u : 64u));
-    auto kern = G == 8 ? msm_combine_wave<8>
-                       : (G == 16 ? msm_combine_wave<16> : (G == 32 ? msm_combine_wave<32> : msm_combine_wave<64>));
-    launch("msm_combine", kern, dim3((unsigned)(((size_t)total_buckets * G + kThreads - 1) / kThreads)), dim3(kThreads),
-           0, stream, (const g1_xyzz*)t.item_pts, (const uint32_t*)t.counts, (const uint32_t*)t.item_off,
-           (const uint32_t*)t.item_base, half, total_buckets, item_len, t.buckets);
+    if (avg_items <= 1 && total_buckets >= 65536) {
+      // buckets of (almost always) ONE item - a few dozen MSMs on the wide table: msm_accumulate wrote those buckets
+      // itself, and eight lanes per bucket would be five million idle threads (a 40-MSM launch: 300 us of them); one
+      // thread per bucket walks the rare second item
+      launch("msm_combine", msm_combine, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0, stream,
+             (const g1_xyzz*)t.item_pts, (const uint32_t*)t.counts, (const uint32_t*)t.item_off,
+             (const uint32_t*)t.item_base, half, total_buckets, item_len, t.buckets);
+    } else {
+      const uint32_t G = want <= 8 ? 8u : (want <= 16 ? 16u : (want <= 32 ? 32u : 64u));
+      auto kern = G == 8 ? msm_combine_wave<8>
+                         : (G == 16 ? msm_combine_wave<16> : (G == 32 ? msm_combine_wave<32> : msm_combine_wave<64>));
+      launch("msm_combine", kern, dim3((unsigned)(((size_t)total_buckets * G + kThreads - 1) / kThreads)),
+             dim3(kThreads), 0, stream, (const g1_xyzz*)t.item_pts, (const uint32_t*)t.counts,
+             (const uint32_t*)t.item_off, (const uint32_t*)t.item_base, half, total_buckets, item_len, t.buckets);
+    }
     if (!out_pair && use_grid_reduce(half)) {
       uint32_t k = 0;
       while ((1u << k) < half) k++;
@@ -1809,7 +1855,7 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
       launch("msm_reduce_grid", msm_reduce_grid,
              dim3((unsigned)(((size_t)sb * nsum * kGridSlices + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
              (const g1_xyzz*)t.buckets, half, lo_bits, sb, t.partial);
-      launch("msm_reduce_grid_final", msm_reduce_grid_final, dim3(sb), dim3(128), 0, stream, (const g1_xyzz*)t.partial,
+      launch("msm_reduce_grid_final", msm_reduce_grid_final, dim3(sb), dim3(256), 0, stream, (const g1_xyzz*)t.partial,
              half, lo_bits, out, out_part);
       return;
     }
