@@ -1236,12 +1236,17 @@ __global__ __launch_bounds__(kThreads) void msm_reduce_grid(const g1_xyzz* __res
 //   sum_{k < 128} k X_k = W_lo + W_hi + 64 S_hi.
 // A chain of 6 + 6 additions, then 6 doublings + 2 additions (pairs of waves), lo_bits doublings and one addition;
 // G1S: the row-wise multiplication schedule of the finishing kernels.
-__global__ __launch_bounds__(256) void msm_reduce_grid_final(const g1_xyzz* __restrict__ sums, uint32_t half,
-                                                             uint32_t lo_bits, g1_jac* __restrict__ out,
-                                                             g1_xyzz* __restrict__ out_part) {
+// BIG = false (both dimensions <= 64: the c = 13 table's 4096 buckets, a single proof's launches): two waves, one per
+// dimension, nothing of the pairing below is compiled in - 155 us per launch against 195 us with it.
+template <bool BIG>
+__global__ __launch_bounds__(BIG ? 256 : 128) void msm_reduce_grid_final(const g1_xyzz* __restrict__ sums, uint32_t half,
+                                                                         uint32_t lo_bits, g1_jac* __restrict__ out,
+                                                                         g1_xyzz* __restrict__ out_part) {
   __shared__ g1_xyzz part[4][2];  // [wave][weighted sum, plain sum]
   const uint32_t cols = 1u << lo_bits, rows = half >> lo_bits;
-  const uint32_t b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t b = blockIdx.x, lane = threadIdx.x & 63;
+  // waves 0, 1: rows (low, high terms), 2, 3: columns; without BIG the two waves of the workgroup are 0 and 2
+  const uint32_t wave = BIG ? threadIdx.x >> 6 : (threadIdx.x >> 6) * 2;
   const bool is_col = wave >= 2;
   const uint32_t cnt = is_col ? cols : rows;
   const uint32_t k = (wave & 1) * 64 + lane;  // the term this lane holds
@@ -1267,7 +1272,7 @@ __global__ __launch_bounds__(256) void msm_reduce_grid_final(const g1_xyzz* __re
   const bool finisher = lane == 0 && !(wave & 1);  // lane 0 of waves 0 and 2 finish their dimension
   if (finisher) {
     g1x tot = G1S::load(part[wave][0]);
-    if (cnt > 64) {
+    if (BIG && cnt > 64) {
       g1x hi = G1S::load(part[wave + 1][1]);  // 64 * S_hi
       for (int d = 0; d < 6; d++)
         if (!G1S::is_inf(hi)) hi = G1S::dbl(hi);
@@ -1277,7 +1282,7 @@ __global__ __launch_bounds__(256) void msm_reduce_grid_final(const g1_xyzz* __re
     if (is_col) {
       // columns weigh lo + 1: one more plain sum of every column
       add_tree<G1S>(tot, G1S::load(part[2][1]));
-      if (cnt > 64) add_tree<G1S>(tot, G1S::load(part[3][1]));
+      if (BIG && cnt > 64) add_tree<G1S>(tot, G1S::load(part[3][1]));
     } else {
       for (uint32_t d = 0; d < lo_bits; d++)
         if (!G1S::is_inf(tot)) tot = G1S::dbl(tot);
@@ -1345,6 +1350,18 @@ uint32_t small_max_batch() {
     const char* e = getenv("CAPGPU_MSM_SMALL_MAX");
     const int x = e ? atoi(e) : 8;
     return (uint32_t)(x >= 1 && x <= 64 ? x : 8);
+  }();
+  return v;
+}
+// Smallest launch, in (sub-)MSMs, that takes the wide table (CAPGPU_MSM_WIDE_MIN).  32 until round 4, when a launch of
+// 32 .. 63 MSMs reduced its 16384 buckets through bit planes (0.9 ms for 40 MSMs); with the grid form (0.65 ms) and one
+// combine thread per single-item bucket the wide table pays from about two dozen MSMs: one-context rates at batch 6 (30
+// MSMs per wire launch) 573 -> 627 proofs/s, batch 4 (20) 521 / 515, batch 2 (10) 358 -> 315 (tools/gpujob_widemin.sh).
+uint32_t wide_min_batch() {
+  static const uint32_t v = [] {
+    const char* e = getenv("CAPGPU_MSM_WIDE_MIN");
+    const int x = e ? atoi(e) : 24;
+    return (uint32_t)(x >= 1 && x <= 1024 ? x : 24);
   }();
   return v;
 }
@@ -1492,7 +1509,7 @@ Plan choose_plan(const MsmBases& bases, size_t n, uint32_t batch) {
   // running-sum additions per bucket instead of a log-depth tree, and (b) buckets still hold several entries
   if (bases.ext2 && n >= 4096) {
     uint32_t parts = n > kMaxSubPoints ? (uint32_t)((n + 65535) / 65536) : 1;
-    if ((size_t)batch * parts >= 32) {
+    if ((size_t)batch * parts >= wide_min_batch()) {
       const size_t n_sub = parts > 1 ? (size_t)65536 : n;
       pl = Plan{bases.c2, bases.windows2, pick_sub_bits(n_sub, bases.c2, bases.windows2), bases.ext2, parts, n_sub};
       return pl;
@@ -1855,8 +1872,12 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
       launch("msm_reduce_grid", msm_reduce_grid,
              dim3((unsigned)(((size_t)sb * nsum * kGridSlices + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
              (const g1_xyzz*)t.buckets, half, lo_bits, sb, t.partial);
-      launch("msm_reduce_grid_final", msm_reduce_grid_final, dim3(sb), dim3(256), 0, stream, (const g1_xyzz*)t.partial,
-             half, lo_bits, out, out_part);
+      if (half > 4096)
+        launch("msm_reduce_grid_final", msm_reduce_grid_final<true>, dim3(sb), dim3(256), 0, stream,
+               (const g1_xyzz*)t.partial, half, lo_bits, out, out_part);
+      else
+        launch("msm_reduce_grid_final", msm_reduce_grid_final<false>, dim3(sb), dim3(128), 0, stream,
+               (const g1_xyzz*)t.partial, half, lo_bits, out, out_part);
       return;
     }
     const uint32_t nplanes = t.planes + (out_pair ? 1u : 0u);
