@@ -1236,17 +1236,17 @@ __global__ __launch_bounds__(kThreads) void msm_reduce_grid(const g1_xyzz* __res
 //   sum_{k < 128} k X_k = W_lo + W_hi + 64 S_hi.
 // A chain of 6 + 6 additions, then 6 doublings + 2 additions (pairs of waves), lo_bits doublings and one addition;
 // G1S: the row-wise multiplication schedule of the finishing kernels.
-// BIG = false (both dimensions <= 64: the c = 13 table's 4096 buckets, a single proof's launches): two waves, one per
-// dimension, nothing of the pairing below is compiled in - 155 us per launch against 195 us with it.
-template <bool BIG>
-__global__ __launch_bounds__(BIG ? 256 : 128) void msm_reduce_grid_final(const g1_xyzz* __restrict__ sums, uint32_t half,
-                                                                         uint32_t lo_bits, g1_jac* __restrict__ out,
-                                                                         g1_xyzz* __restrict__ out_part) {
+// (the form for grids of up to 128 x 128: the wide table's 16384 buckets, launches of 24 .. 63 MSMs; grids of at most
+// 64 x 64 - a single proof's launches, where every microsecond of this chain is a microsecond of the proof - take
+// msm_reduce_grid_final_small below: one barrier instead of two, no pairing of waves: 155 against 180 us per launch)
+constexpr bool BIG = true;
+__global__ __launch_bounds__(256) void msm_reduce_grid_final(const g1_xyzz* __restrict__ sums, uint32_t half,
+                                                             uint32_t lo_bits, g1_jac* __restrict__ out,
+                                                             g1_xyzz* __restrict__ out_part) {
   __shared__ g1_xyzz part[4][2];  // [wave][weighted sum, plain sum]
   const uint32_t cols = 1u << lo_bits, rows = half >> lo_bits;
   const uint32_t b = blockIdx.x, lane = threadIdx.x & 63;
-  // waves 0, 1: rows (low, high terms), 2, 3: columns; without BIG the two waves of the workgroup are 0 and 2
-  const uint32_t wave = BIG ? threadIdx.x >> 6 : (threadIdx.x >> 6) * 2;
+  const uint32_t wave = threadIdx.x >> 6;  // waves 0, 1: rows (low, high terms), 2, 3: columns
   const bool is_col = wave >= 2;
   const uint32_t cnt = is_col ? cols : rows;
   const uint32_t k = (wave & 1) * 64 + lane;  // the term this lane holds
@@ -1293,6 +1293,37 @@ __global__ __launch_bounds__(BIG ? 256 : 128) void msm_reduce_grid_final(const g
   if (threadIdx.x == 0) {
     g1x r = G1S::load(part[0][0]);
     add_tree<G1S>(r, G1S::load(part[2][0]));
+    if (out_part) out_part[b] = G1S::store(r);
+    else out[b] = G1S::to_jac_ext(r);
+  }
+}
+// Grids of at most 64 x 64: one workgroup of two waves per entry - wave 0 takes the row sums (weights hi = 0 .. rows - 1),
+// wave 1 the column sums (weights lo + 1 = 1 .. cols).  Inclusive suffix scan over the lanes, then the wave sum of the
+// suffixes - from lane 1 on for the rows, from lane 0 on for the columns.  A chain of 6 + 6 additions, lo_bits
+// doublings and one addition.
+__global__ __launch_bounds__(128) void msm_reduce_grid_final_small(const g1_xyzz* __restrict__ sums, uint32_t half,
+                                                                   uint32_t lo_bits, g1_jac* __restrict__ out,
+                                                                   g1_xyzz* __restrict__ out_part) {
+  __shared__ g1_xyzz row_part;
+  const uint32_t cols = 1u << lo_bits, rows = half >> lo_bits;
+  const uint32_t b = blockIdx.x, wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const g1_xyzz* sp = sums + (size_t)b * (rows + cols) + (wave ? rows : 0);
+  const uint32_t cnt = wave ? cols : rows;
+  g1x suf = lane < cnt ? G1S::load(sp[lane]) : G1S::inf();
+  for (int d = 1; d < 64; d <<= 1) {  // suf_l = X_l + X_{l+1} + ... (lanes beyond cnt hold infinity)
+    g1x o = shfl_down_pt(suf, d);
+    if (lane + d < 64) add_tree<G1S>(suf, o);
+  }
+  if (wave == 0 && lane == 0) suf = G1S::inf();  // rows: weight hi starts at 0, so the full sum (lane 0) is left out
+  g1x r = wave_sum<G1S>(suf);
+  if (wave == 0) {
+    for (uint32_t k = 0; k < lo_bits; k++)
+      if (!G1S::is_inf(r)) r = G1S::dbl(r);
+    if (lane == 0) row_part = G1S::store(r);
+  }
+  __syncthreads();
+  if (wave == 1 && lane == 0) {
+    add_tree<G1S>(r, G1S::load(row_part));
     if (out_part) out_part[b] = G1S::store(r);
     else out[b] = G1S::to_jac_ext(r);
   }
@@ -1873,10 +1904,10 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
              dim3((unsigned)(((size_t)sb * nsum * kGridSlices + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
              (const g1_xyzz*)t.buckets, half, lo_bits, sb, t.partial);
       if (half > 4096)
-        launch("msm_reduce_grid_final", msm_reduce_grid_final<true>, dim3(sb), dim3(256), 0, stream,
+        launch("msm_reduce_grid_final", msm_reduce_grid_final, dim3(sb), dim3(256), 0, stream,
                (const g1_xyzz*)t.partial, half, lo_bits, out, out_part);
       else
-        launch("msm_reduce_grid_final", msm_reduce_grid_final<false>, dim3(sb), dim3(128), 0, stream,
+        launch("msm_reduce_grid_final", msm_reduce_grid_final_small, dim3(sb), dim3(128), 0, stream,
                (const g1_xyzz*)t.partial, half, lo_bits, out, out_part);
       return;
     }

@@ -13,7 +13,7 @@
 //    254 sequential doublings of the window combine (ruinous on a 64-lane SIMT
 //    machine where one field multiplication is ~1 us of latency) disappear;
 //  * two such tables: c = 13 for a single MSM (few buckets, log-depth reduction)
-//    and c = 15 for batches of >= 32 MSMs (17 instead of 20 mixed additions per
+//    and c = 15 for batches of >= 24 MSMs (17 instead of 20 mixed additions per
 //    254-bit scalar; the 4x larger bucket set costs two running-sum additions per
 //    bucket because the batch alone fills the chip);
 //  * signed digits halve the bucket count (2^(c-1) buckets);
