@@ -178,12 +178,13 @@ int run_segment(Context& c, ProveGraphSet* g, int id, F&& enqueue) {
     g->broken = true;
     return enqueue();
   }
+  const LaunchError before = launch_error();  // an error latched by an earlier segment of this call must survive the attempt
   c.capturing = true;
   int rc = enqueue();
   c.capturing = false;
   hipGraph_t graph = nullptr;
   hipError_t e = hipStreamEndCapture(s, &graph);
-  if (rc == CAPGPU_OK && e == hipSuccess && graph && launch_error().code == hipSuccess) {
+  if (rc == CAPGPU_OK && e == hipSuccess && graph && launch_error().code == before.code) {
     hipGraphExec_t ex = nullptr;
     e = hipGraphInstantiate(&ex, graph, nullptr, nullptr, 0);
     (void)hipGraphDestroy(graph);
@@ -198,7 +199,7 @@ int run_segment(Context& c, ProveGraphSet* g, int id, F&& enqueue) {
   }
   // nothing of the captured attempt has run: abandon graphs for this signature and enqueue the segment directly
   (void)hipGetLastError();
-  launch_error() = LaunchError{};
+  launch_error() = before;
   g->broken = true;
   return enqueue();
 }
@@ -497,7 +498,8 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   // small batches replay their kernel segments as hipGraphs (see ProveGraphSet)
   const uint32_t chunks = h_wires ? h2d_chunks(P) : 1;
   ProveGraphSet* gs = nullptr;
-  if (P <= graph_max_batch() && chunks == 1 && !c.prof.on && comm_shard_slot() < 0) {
+  // (only on the library's own stream: a caller's stream - capgpu_set_stream - may carry work of its own)
+  if (P <= graph_max_batch() && chunks == 1 && !c.prof.on && comm_shard_slot() < 0 && s == c.own_stream) {
     ProveGraphSig sig;
     sig.key_uid = K.uid;
     sig.srs = K.srs_handle;
