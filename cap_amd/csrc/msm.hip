@@ -1203,39 +1203,40 @@ __global__ __launch_bounds__(256) void msm_reduce_bits_final(const g1_xyzz* __re
 // the factor 2^lo_bits costs lo_bits = 6 doublings.  A single proof's four MSM launches (1, 2 and 5 MSMs of 4096 buckets):
 // see DESIGN.md round-4 log for the measured times.
 // grid: (ceil(sb * 2 * (R_hi + R_lo)... one thread per (entry, sum, slice)
-constexpr uint32_t kGridSlices = 8;  // lanes per row / column sum (each adds dim / 8 buckets serially, then a 3-level tree)
+// Lanes per row / column sum: each adds dim / slices buckets serially, then a log2(slices)-level tree folds them - a chain
+// of dim / slices + log2(slices) dependent additions.  A launch of a few MSMs has lanes to spare, so it takes as many
+// slices as keep the launch within one wave per SIMD (65536 lanes): 64 for a single proof's launches - 6 tree levels
+// instead of 8 + 3 additions, 93 -> ~55 us per launch; the 128 x 128 grids of 24 .. 63 MSMs stay at 8.
+uint32_t grid_slices(uint32_t sb, uint32_t nsum, uint32_t dim) {
+  uint32_t sl = 8;
+  while (sl < 64 && sl * 2 <= dim && (uint64_t)sb * nsum * (sl * 2) <= 65536) sl *= 2;
+  return sl;
+}
 __global__ __launch_bounds__(kThreads) void msm_reduce_grid(const g1_xyzz* __restrict__ buckets, uint32_t half,
-                                                            uint32_t lo_bits, uint32_t sb,
+                                                            uint32_t lo_bits, uint32_t sb, uint32_t slices,
                                                             g1_xyzz* __restrict__ sums /* [sb][rows + cols] */) {
   const uint32_t cols = 1u << lo_bits, rows = half >> lo_bits, nsum = rows + cols;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t g = t / kGridSlices, q = t % kGridSlices;  // g: (entry, sum); whole groups leave together
+  const uint32_t g = t / slices, q = t % slices;  // g: (entry, sum); whole groups leave together (slices divides 64)
   if (g >= sb * nsum) return;
   const uint32_t b = g / nsum, sidx = g - b * nsum;
   const g1_xyzz* bk = buckets + (size_t)b * half;
   g1x acc = G1L::inf();
   if (sidx < rows) {  // row sum R_hi: buckets hi * cols + lo, lo in this lane's slice (consecutive 128-byte entries)
-    const uint32_t per = (cols + kGridSlices - 1) / kGridSlices, l0 = q * per;
+    const uint32_t per = (cols + slices - 1) / slices, l0 = q * per;
     for (uint32_t l = l0; l < l0 + per && l < cols; l++) add_tree<G1L>(acc, G1L::load(bk[(size_t)sidx * cols + l]));
   } else {  // column sum C_lo: buckets hi * cols + lo, hi in this lane's slice
     const uint32_t lo = sidx - rows;
-    const uint32_t per = (rows + kGridSlices - 1) / kGridSlices, h0 = q * per;
+    const uint32_t per = (rows + slices - 1) / slices, h0 = q * per;
     for (uint32_t h = h0; h < h0 + per && h < rows; h++) add_tree<G1L>(acc, G1L::load(bk[(size_t)h * cols + lo]));
   }
-  for (int d = kGridSlices / 2; d >= 1; d >>= 1) {
-    g1x o = shfl_down_pt(acc, d);
-    if (q < (uint32_t)d) add_tree<G1L>(acc, o);
+  for (uint32_t d = slices / 2; d >= 1; d >>= 1) {
+    g1x o = shfl_down_pt(acc, (int)d);
+    if (q < d) add_tree<G1L>(acc, o);
   }
   if (q == 0) sums[g] = G1L::store(acc);
 }
 
-// One workgroup of four waves per entry: waves 0-1 take the row sums (weights hi = 0 .. rows - 1), waves 2-3 the column
-// sums (weights lo + 1 = 1 .. cols); rows, cols <= 128: lane l of the second wave of a pair holds term 64 + l.  Per wave:
-// inclusive suffix scan over the lanes, then the wave sum of the suffixes (from lane 1 on: sum_k k X_k over the wave's own
-// 64 terms; lane 0 of the scan is the wave's plain sum).  The high wave's terms weigh 64 more each:
-//   sum_{k < 128} k X_k = W_lo + W_hi + 64 S_hi.
-// A chain of 6 + 6 additions, then 6 doublings + 2 additions (pairs of waves), lo_bits doublings and one addition;
-// G1S: the row-wise multiplication schedule of the finishing kernels.
 // (the form for grids of up to 128 x 128: the wide table's 16384 buckets, launches of 24 .. 63 MSMs; grids of at most
 // 64 x 64 - a single proof's launches, where every microsecond of this chain is a microsecond of the proof - take
 // msm_reduce_grid_final_small below: one barrier instead of two, no pairing of waves: 155 against 180 us per launch)
@@ -1900,9 +1901,10 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
       uint32_t k = 0;
       while ((1u << k) < half) k++;
       const uint32_t lo_bits = k / 2, nsum = (half >> lo_bits) + (1u << lo_bits);
+      const uint32_t slices = grid_slices(sb, nsum, std::min(half >> lo_bits, 1u << lo_bits));
       launch("msm_reduce_grid", msm_reduce_grid,
-             dim3((unsigned)(((size_t)sb * nsum * kGridSlices + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
-             (const g1_xyzz*)t.buckets, half, lo_bits, sb, t.partial);
+             dim3((unsigned)(((size_t)sb * nsum * slices + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
+             (const g1_xyzz*)t.buckets, half, lo_bits, sb, slices, t.partial);
       if (half > 4096)
         launch("msm_reduce_grid_final", msm_reduce_grid_final, dim3(sb), dim3(256), 0, stream,
                (const g1_xyzz*)t.partial, half, lo_bits, out, out_part);
