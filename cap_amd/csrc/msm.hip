@@ -1230,9 +1230,13 @@ __global__ __launch_bounds__(kThreads) void msm_reduce_grid(const g1_xyzz* __res
     const uint32_t per = (rows + slices - 1) / slices, h0 = q * per;
     for (uint32_t h = h0; h < h0 + per && h < rows; h++) add_tree<G1L>(acc, G1L::load(bk[(size_t)h * cols + lo]));
   }
-  for (uint32_t d = slices / 2; d >= 1; d >>= 1) {
-    g1x o = shfl_down_pt(acc, (int)d);
-    if (q < d) add_tree<G1L>(acc, o);
+  // (compile-time shuffle distances - a run-time distance turns the 36 shuffles of a level into LDS-routed permutes -
+  // behind a uniform test of the run-time slice count)
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    if ((uint32_t)d >= slices) continue;
+    g1x o = shfl_down_pt(acc, d);
+    if (q < (uint32_t)d) add_tree<G1L>(acc, o);
   }
   if (q == 0) sums[g] = G1L::store(acc);
 }
