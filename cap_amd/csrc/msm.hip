@@ -1203,13 +1203,18 @@ __global__ __launch_bounds__(256) void msm_reduce_bits_final(const g1_xyzz* __re
 // the factor 2^lo_bits costs lo_bits = 6 doublings.  A single proof's four MSM launches (1, 2 and 5 MSMs of 4096 buckets):
 // see DESIGN.md round-4 log for the measured times.
 // grid: (ceil(sb * 2 * (R_hi + R_lo)... one thread per (entry, sum, slice)
-// Lanes per row / column sum: each adds dim / slices buckets serially, then a log2(slices)-level tree folds them - a chain
-// of dim / slices + log2(slices) dependent additions.  A launch of a few MSMs has lanes to spare, so it takes as many
-// slices as keep the launch within one wave per SIMD (65536 lanes): 64 for a single proof's launches - 6 tree levels
-// instead of 8 + 3 additions, 93 -> ~55 us per launch; the 128 x 128 grids of 24 .. 63 MSMs stay at 8.
+// Lanes per row / column sum: each adds dim / slices buckets serially, then a log2(slices)-level tree folds them.  More
+// slices for launches with lanes to spare - 64 for a single proof's launches: 6 tree levels instead of 8 + 3 additions -
+// were measured in round 4 and are no gain (single proof 3.33 -> 3.36-3.41 ms, batches of 2 and 4 within noise): a tree
+// level costs what a serial addition costs, plus its 36 shuffles.  CAPGPU_MSM_GRID_SLICES=64 brings them back.
 uint32_t grid_slices(uint32_t sb, uint32_t nsum, uint32_t dim) {
+  static const uint32_t cap = [] {
+    const char* e = getenv("CAPGPU_MSM_GRID_SLICES");
+    const int x = e ? atoi(e) : 8;
+    return (uint32_t)(x == 16 || x == 32 || x == 64 ? x : 8);
+  }();
   uint32_t sl = 8;
-  while (sl < 64 && sl * 2 <= dim && (uint64_t)sb * nsum * (sl * 2) <= 65536) sl *= 2;
+  while (sl < cap && sl * 2 <= dim && (uint64_t)sb * nsum * (sl * 2) <= 65536) sl *= 2;
   return sl;
 }
 __global__ __launch_bounds__(kThreads) void msm_reduce_grid(const g1_xyzz* __restrict__ buckets, uint32_t half,
