@@ -1217,8 +1217,9 @@ uint32_t grid_slices(uint32_t sb, uint32_t nsum, uint32_t dim) {
   while (sl < cap && sl * 2 <= dim && (uint64_t)sb * nsum * (sl * 2) <= 65536) sl *= 2;
   return sl;
 }
+template <uint32_t slices>  // compile-time: the tree's shuffle distances must be constants (DPP, not LDS-routed permutes)
 __global__ __launch_bounds__(kThreads) void msm_reduce_grid(const g1_xyzz* __restrict__ buckets, uint32_t half,
-                                                            uint32_t lo_bits, uint32_t sb, uint32_t slices,
+                                                            uint32_t lo_bits, uint32_t sb,
                                                             g1_xyzz* __restrict__ sums /* [sb][rows + cols] */) {
   const uint32_t cols = 1u << lo_bits, rows = half >> lo_bits, nsum = rows + cols;
   const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
@@ -1235,11 +1236,8 @@ __global__ __launch_bounds__(kThreads) void msm_reduce_grid(const g1_xyzz* __res
     const uint32_t per = (rows + slices - 1) / slices, h0 = q * per;
     for (uint32_t h = h0; h < h0 + per && h < rows; h++) add_tree<G1L>(acc, G1L::load(bk[(size_t)h * cols + lo]));
   }
-  // (compile-time shuffle distances - a run-time distance turns the 36 shuffles of a level into LDS-routed permutes -
-  // behind a uniform test of the run-time slice count)
 #pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) {
-    if ((uint32_t)d >= slices) continue;
+  for (int d = (int)slices / 2; d >= 1; d >>= 1) {
     g1x o = shfl_down_pt(acc, d);
     if (q < (uint32_t)d) add_tree<G1L>(acc, o);
   }
@@ -1911,9 +1909,9 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
       while ((1u << k) < half) k++;
       const uint32_t lo_bits = k / 2, nsum = (half >> lo_bits) + (1u << lo_bits);
       const uint32_t slices = grid_slices(sb, nsum, std::min(half >> lo_bits, 1u << lo_bits));
-      launch("msm_reduce_grid", msm_reduce_grid,
-             dim3((unsigned)(((size_t)sb * nsum * slices + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
-             (const g1_xyzz*)t.buckets, half, lo_bits, sb, slices, t.partial);
+      auto gk = slices == 64 ? msm_reduce_grid<64> : (slices == 32 ? msm_reduce_grid<32> : (slices == 16 ? msm_reduce_grid<16> : msm_reduce_grid<8>));
+      launch("msm_reduce_grid", gk, dim3((unsigned)(((size_t)sb * nsum * slices + kThreads - 1) / kThreads)),
+             dim3(kThreads), 0, stream, (const g1_xyzz*)t.buckets, half, lo_bits, sb, t.partial);
       if (half > 4096)
         launch("msm_reduce_grid_final", msm_reduce_grid_final, dim3(sb), dim3(256), 0, stream,
                (const g1_xyzz*)t.partial, half, lo_bits, out, out_part);
