@@ -1217,7 +1217,7 @@ uint32_t grid_slices(uint32_t sb, uint32_t nsum, uint32_t dim) {
   while (sl < cap && sl * 2 <= dim && (uint64_t)sb * nsum * (sl * 2) <= 65536) sl *= 2;
   return sl;
 }
-template <uint32_t slices>  // compile-time: the tree's shuffle distances must be constants (DPP, not LDS-routed permutes)
+template <uint32_t slices>
 __global__ __launch_bounds__(kThreads) void msm_reduce_grid(const g1_xyzz* __restrict__ buckets, uint32_t half,
                                                             uint32_t lo_bits, uint32_t sb,
                                                             g1_xyzz* __restrict__ sums /* [sb][rows + cols] */) {
@@ -1236,7 +1236,6 @@ __global__ __launch_bounds__(kThreads) void msm_reduce_grid(const g1_xyzz* __res
     const uint32_t per = (rows + slices - 1) / slices, h0 = q * per;
     for (uint32_t h = h0; h < h0 + per && h < rows; h++) add_tree<G1L>(acc, G1L::load(bk[(size_t)h * cols + lo]));
   }
-#pragma unroll
   for (int d = (int)slices / 2; d >= 1; d >>= 1) {
     g1x o = shfl_down_pt(acc, d);
     if (q < (uint32_t)d) add_tree<G1L>(acc, o);
