@@ -827,7 +827,10 @@ __global__ __launch_bounds__(1024) void msm_item_bases(const uint32_t* __restric
     if (threadIdx.x == 1023) carry_s = carry + sh[1023];
     __syncthreads();
   }
-  if (threadIdx.x == 0) item_base[batch] = carry_s;
+  if (threadIdx.x == 0) {
+    item_base[batch] = carry_s;
+    item_base[batch + 1] = 0;  // chunk counter of a dynamic msm_accumulate launch
+  }
 }
 
 // Work items of one batch entry, ordered by length (longest first): slot -> (bucket, sub-item).  Bucket sizes are
@@ -920,10 +923,27 @@ __global__ __launch_bounds__(kThreads) CAP_ACC_ATTR void msm_accumulate(const g1
                                                            const uint32_t* __restrict__ item_bucket,
                                                            const uint32_t* __restrict__ item_sub, size_t per,
                                                            uint32_t half, uint32_t batch, uint32_t item_len,
-                                                           g1_xyzz* __restrict__ item_pts,
+                                                           uint32_t dynamic, g1_xyzz* __restrict__ item_pts,
                                                            g1_xyzz* __restrict__ buckets) {
-  uint32_t it = blockIdx.x * blockDim.x + threadIdx.x;
-  if (it >= item_base[batch]) return;
+  // Grid-stride over the items: with a grid of a few workgroups per CU (accumulate_persistent) a workgroup walks chunk
+  // b, b + G, b + 2G, ... itself instead of being dispatched once per chunk.  G is a multiple of 8, so a chunk stays on the
+  // XCD the one-shot launch would put it on.
+  const uint32_t n_items = item_base[batch];
+  __shared__ uint32_t chunk_s;
+  for (uint32_t round = 0;; round++) {
+    uint32_t it;
+    if (dynamic) {  // the next chunk of 256 items from a counter: a workgroup that finishes early takes more
+      if (threadIdx.x == 0) chunk_s = atomicAdd(const_cast<uint32_t*>(item_base) + batch + 1, 1u);
+      __syncthreads();
+      const uint32_t chunk = chunk_s;
+      __syncthreads();
+      if ((uint64_t)chunk * blockDim.x >= n_items) break;
+      it = chunk * blockDim.x + threadIdx.x;
+    } else {
+      it = (blockIdx.x + round * gridDim.x) * blockDim.x + threadIdx.x;
+      if ((uint64_t)(blockIdx.x + round * gridDim.x) * blockDim.x >= n_items) break;
+    }
+    if (it >= n_items) continue;
   const uint32_t gb = item_bucket[it], j = item_sub[it];
   const uint32_t b = gb / half;
   const uint32_t cnt = counts[gb];
@@ -946,6 +966,7 @@ __global__ __launch_bounds__(kThreads) CAP_ACC_ATTR void msm_accumulate(const g1
   // a bucket made of a single item is final: it goes straight to the bucket array and msm_combine skips it
   if (items == 1) buckets[gb] = G1L::store(acc);
   else item_pts[item_base[b] + item_off[gb] + j] = G1L::store(acc);
+  }
 }
 
 // ---- K6: bucket reduction by running sums ------------------------------------------------------------------
@@ -1629,7 +1650,7 @@ WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t sb, uint32_t
   }
   L.max_items = per * sb / choose_item_len(per * sb, half * sb) + half * sb;  // sum ceil(cnt/L) <= entries/L + buckets
   L.item_off = o;    o = align_up(o + sizeof(uint32_t) * half * sb, 256);
-  L.item_base = o;   o = align_up(o + sizeof(uint32_t) * ((size_t)sb + 1), 256);
+  L.item_base = o;   o = align_up(o + sizeof(uint32_t) * ((size_t)sb + 2), 256);
   L.totals = o;      o = align_up(o + sizeof(uint32_t) * sb, 256);
   L.item_bucket = o; o = align_up(o + sizeof(uint32_t) * L.max_items, 256);
   L.item_sub = o;    o = align_up(o + sizeof(uint32_t) * L.max_items, 256);
@@ -1685,7 +1706,7 @@ DeepLayout deep_layout(const Plan& pl, size_t n) {
   L.partial = take(sizeof(g1_xyzz) * (size_t)L.sbp * 2 * (kDeepEntryBuckets / kDeepSegLen));  // (S, T) per segment
   L.pairs = take(sizeof(g1_xyzz) * 2 * (nb / kDeepReduceBuckets));
   L.item_off = take(4 * nb);
-  L.item_base = take(4 * ((size_t)L.sbp + 1));
+  L.item_base = take(4 * ((size_t)L.sbp + 2));
   L.totals = take(4 * (size_t)L.sbp);
   L.item_bucket = take(4 * L.max_items);
   L.item_sub = take(4 * L.max_items);
@@ -1832,6 +1853,30 @@ size_t accumulate_lds_bytes() {
   const long x = e ? atol(e) : 0;
   return (size_t)(x >= 0 && x <= 65536 ? x : 0);
 }
+// msm_accumulate as a PERSISTENT launch (round 4): k workgroups per CU (CAPGPU_ACC_PERSISTENT, default 4; 0 = one
+// workgroup per chunk of 256 items) that take chunk after chunk from an atomic counter (CAPGPU_ACC_DYNAMIC, default 1;
+// 0 = a fixed stride).  The one-shot launch of a batch is ~12 000 workgroups of equal duration - their items are
+// length-sorted - so the three workgroups a CU holds start together, end together, and the CU idles while the next
+// three are dispatched: SQ_BUSY_CU_CYCLES said a CU was busy 0.95 of the launch (round 3: "not occupancy, not the tail").
+// Measured, same box, batch 256 (tools/gpujob_accpersist.sh): one-shot 114.2 ms per step; persistent + counter, k = 3 / 4 /
+// 6: 109.7 / 109.3 / 109.3 ms (-4.3 %, 1303 -> 1346 proofs/s on one context); persistent with a FIXED stride: 149.7 ms -
+// without the counter a workgroup cannot make up for a slower CU, and a stride of whole MSMs (64 chunks each) would
+// even hand it the same position of every MSM's length-sorted list (183 ms).
+unsigned accumulate_persistent() {
+  static const unsigned v = [] {
+    const char* e = getenv("CAPGPU_ACC_PERSISTENT");
+    const long x = e ? atol(e) : 4;
+    return (unsigned)(x >= 1 && x <= 64 ? x : 0);
+  }();
+  return v;
+}
+bool accumulate_dynamic() {
+  static const bool v = [] {
+    const char* e = getenv("CAPGPU_ACC_DYNAMIC");
+    return accumulate_persistent() != 0 && (!e || atoi(e) != 0);
+  }();
+  return v;
+}
 // Workgroup size of msm_accumulate (experiments: CAPGPU_ACC_THREADS = 64, 128 or 256)
 unsigned accumulate_threads() {
   static const unsigned v = [] {
@@ -1868,10 +1913,20 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
          (const uint32_t*)t.item_base, half, item_len, t.item_bucket, t.item_sub);
   if (t.max_items > 0) {
     const unsigned at = accumulate_threads();
-    launch("msm_accumulate", msm_accumulate, dim3((unsigned)((t.max_items + at - 1) / at)), dim3(at),
+    unsigned wgs = (unsigned)((t.max_items + at - 1) / at);
+    // (256 CUs; + 8: a multiple of 8 that is NOT a whole number of MSMs - an MSM is 64 chunks of length-sorted items, and a
+    // stride of whole MSMs would hand a workgroup the same position, the longest or the shortest items, every time)
+    bool dynamic = false;
+    if (const unsigned per_cu = accumulate_persistent()) {
+      if (wgs > 256u * per_cu + 8u) {  // (a launch that fits the chip at once stays one-shot: nothing to re-dispatch)
+        wgs = 256u * per_cu + 8u;
+        dynamic = accumulate_dynamic();
+      }
+    }
+    launch("msm_accumulate", msm_accumulate, dim3(wgs), dim3(at),
            accumulate_lds_bytes(), stream, t.ext, (const uint32_t*)t.sorted, (const uint32_t*)t.counts, (const uint32_t*)t.offsets,
            (const uint32_t*)t.item_off, (const uint32_t*)t.item_base, (const uint32_t*)t.item_bucket,
-           (const uint32_t*)t.item_sub, t.per, half, sb, item_len, t.item_pts, t.buckets);
+           (const uint32_t*)t.item_sub, t.per, half, sb, item_len, dynamic ? 1u : 0u, t.item_pts, t.buckets);
   }
   if (segments) {
     launch("msm_combine", msm_combine, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0, stream,
