@@ -1586,6 +1586,36 @@ uint32_t reduce_seg_len(uint32_t half) {
   if (half >= 16384) return 64;  // wide windows: 256 segments per entry keep msm_reduce_final at 4 segments per lane
   return half >= 1024 ? 16u : (half >= 64 ? half / 64 : 1u);
 }
+// ... sized to the launch (round 4).  Every msm_reduce_segments thread does the same work - 2 * seg_len dependent
+// additions - and the kernel holds two waves per SIMD (226 VGPRs): 131072 threads at a time.  A launch of 1280 MSMs with
+// 256 segments each is 2.5 such rounds, i.e. three, the last one half empty; 256 MSMs are half a round that costs a whole
+// one.  So the segment length is chosen per launch: the one that minimises rounds * 2 * seg_len plus the one-wave finish
+// (3 additions per segment a lane owns), between 32 and 128 buckets.  1280 MSMs: 82 (200 segments, two rounds); 256: 32;
+// 512: 64.  CAPGPU_MSM_SEG_TUNE=0: always 64.
+constexpr uint32_t kSegLenMin = 32, kSegLenMax = 128;
+uint32_t reduce_seg_len_for(uint32_t half, uint32_t sb) {
+  static const bool tune = [] {
+    const char* e = getenv("CAPGPU_MSM_SEG_TUNE");
+    return !e || atoi(e) != 0;
+  }();
+  const uint32_t base = reduce_seg_len(half);
+  if (!tune || half < 16384 || sb == 0) return base;
+  const uint64_t slots = 2ull * 1024 * 64;  // threads of msm_reduce_segments the chip holds at once
+  uint32_t best = base;
+  uint64_t best_cost = ~0ull;
+  for (uint32_t sl = kSegLenMin; sl <= kSegLenMax; sl += 2) {
+    const uint64_t nseg = (half + sl - 1) / sl;
+    const uint64_t rounds = (nseg * sb + slots - 1) / slots;
+    const uint64_t q = (nseg + 63) / 64;
+    const uint64_t final_rounds = ((uint64_t)sb + 1023) / 1024;  // msm_reduce_final: one wave per entry, one per SIMD
+    const uint64_t cost = rounds * 2 * sl + final_rounds * (3 * q + 25);
+    if (cost < best_cost) {
+      best_cost = cost;
+      best = sl;
+    }
+  }
+  return best;
+}
 // the running-sum reduction wants >= 16 Ki independent segments (64 waves per XCD); below that the log-depth path
 bool use_segment_reduce(uint32_t half, uint32_t batch) {
   uint32_t seg_len = reduce_seg_len(half);
@@ -1631,8 +1661,8 @@ WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t sb, uint32_t
   const size_t bins = ((size_t)1 << (c - 1)) >> sub_bits;  // sort keys of the tile-local level
   size_t half = (size_t)1 << (c - 1);
   size_t per = (size_t)windows * n;
-  size_t seg_len = reduce_seg_len((uint32_t)half);
-  size_t nseg = (half + seg_len - 1) / seg_len;
+  size_t seg_len = std::min<size_t>(reduce_seg_len((uint32_t)half), half >= 16384 ? kSegLenMin : ~(size_t)0);
+  size_t nseg = (half + seg_len - 1) / seg_len;  // (the most segments reduce_seg_len_for may choose: room in `partial`)
   size_t o = 0;
   L.counts = o;  o = align_up(o + sizeof(uint32_t) * half * sb, 256);
   L.offsets = o; o = align_up(o + sizeof(uint32_t) * half * sb, 256);
@@ -1903,7 +1933,7 @@ struct Tail {
 };
 void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, hipStream_t stream) {
   const uint32_t half = t.half, sb = t.sb, item_len = t.item_len;
-  const uint32_t seg_len = t.seg_len ? t.seg_len : reduce_seg_len(half);
+  const uint32_t seg_len = t.seg_len ? t.seg_len : reduce_seg_len_for(half, sb);
   const bool segments = t.seg_len != 0 || use_segment_reduce(half, sb);
   const uint32_t total_buckets = half * sb;
   launch("msm_scan_items", msm_scan<1>, dim3(sb), dim3(1024), 0, stream, (const uint32_t*)t.counts, t.item_off, half,
