@@ -1586,17 +1586,17 @@ uint32_t reduce_seg_len(uint32_t half) {
   if (half >= 16384) return 64;  // wide windows: 256 segments per entry keep msm_reduce_final at 4 segments per lane
   return half >= 1024 ? 16u : (half >= 64 ? half / 64 : 1u);
 }
-// ... sized to the launch (round 4).  Every msm_reduce_segments thread does the same work - 2 * seg_len dependent
-// additions - and the kernel holds two waves per SIMD (226 VGPRs): 131072 threads at a time.  A launch of 1280 MSMs with
-// 256 segments each is 2.5 such rounds, i.e. three, the last one half empty; 256 MSMs are half a round that costs a whole
-// one.  So the segment length is chosen per launch: the one that minimises rounds * 2 * seg_len plus the one-wave finish
-// (3 additions per segment a lane owns), between 32 and 128 buckets.  1280 MSMs: 82 (200 segments, two rounds); 256: 32;
-// 512: 64.  CAPGPU_MSM_SEG_TUNE=0: always 64.
+// ... sized to the launch (round-4 experiment, CAPGPU_MSM_SEG_TUNE=1; off by default).  Every msm_reduce_segments thread
+// does the same work - 2 * seg_len dependent additions - and the kernel holds two waves per SIMD (226 VGPRs): 131072
+// threads at a time; a launch of 1280 MSMs with 256 segments each is 2.5 such "rounds".  Choosing the segment length that
+// minimises rounds * 2 * seg_len plus the one-wave finish (1280 MSMs: 82 buckets, 200 segments; 256 MSMs: 32) was
+// measured and is no gain: msm_reduce_segments 9.33 -> 9.45 ms per step, msm_reduce_final 1.50 -> 1.65 ms
+// (tools/gpujob_segtune.sh) - the chip does not run this kernel in lock-step rounds.
 constexpr uint32_t kSegLenMin = 32, kSegLenMax = 128;
 uint32_t reduce_seg_len_for(uint32_t half, uint32_t sb) {
   static const bool tune = [] {
     const char* e = getenv("CAPGPU_MSM_SEG_TUNE");
-    return !e || atoi(e) != 0;
+    return e && atoi(e) != 0;
   }();
   const uint32_t base = reduce_seg_len(half);
   if (!tune || half < 16384 || sb == 0) return base;
