@@ -76,7 +76,29 @@ struct PassParams {
   uint32_t log_c;            // tile width
   uint32_t log_m;            // col pass: segment size
   uint32_t log_n1, log_n2;   // row pass: digit sizes of the leading digits
+  // persistent launch: tiles_x * tiles_y tiles are handed out by *tile_counter to a fixed number of workgroups (null:
+  // one workgroup per tile, blockIdx = tile)
+  uint32_t* tile_counter;
+  uint32_t tiles_x, tiles_y;
 };
+
+// the tile a workgroup works on next: (blockIdx.x, blockIdx.y) once, or the next one from the counter; false: none left
+__device__ __forceinline__ bool next_tile(const PassParams& p, uint32_t round, uint32_t& bx, uint32_t& by) {
+  if (!p.tile_counter) {
+    bx = blockIdx.x;
+    by = blockIdx.y;
+    return round == 0;
+  }
+  __shared__ uint32_t tile_s;
+  __syncthreads();  // (everybody is done with the LDS tile and with tile_s of the round before)
+  if (threadIdx.x == 0) tile_s = atomicAdd(p.tile_counter, 1u);
+  __syncthreads();
+  const uint32_t t = tile_s;
+  if (t >= p.tiles_x * p.tiles_y) return false;
+  bx = t % p.tiles_x;
+  by = t / p.tiles_x;
+  return true;
+}
 
 __device__ __forceinline__ uint32_t bitrev32(uint32_t x, uint32_t bits) { return __brev(x) >> (32 - bits); }
 
@@ -170,20 +192,19 @@ __device__ __forceinline__ void lds_ntt(fl* sh, const fl* __restrict__ tw_small,
 }
 
 // column pass: len rows at stride S = M/len, C adjacent columns per tile
-__global__ __launch_bounds__(kThreads) CAP_NTT_ATTR void ntt_col_pass(PassParams p) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  fl* sh = reinterpret_cast<fl*>(smem);
+__device__ __forceinline__ void col_tile(const PassParams& p, fl* sh, const uint32_t bx, const uint32_t by) {
+  {
   const uint32_t log_s = p.log_m - p.log_len;           // columns per segment (log)
   const uint32_t tiles_per_seg_log = log_s - p.log_c;
-  const uint32_t t = blockIdx.x;
+  const uint32_t t = bx;
   const size_t seg = t >> tiles_per_seg_log;
   const uint32_t col0 = (t & ((1u << tiles_per_seg_log) - 1)) << p.log_c;
-  const uint32_t q2 = blockIdx.y / p.in_group;
+  const uint32_t q2 = by / p.in_group;
   const fe* in = p.in + (size_t)(q2 / p.in_group2) * p.in_outer + (size_t)(q2 % p.in_group2) * p.in_inner2 +
-                 (size_t)(blockIdx.y % p.in_group) * p.in_inner;
-  const uint32_t o2 = blockIdx.y / p.out_group;
+                 (size_t)(by % p.in_group) * p.in_inner;
+  const uint32_t o2 = by / p.out_group;
   fe* out = p.out + (size_t)(o2 / p.out_group2) * p.out_outer + (size_t)(o2 % p.out_group2) * p.out_inner2 +
-            (size_t)(blockIdx.y % p.out_group) * p.out_inner;
+            (size_t)(by % p.out_group) * p.out_inner;
   const size_t base = (seg << p.log_m) + col0;
   const uint32_t tile = 1u << (p.log_len + p.log_c);
   const uint32_t cmask = (1u << p.log_c) - 1;
@@ -199,7 +220,7 @@ __global__ __launch_bounds__(kThreads) CAP_NTT_ATTR void ntt_col_pass(PassParams
       const uint32_t c = e & cmask, j = e >> p.log_c;
       const size_t g = base + ((size_t)j << log_s) + c;
       // position inside the source array (decimated input: every in_es-th element, starting at the group offset)
-      const size_t sg = p.in_es == 1 ? g : g * p.in_es + (size_t)(blockIdx.y % p.in_group) * p.in_inner;
+      const size_t sg = p.in_es == 1 ? g : g * p.in_es + (size_t)(by % p.in_group) * p.in_inner;
       sgs[u] = sg;
       any[u] = 0;
       if (e < tile && sg < p.in_len) {
@@ -213,7 +234,7 @@ __global__ __launch_bounds__(kThreads) CAP_NTT_ATTR void ntt_col_pass(PassParams
     if (p.pre_scale) {
 #pragma unroll
       for (int u = 0; u < kIoBatch; u++)
-        if (any[u]) pre[u] = p.pre_scale[sgs[u] + (size_t)(blockIdx.y % p.in_group) * p.pre_inner];
+        if (any[u]) pre[u] = p.pre_scale[sgs[u] + (size_t)(by % p.in_group) * p.pre_inner];
     }
 #pragma unroll
     for (int u = 0; u < kIoBatch; u++) {
@@ -251,21 +272,34 @@ __global__ __launch_bounds__(kThreads) CAP_NTT_ATTR void ntt_col_pass(PassParams
       out[base + ((size_t)k << log_s) + c] = Fr29::pack(v);   // < 2p: fits the 32-byte image
     }
   }
+  }
+}
+// PERSIST: a fixed number of workgroups take tile after tile from a counter (next_tile); otherwise one tile per workgroup.
+// Two instantiations, because the loop around the tile costs the one-shot form 55 VGPRs (93 -> 148: three waves per SIMD).
+template <bool PERSIST>
+__global__ __launch_bounds__(kThreads) CAP_NTT_ATTR void ntt_col_pass(PassParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  fl* sh = reinterpret_cast<fl*>(smem);
+  if constexpr (!PERSIST) {
+    col_tile(p, sh, blockIdx.x, blockIdx.y);
+  } else {
+    uint32_t bx, by;
+    for (uint32_t round = 0; next_tile(p, round, bx, by); round++) col_tile(p, sh, bx, by);
+  }
 }
 
 // row pass: contiguous rows of len elements; C rows with adjacent k1 per tile; digit-reversed store
-__global__ __launch_bounds__(kThreads) CAP_NTT_ATTR void ntt_row_pass(PassParams p) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  fl* sh = reinterpret_cast<fl*>(smem);
-  const uint32_t t = blockIdx.x;
+__device__ __forceinline__ void row_tile(const PassParams& p, fl* sh, const uint32_t bx, const uint32_t by) {
+  {
+  const uint32_t t = bx;
   const uint32_t k2 = t & ((1u << p.log_n2) - 1);
   const uint32_t r0 = (t >> p.log_n2) << p.log_c;
-  const uint32_t q2 = blockIdx.y / p.in_group;
+  const uint32_t q2 = by / p.in_group;
   const fe* in = p.in + (size_t)(q2 / p.in_group2) * p.in_outer + (size_t)(q2 % p.in_group2) * p.in_inner2 +
-                 (size_t)(blockIdx.y % p.in_group) * p.in_inner;
-  const uint32_t o2 = blockIdx.y / p.out_group;
+                 (size_t)(by % p.in_group) * p.in_inner;
+  const uint32_t o2 = by / p.out_group;
   fe* out = p.out + (size_t)(o2 / p.out_group2) * p.out_outer + (size_t)(o2 % p.out_group2) * p.out_inner2 +
-            (size_t)(blockIdx.y % p.out_group) * p.out_inner;
+            (size_t)(by % p.out_group) * p.out_inner;
   const uint32_t tile = 1u << (p.log_len + p.log_c);
   const uint32_t lmask = (1u << p.log_len) - 1;
   const uint32_t cmask = (1u << p.log_c) - 1;
@@ -278,7 +312,7 @@ __global__ __launch_bounds__(kThreads) CAP_NTT_ATTR void ntt_row_pass(PassParams
       const uint32_t e = e0 + u * kThreads;
       const uint32_t j = e & lmask, c = e >> p.log_len;
       const size_t g = ((((size_t)(r0 + c) << p.log_n2) + k2) << p.log_len) + j;
-      const size_t sg = p.in_es == 1 ? g : g * p.in_es + (size_t)(blockIdx.y % p.in_group) * p.in_inner;
+      const size_t sg = p.in_es == 1 ? g : g * p.in_es + (size_t)(by % p.in_group) * p.in_inner;
       sgs[u] = sg;
       any[u] = 0;
       if (e < tile && sg < p.in_len) {
@@ -292,7 +326,7 @@ __global__ __launch_bounds__(kThreads) CAP_NTT_ATTR void ntt_row_pass(PassParams
     if (p.pre_scale) {
 #pragma unroll
       for (int u = 0; u < kIoBatch; u++)
-        if (any[u]) pre[u] = p.pre_scale[sgs[u] + (size_t)(blockIdx.y % p.in_group) * p.pre_inner];
+        if (any[u]) pre[u] = p.pre_scale[sgs[u] + (size_t)(by % p.in_group) * p.pre_inner];
     }
 #pragma unroll
     for (int u = 0; u < kIoBatch; u++) {
@@ -318,6 +352,18 @@ __global__ __launch_bounds__(kThreads) CAP_NTT_ATTR void ntt_row_pass(PassParams
     // results leave the transform canonical (< r), as arkworks stores them - except the internal-form coset
     // evaluations, whose only reader (k_quotient) takes any representative below 2^256
     out[g] = p.lazy_out ? Fr29::store(v) : Fr29::pack(Fr29::canonical(v));
+  }
+  }
+}
+template <bool PERSIST>
+__global__ __launch_bounds__(kThreads) CAP_NTT_ATTR void ntt_row_pass(PassParams p) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  fl* sh = reinterpret_cast<fl*>(smem);
+  if constexpr (!PERSIST) {
+    row_tile(p, sh, blockIdx.x, blockIdx.y);
+  } else {
+    uint32_t bx, by;
+    for (uint32_t round = 0; next_tile(p, round, bx, by); round++) row_tile(p, sh, bx, by);
   }
 }
 
@@ -424,6 +470,10 @@ int build_powers(fe* d_out, size_t n, fe base, const fe* scale, hipStream_t stre
 fe ntt_root_of_unity(uint32_t log_n) { return host_root_of_unity(log_n); }
 
 int ntt_build_small_tables(NttSmallTables* t, hipStream_t stream) {
+  if (!t->pass_counters) {
+    hipError_t ec = hipMalloc(&t->pass_counters, sizeof(uint32_t) * kNttPassCounters);
+    if (ec != hipSuccess) return (int)ec;
+  }
   for (int s = 1; s <= kMaxLogTile; s++) {
     size_t n = (size_t)1 << (s - 1);
     hipError_t e = hipMalloc(&t->fwd[s], sizeof(fe) * n);
@@ -453,6 +503,8 @@ int ntt_build_small_tables(NttSmallTables* t, hipStream_t stream) {
 }
 
 void ntt_free_small_tables(NttSmallTables* t) {
+  if (t->pass_counters) hipFree(t->pass_counters);
+  t->pass_counters = nullptr;
   for (int s = 0; s <= kMaxLogTile; s++) {
     if (t->fwd[s]) hipFree(t->fwd[s]);
     if (t->inv[s]) hipFree(t->inv[s]);
@@ -511,6 +563,37 @@ void ntt_table_to_internal(fe* out, const fe* in, size_t n, hipStream_t stream) 
   if (n == 0) return;
   launch("table_to_internal", table_to_internal, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, out, in, n);
 }
+
+namespace {
+// Workgroups per CU of a persistent pass launch (CAPGPU_NTT_PERSISTENT; 0 = one workgroup per tile)
+unsigned ntt_persistent() {
+  static const unsigned v = [] {
+    const char* e = getenv("CAPGPU_NTT_PERSISTENT");
+    const long x = e ? atol(e) : 0;
+    return (unsigned)(x >= 1 && x <= 16 ? x : 0);
+  }();
+  return v;
+}
+template <class K>
+void launch_pass(const char* name, K kernel, K kernel_persistent, PassParams& p, const NttSmallTables& small, size_t tiles,
+                 uint32_t count, size_t lds, hipStream_t stream) {
+  p.tile_counter = nullptr;
+  p.tiles_x = (uint32_t)tiles;
+  p.tiles_y = count;
+  const unsigned per_cu = ntt_persistent();
+  const uint64_t total = (uint64_t)tiles * count;
+  if (per_cu && small.pass_counters && total > 4ull * 256 * per_cu && total < (1ull << 32)) {
+    uint32_t* ctr = small.pass_counters + (small.next_counter++ % kNttPassCounters);
+    if (hipMemsetAsync(ctr, 0, sizeof(uint32_t), stream) == hipSuccess) {
+      p.tile_counter = ctr;
+      launch(name, kernel_persistent, dim3(256u * per_cu), dim3(kThreads), lds, stream, p);
+      return;
+    }
+    (void)hipGetLastError();
+  }
+  launch(name, kernel, dim3((unsigned)tiles, count), dim3(kThreads), lds, stream, p);
+}
+}  // namespace
 
 int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scratch, size_t stride_elems,
             uint32_t count, int dir, int coset, hipStream_t stream, const NttIo* io) {
@@ -605,7 +688,7 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
     p.log_m = log_m;
     size_t tiles = (size_t)1 << (log_n - log_len - log_c);
     size_t lds = sizeof(fl) << (log_len + log_c);
-    launch("ntt_col_pass", ntt_col_pass, dim3((unsigned)tiles, count), dim3(kThreads), lds, stream, p);
+    launch_pass("ntt_col_pass", ntt_col_pass<false>, ntt_col_pass<true>, p, small, tiles, count, lds, stream);
     cur_in = scratch;
     first = false;
     log_m -= log_len;
@@ -634,7 +717,7 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
     p.log_n2 = log_n2;
     size_t tiles = (size_t)1 << (log_n - log_len - log_c);
     size_t lds = sizeof(fl) << (log_len + log_c);
-    launch("ntt_row_pass", ntt_row_pass, dim3((unsigned)tiles, count), dim3(kThreads), lds, stream, p);
+    launch_pass("ntt_row_pass", ntt_row_pass<false>, ntt_row_pass<true>, p, small, tiles, count, lds, stream);
   }
   return 0;  // launch failures are latched by launch() and reported by take_launch_error()
 }

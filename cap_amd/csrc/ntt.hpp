@@ -39,7 +39,12 @@ struct NttSmallTables {
   // 8 -> 9 word unpacking in every butterfly
   uint32_t* fwd_u[kMaxLogTile + 1] = {nullptr};
   uint32_t* inv_u[kMaxLogTile + 1] = {nullptr};
+  // tile counters of persistent pass launches (ntt.hip: a launch of many tiles is a few workgroups per CU that take tile
+  // after tile from a counter); one slot per launch, reused in rotation on the context's one stream
+  uint32_t* pass_counters = nullptr;
+  mutable uint32_t next_counter = 0;
 };
+constexpr uint32_t kNttPassCounters = 256;
 
 // Host-side table construction (runs tiny setup kernels).  Returns hipError_t as int.
 int ntt_build_small_tables(NttSmallTables* t, hipStream_t stream);
