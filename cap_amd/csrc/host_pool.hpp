@@ -44,8 +44,8 @@ class HostPool {
     const unsigned procs = lw && atoi(lw) > 0 ? (unsigned)atoi(lw) : 1u;
     const unsigned sharers = std::max(contexts, 1u) * procs;
     unsigned hw = std::thread::hardware_concurrency();
-    unsigned v = e ? (unsigned)atoi(e) : (hw + sharers - 1) / sharers;
-    return std::min(std::max(v, 2u), 32u);
+    unsigned v = e ? (unsigned)atoi(e) : std::max((hw + sharers - 1) / sharers, 2u);
+    return std::min(std::max(v, 1u), 32u);
   }
   // runs job(i) for i in [0, count); the caller takes part
   void run(uint32_t count, const std::function<void(uint32_t)>& job) {
