@@ -12,6 +12,7 @@
 #define CAP_FL_SCHED 1
 #include "msm.hpp"
 #include "curve29.hpp"
+#include "quad29.hpp"
 #include "launch.hpp"
 
 #include <math.h>
@@ -1356,6 +1357,130 @@ __global__ __launch_bounds__(128) void msm_reduce_grid_final_small(const g1_xyzz
     else out[b] = G1S::to_jac_ext(r);
   }
 }
+// ---- K5 / K6 tails of SMALL launches on quads: one point per four lanes (quad29.hpp) ---------------------------------
+// A single proof's launches (1, 2 and 5 MSMs of 4096 buckets) spend most of their time in three chains of dependent point
+// additions - bucket = sum of its items, the row / column sums of the grid, the two weighted sums of 64 terms - on a chip
+// with lanes to spare.  The quad form of the same kernels runs every addition four multiplications deep instead of twelve.
+// Same sums, same order of the operands where it matters (none: the group is commutative and the results leave as affine
+// coordinates); taken for launches of up to quad_max_batch() MSMs, the one-lane kernels above stay for everything else.
+using QD = QuadG1<G1S, QuadDev>;
+__device__ __noinline__ g1x quad_slow_add(const g1x& a, const g1x& b) { return G1S::add(a, b); }
+struct QuadSlow {
+  __device__ __forceinline__ g1x operator()(const g1x& a, const g1x& b) const { return quad_slow_add(a, b); }
+};
+__device__ __forceinline__ fl quad_zero() { return G1S::F::zero(); }
+__device__ __forceinline__ fl quad_load(const g1_xyzz* p) {
+  return G1S::F::load(reinterpret_cast<const fe*>(p)[threadIdx.x & 3]);
+}
+__device__ __forceinline__ void quad_store(g1_xyzz* p, const fl& v) {
+  reinterpret_cast<fe*>(p)[threadIdx.x & 3] = G1S::F::pack(v);
+}
+// the value of the quad `d` quads up the wave
+__device__ __forceinline__ fl quad_shfl_down(const fl& a, int d) { return shfl_down_fl(a, 4 * d); }
+
+// bucket = sum of its work items, GQ quads per bucket (msm_combine_wave's job: there eight lanes hold eight items and a
+// three-level tree adds them; here two quads - the same eight lanes - take the items in turn and one level joins them)
+template <int GQ>
+__global__ __launch_bounds__(kThreads) void msm_combine_quad(const g1_xyzz* __restrict__ item_pts,
+                                                             const uint32_t* __restrict__ counts,
+                                                             const uint32_t* __restrict__ item_off,
+                                                             const uint32_t* __restrict__ item_base, uint32_t half,
+                                                             uint32_t total_buckets, uint32_t item_len,
+                                                             g1_xyzz* __restrict__ buckets) {
+  const uint32_t quad = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const uint32_t gb = quad / GQ, lane = quad % GQ;
+  if (gb >= total_buckets) return;  // whole groups leave together (4 GQ lanes, a divisor of 64)
+  const uint32_t items = (counts[gb] + item_len - 1) / item_len;
+  const uint32_t first = item_base[gb / half] + item_off[gb];
+  fl acc = quad_zero();
+  if (items != 1) {  // single-item buckets were written by msm_accumulate
+    if (lane < items) acc = quad_load(&item_pts[first + lane]);
+    for (uint32_t j = lane + GQ; j < items; j += GQ) QD::add(acc, quad_load(&item_pts[first + j]), QuadSlow());
+  }
+#pragma unroll 1
+  for (int d = GQ / 2; d >= 1; d >>= 1) {
+    const fl o = quad_shfl_down(acc, d);
+    if (lane < (uint32_t)d) QD::add(acc, o, QuadSlow());
+  }
+  if (lane == 0 && items != 1) quad_store(&buckets[gb], acc);
+}
+
+// msm_reduce_grid on quads: `slices` quads per row / column sum
+template <uint32_t slices>
+__global__ __launch_bounds__(kThreads) void msm_reduce_grid_quad(const g1_xyzz* __restrict__ buckets, uint32_t half,
+                                                                 uint32_t lo_bits, uint32_t sb,
+                                                                 g1_xyzz* __restrict__ sums /* [sb][rows + cols] */) {
+  const uint32_t cols = 1u << lo_bits, rows = half >> lo_bits, nsum = rows + cols;
+  const uint32_t quad = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const uint32_t g = quad / slices, q = quad % slices;
+  if (g >= sb * nsum) return;
+  const uint32_t b = g / nsum, sidx = g - b * nsum;
+  const g1_xyzz* bk = buckets + (size_t)b * half;
+  // one loop for both kinds of sum (a row walks along the buckets, a column strides over them): one copy of the addition
+  const bool row = sidx < rows;
+  const uint32_t dim = row ? cols : rows, per = (dim + slices - 1) / slices, i0 = q * per;
+  const size_t origin = row ? (size_t)sidx * cols : (size_t)(sidx - rows), stride = row ? 1 : cols;
+  fl acc = quad_zero();
+#pragma unroll 1
+  for (uint32_t i = i0; i < i0 + per && i < dim; i++) QD::add(acc, quad_load(&bk[origin + (size_t)i * stride]), QuadSlow());
+#pragma unroll 1
+  for (int d = (int)slices / 2; d >= 1; d >>= 1) {
+    const fl o = quad_shfl_down(acc, d);
+    if (q < (uint32_t)d) QD::add(acc, o, QuadSlow());
+  }
+  if (q == 0) quad_store(&sums[g], acc);
+}
+
+// msm_reduce_grid_final_small on quads: one workgroup of 512 lanes per entry - 64 quads for the row sums, 64 for the
+// column sums.  The 64 terms of a dimension span four waves, so the suffix scan and the tree exchange them through LDS
+// (two buffers in turn: one barrier per step).  Chain: 6 + 6 additions, lo_bits doublings, one addition - as before, each
+// a third as deep.
+__global__ __launch_bounds__(512) void msm_reduce_grid_final_quad(const g1_xyzz* __restrict__ sums, uint32_t half,
+                                                                  uint32_t lo_bits, g1_jac* __restrict__ out,
+                                                                  g1_xyzz* __restrict__ out_part) {
+  __shared__ fl ex[2][2][64][4];  // [buffer][dimension][term][coordinate]
+  const uint32_t cols = 1u << lo_bits, rows = half >> lo_bits;
+  const uint32_t b = blockIdx.x, dim = threadIdx.x >> 8, k = (threadIdx.x & 255) >> 2, c = threadIdx.x & 3;
+  const g1_xyzz* sp = sums + (size_t)b * (rows + cols) + (dim ? rows : 0);
+  const uint32_t cnt = dim ? cols : rows;
+  fl suf = k < cnt ? quad_load(&sp[k]) : quad_zero();
+  uint32_t buf = 0;
+#pragma unroll 1
+  for (uint32_t step = 0; step < 12; step++) {
+    // steps 0 .. 5: suf_k += suf_{k + d}, d = 1, 2, .. 32 (inclusive suffix sums); steps 6 .. 11: the sum of the suffixes -
+    // from term 1 on for the rows (weights hi = 0 .. rows - 1), from term 0 on for the columns (weights lo + 1)
+    if (step == 6 && dim == 0 && k == 0) suf = quad_zero();
+    const uint32_t d = step < 6 ? 1u << step : 32u >> (step - 6);
+    const bool take = step < 6 ? k + d < 64 : k < d;
+    ex[buf][dim][k][c] = suf;
+    __syncthreads();
+    if (take) QD::add(suf, ex[buf][dim][k + d][c], QuadSlow());
+    buf ^= 1;
+  }
+  if (dim == 0 && k == 0) {
+    for (uint32_t i = 0; i < lo_bits; i++) QD::dbl(suf);
+    ex[buf][0][0][c] = suf;
+  }
+  __syncthreads();
+  if (dim == 1 && k == 0) {
+    QD::add(suf, ex[buf][0][0][c], QuadSlow());
+    const g1x r = QD::gather(suf);
+    if (c == 0) {
+      if (out_part) out_part[b] = G1S::store(r);
+      else out[b] = G1S::to_jac_ext(r);
+    }
+  }
+}
+// launches the quad tails take: up to this many MSMs (CAPGPU_MSM_QUAD_MAX; 0: never)
+uint32_t quad_max_batch() {
+  static const uint32_t v = [] {
+    const char* e = getenv("CAPGPU_MSM_QUAD_MAX");
+    const int x = e ? atoi(e) : 23;  // (every launch of the narrow table: the wide one takes over at 24 MSMs)
+    return (uint32_t)(x < 0 ? 0 : x);
+  }();
+  return v;
+}
+
 // bucket sets the grid form takes: 2^k buckets, 2 <= k <= 14, both grid dimensions <= 128 (CAPGPU_MSM_GRID_REDUCE=0: off)
 bool use_grid_reduce(uint32_t half) {
   static const bool on = [] {
@@ -1973,6 +2098,8 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
     // bucket sizes (a bucket with more items than lanes loops), so that the shuffle tree is no deeper than needed
     const size_t avg_items = (t.entries / total_buckets + item_len - 1) / item_len;
     const size_t want = avg_items * 3 / 2;
+    // small launches on the narrow table: the tails run on quads (see msm_combine_quad)
+    const bool quad = !out_pair && use_grid_reduce(half) && half <= 4096 && sb <= quad_max_batch();
     if (avg_items <= 1 && total_buckets >= 65536) {
       // buckets of (almost always) ONE item - a few dozen MSMs on the wide table: msm_accumulate wrote those buckets
       // itself, and eight lanes per bucket would be five million idle threads (a 40-MSM launch: 300 us of them); one
@@ -1980,6 +2107,13 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
       launch("msm_combine", msm_combine, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0, stream,
              (const g1_xyzz*)t.item_pts, (const uint32_t*)t.counts, (const uint32_t*)t.item_off,
              (const uint32_t*)t.item_base, half, total_buckets, item_len, t.buckets);
+    } else if (quad && want <= 32) {
+      // (the same 8, 16 or 32 lanes per bucket as msm_combine_wave would take: two, four or eight quads)
+      const uint32_t GQ = want <= 8 ? 2u : (want <= 16 ? 4u : 8u);
+      auto kern = GQ == 2 ? msm_combine_quad<2> : (GQ == 4 ? msm_combine_quad<4> : msm_combine_quad<8>);
+      launch("msm_combine", kern, dim3((unsigned)(((size_t)total_buckets * GQ * 4 + kThreads - 1) / kThreads)),
+             dim3(kThreads), 0, stream, (const g1_xyzz*)t.item_pts, (const uint32_t*)t.counts,
+             (const uint32_t*)t.item_off, (const uint32_t*)t.item_base, half, total_buckets, item_len, t.buckets);
     } else {
       const uint32_t G = want <= 8 ? 8u : (want <= 16 ? 16u : (want <= 32 ? 32u : 64u));
       auto kern = G == 8 ? msm_combine_wave<8>
@@ -1992,6 +2126,17 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
       uint32_t k = 0;
       while ((1u << k) < half) k++;
       const uint32_t lo_bits = k / 2, nsum = (half >> lo_bits) + (1u << lo_bits);
+      if (quad) {
+        // 16 quads per sum where the dimension allows it (4 + 4 additions deep), 8 otherwise
+        const bool s16 = std::min(half >> lo_bits, 1u << lo_bits) >= 32;
+        const uint32_t qs = s16 ? 16u : 8u;
+        launch("msm_reduce_grid", s16 ? msm_reduce_grid_quad<16> : msm_reduce_grid_quad<8>,
+               dim3((unsigned)(((size_t)sb * nsum * qs * 4 + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
+               (const g1_xyzz*)t.buckets, half, lo_bits, sb, t.partial);
+        launch("msm_reduce_grid_final", msm_reduce_grid_final_quad, dim3(sb), dim3(512), 0, stream,
+               (const g1_xyzz*)t.partial, half, lo_bits, out, out_part);
+        return;
+      }
       const uint32_t slices = grid_slices(sb, nsum, std::min(half >> lo_bits, 1u << lo_bits));
       auto gk = slices == 64 ? msm_reduce_grid<64> : (slices == 32 ? msm_reduce_grid<32> : (slices == 16 ? msm_reduce_grid<16> : msm_reduce_grid<8>));
       launch("msm_reduce_grid", gk, dim3((unsigned)(((size_t)sb * nsum * slices + kThreads - 1) / kThreads)),
