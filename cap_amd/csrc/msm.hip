@@ -1395,7 +1395,16 @@ __global__ __launch_bounds__(kThreads) void msm_combine_quad(const g1_xyzz* __re
   fl acc = quad_zero();
   if (items != 1) {  // single-item buckets were written by msm_accumulate
     if (lane < items) acc = quad_load(&item_pts[first + lane]);
-    for (uint32_t j = lane + GQ; j < items; j += GQ) QD::add(acc, quad_load(&item_pts[first + j]), QuadSlow());
+    if (lane + GQ < items) {
+      fl cur = quad_load(&item_pts[first + lane + GQ]);
+#pragma unroll 1
+      for (uint32_t j = lane + GQ; j < items; j += GQ) {
+        // (the next item is in flight while this one is added)
+        const fl nxt = quad_load(&item_pts[first + (j + GQ < items ? j + GQ : j)]);
+        QD::add(acc, cur, QuadSlow());
+        cur = nxt;
+      }
+    }
   }
 #pragma unroll 1
   for (int d = GQ / 2; d >= 1; d >>= 1) {
@@ -1409,7 +1418,8 @@ __global__ __launch_bounds__(kThreads) void msm_combine_quad(const g1_xyzz* __re
 template <uint32_t slices>
 __global__ __launch_bounds__(kThreads) void msm_reduce_grid_quad(const g1_xyzz* __restrict__ buckets, uint32_t half,
                                                                  uint32_t lo_bits, uint32_t sb,
-                                                                 g1_xyzz* __restrict__ sums /* [sb][rows + cols] */) {
+                                                                 g1_xyzz* __restrict__ sums /* [sb][rows + cols] */,
+                                                                 uint32_t* __restrict__ fin_count /* [sb] */) {
   const uint32_t cols = 1u << lo_bits, rows = half >> lo_bits, nsum = rows + cols;
   const uint32_t quad = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
   const uint32_t g = quad / slices, q = quad % slices;
@@ -1420,27 +1430,45 @@ __global__ __launch_bounds__(kThreads) void msm_reduce_grid_quad(const g1_xyzz* 
   const bool row = sidx < rows;
   const uint32_t dim = row ? cols : rows, per = (dim + slices - 1) / slices, i0 = q * per;
   const size_t origin = row ? (size_t)sidx * cols : (size_t)(sidx - rows), stride = row ? 1 : cols;
+  const uint32_t i1 = i0 + per < dim ? i0 + per : dim;
   fl acc = quad_zero();
+  if (i0 < i1) {
+    acc = quad_load(&bk[origin + (size_t)i0 * stride]);
+    if (i0 + 1 < i1) {
+      fl cur = quad_load(&bk[origin + (size_t)(i0 + 1) * stride]);
 #pragma unroll 1
-  for (uint32_t i = i0; i < i0 + per && i < dim; i++) QD::add(acc, quad_load(&bk[origin + (size_t)i * stride]), QuadSlow());
+      for (uint32_t i = i0 + 1; i < i1; i++) {
+        const fl nxt = quad_load(&bk[origin + (size_t)(i + 1 < i1 ? i + 1 : i) * stride]);  // in flight during the addition
+        QD::add(acc, cur, QuadSlow());
+        cur = nxt;
+      }
+    }
+  }
 #pragma unroll 1
   for (int d = (int)slices / 2; d >= 1; d >>= 1) {
     const fl o = quad_shfl_down(acc, d);
     if (q < (uint32_t)d) QD::add(acc, o, QuadSlow());
   }
   if (q == 0) quad_store(&sums[g], acc);
+  if (sidx == 0 && q == 0 && (threadIdx.x & 3) == 0) fin_count[b] = 0;  // for msm_reduce_grid_final_quad
 }
 
-// msm_reduce_grid_final_small on quads: one workgroup of 512 lanes per entry - 64 quads for the row sums, 64 for the
-// column sums.  The 64 terms of a dimension span four waves, so the suffix scan and the tree exchange them through LDS
-// (two buffers in turn: one barrier per step).  Chain: 6 + 6 additions, lo_bits doublings, one addition - as before, each
-// a third as deep.
-__global__ __launch_bounds__(512) void msm_reduce_grid_final_quad(const g1_xyzz* __restrict__ sums, uint32_t half,
-                                                                  uint32_t lo_bits, g1_jac* __restrict__ out,
+// msm_reduce_grid_final_small on quads: TWO workgroups of 256 lanes per entry - 64 quads for the row sums in one, 64 for
+// the column sums in the other, so that each runs one wave per SIMD on a CU of its own (eight waves on one CU: 90 us per
+// launch, the two chains in each other's way).  The 64 terms of a dimension span four waves, so the suffix scan and the
+// tree exchange them through LDS (two buffers in turn: one barrier per step).  Chain: 6 + 6 additions, lo_bits
+// doublings, one addition - as before, each a third as deep.  The workgroup that finishes second (a counter per entry,
+// zeroed by msm_reduce_grid_quad) adds the other one's result to its own and writes the entry's sum.
+// fin: [sb][2] results of the two dimensions, then [sb] counters.
+__global__ __launch_bounds__(256) void msm_reduce_grid_final_quad(const g1_xyzz* __restrict__ sums, uint32_t half,
+                                                                  uint32_t lo_bits, g1_xyzz* __restrict__ fin,
+                                                                  uint32_t* __restrict__ fin_count,
+                                                                  g1_jac* __restrict__ out,
                                                                   g1_xyzz* __restrict__ out_part) {
-  __shared__ fl ex[2][2][64][4];  // [buffer][dimension][term][coordinate]
+  __shared__ fl ex[2][64][4];  // [buffer][term][coordinate]
+  __shared__ uint32_t second_s;
   const uint32_t cols = 1u << lo_bits, rows = half >> lo_bits;
-  const uint32_t b = blockIdx.x, dim = threadIdx.x >> 8, k = (threadIdx.x & 255) >> 2, c = threadIdx.x & 3;
+  const uint32_t b = blockIdx.x, dim = blockIdx.y, k = threadIdx.x >> 2, c = threadIdx.x & 3;
   const g1_xyzz* sp = sums + (size_t)b * (rows + cols) + (dim ? rows : 0);
   const uint32_t cnt = dim ? cols : rows;
   fl suf = k < cnt ? quad_load(&sp[k]) : quad_zero();
@@ -1452,23 +1480,32 @@ __global__ __launch_bounds__(512) void msm_reduce_grid_final_quad(const g1_xyzz*
     if (step == 6 && dim == 0 && k == 0) suf = quad_zero();
     const uint32_t d = step < 6 ? 1u << step : 32u >> (step - 6);
     const bool take = step < 6 ? k + d < 64 : k < d;
-    ex[buf][dim][k][c] = suf;
+    ex[buf][k][c] = suf;
     __syncthreads();
-    if (take) QD::add(suf, ex[buf][dim][k + d][c], QuadSlow());
+    if (take) QD::add(suf, ex[buf][k + d][c], QuadSlow());
     buf ^= 1;
   }
-  if (dim == 0 && k == 0) {
-    for (uint32_t i = 0; i < lo_bits; i++) QD::dbl(suf);
-    ex[buf][0][0][c] = suf;
+  if (k == 0) {
+    if (dim == 0)
+      for (uint32_t i = 0; i < lo_bits; i++) QD::dbl(suf);
+    quad_store(&fin[2 * (size_t)b + dim], suf);
+    __threadfence();  // the result is out before the counter says so
   }
   __syncthreads();
-  if (dim == 1 && k == 0) {
-    QD::add(suf, ex[buf][0][0][c], QuadSlow());
-    const g1x r = QD::gather(suf);
-    if (c == 0) {
-      if (out_part) out_part[b] = G1S::store(r);
-      else out[b] = G1S::to_jac_ext(r);
-    }
+  if (threadIdx.x == 0) second_s = atomicAdd(&fin_count[b], 1u);
+  __syncthreads();
+  if (second_s == 0 || k != 0) return;
+  __threadfence();
+  // (read past the caches: the other workgroup ran on another CU, likely on another XCD)
+  const uint32_t* op = reinterpret_cast<const uint32_t*>(&fin[2 * (size_t)b + (1 - dim)]) + 8 * c;
+  fe o;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o.v[i] = __hip_atomic_load(op + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  QD::add(suf, G1S::F::load(o), QuadSlow());
+  const g1x r = QD::gather(suf);
+  if (c == 0) {
+    if (out_part) out_part[b] = G1S::store(r);
+    else out[b] = G1S::to_jac_ext(r);
   }
 }
 // launches the quad tails take: up to this many MSMs (CAPGPU_MSM_QUAD_MAX; 0: never)
@@ -1798,7 +1835,7 @@ WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t sb, uint32_t
     {  // the grid reduction's row and column sums (msm_reduce_grid): 2^ceil(k/2) + 2^floor(k/2) per entry
       uint32_t k = 0;
       while (((size_t)1 << k) < half) k++;
-      npart = std::max(npart, ((size_t)half >> (k / 2)) + ((size_t)1 << (k / 2)));
+      npart = std::max(npart, ((size_t)half >> (k / 2)) + ((size_t)1 << (k / 2)) + 3);  // (+ 3: msm_reduce_grid_final_quad)
     }
     L.buckets = o; o = align_up(o + sizeof(g1_xyzz) * half * sb, 256);
     L.partial = o; o = align_up(o + sizeof(g1_xyzz) * npart * sb, 256);
@@ -2129,12 +2166,15 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
       if (quad) {
         // 16 quads per sum where the dimension allows it (4 + 4 additions deep), 8 otherwise
         const bool s16 = std::min(half >> lo_bits, 1u << lo_bits) >= 32;
+        // behind the sums in `partial` (ws_layout keeps the room): the two dimensions' results and a counter per entry
+        g1_xyzz* fin = t.partial + (size_t)sb * nsum;
+        uint32_t* fin_count = reinterpret_cast<uint32_t*>(fin + 2 * (size_t)sb);
         const uint32_t qs = s16 ? 16u : 8u;
         launch("msm_reduce_grid", s16 ? msm_reduce_grid_quad<16> : msm_reduce_grid_quad<8>,
                dim3((unsigned)(((size_t)sb * nsum * qs * 4 + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
-               (const g1_xyzz*)t.buckets, half, lo_bits, sb, t.partial);
-        launch("msm_reduce_grid_final", msm_reduce_grid_final_quad, dim3(sb), dim3(512), 0, stream,
-               (const g1_xyzz*)t.partial, half, lo_bits, out, out_part);
+               (const g1_xyzz*)t.buckets, half, lo_bits, sb, t.partial, fin_count);
+        launch("msm_reduce_grid_final", msm_reduce_grid_final_quad, dim3(sb, 2), dim3(256), 0, stream,
+               (const g1_xyzz*)t.partial, half, lo_bits, fin, fin_count, out, out_part);
         return;
       }
       const uint32_t slices = grid_slices(sb, nsum, std::min(half >> lo_bits, 1u << lo_bits));
