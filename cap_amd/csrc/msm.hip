@@ -1460,12 +1460,15 @@ __global__ __launch_bounds__(kThreads) void msm_reduce_grid_quad(const g1_xyzz* 
 // doublings, one addition - as before, each a third as deep.  The workgroup that finishes second (a counter per entry,
 // zeroed by msm_reduce_grid_quad) adds the other one's result to its own and writes the entry's sum.
 // fin: [sb][2] results of the two dimensions, then [sb] counters.
-__global__ __launch_bounds__(256) void msm_reduce_grid_final_quad(const g1_xyzz* __restrict__ sums, uint32_t half,
-                                                                  uint32_t lo_bits, g1_xyzz* __restrict__ fin,
-                                                                  uint32_t* __restrict__ fin_count,
-                                                                  g1_jac* __restrict__ out,
-                                                                  g1_xyzz* __restrict__ out_part) {
-  __shared__ fl ex[2][64][4];  // [buffer][term][coordinate]
+// TERMS: 64 (grids of up to 64 x 64: the narrow table's 4096 buckets) or 128 (the wide table's 16384: eight waves).
+template <uint32_t TERMS>
+__global__ __launch_bounds__(4 * TERMS) void msm_reduce_grid_final_quad(const g1_xyzz* __restrict__ sums, uint32_t half,
+                                                                        uint32_t lo_bits, g1_xyzz* __restrict__ fin,
+                                                                        uint32_t* __restrict__ fin_count,
+                                                                        g1_jac* __restrict__ out,
+                                                                        g1_xyzz* __restrict__ out_part) {
+  constexpr uint32_t LOG = TERMS == 64 ? 6 : 7;
+  __shared__ fl ex[2][TERMS][4];  // [buffer][term][coordinate]
   __shared__ uint32_t second_s;
   const uint32_t cols = 1u << lo_bits, rows = half >> lo_bits;
   const uint32_t b = blockIdx.x, dim = blockIdx.y, k = threadIdx.x >> 2, c = threadIdx.x & 3;
@@ -1474,12 +1477,12 @@ __global__ __launch_bounds__(256) void msm_reduce_grid_final_quad(const g1_xyzz*
   fl suf = k < cnt ? quad_load(&sp[k]) : quad_zero();
   uint32_t buf = 0;
 #pragma unroll 1
-  for (uint32_t step = 0; step < 12; step++) {
-    // steps 0 .. 5: suf_k += suf_{k + d}, d = 1, 2, .. 32 (inclusive suffix sums); steps 6 .. 11: the sum of the suffixes -
-    // from term 1 on for the rows (weights hi = 0 .. rows - 1), from term 0 on for the columns (weights lo + 1)
-    if (step == 6 && dim == 0 && k == 0) suf = quad_zero();
-    const uint32_t d = step < 6 ? 1u << step : 32u >> (step - 6);
-    const bool take = step < 6 ? k + d < 64 : k < d;
+  for (uint32_t step = 0; step < 2 * LOG; step++) {
+    // steps 0 .. LOG - 1: suf_k += suf_{k + d}, d = 1, 2, .. TERMS / 2 (inclusive suffix sums); then LOG steps for the sum
+    // of the suffixes - from term 1 on for the rows (weights hi = 0 .. rows - 1), from term 0 on for the columns (lo + 1)
+    if (step == LOG && dim == 0 && k == 0) suf = quad_zero();
+    const uint32_t d = step < LOG ? 1u << step : (TERMS / 2) >> (step - LOG);
+    const bool take = step < LOG ? k + d < TERMS : k < d;
     ex[buf][k][c] = suf;
     __syncthreads();
     if (take) QD::add(suf, ex[buf][k + d][c], QuadSlow());
@@ -1518,6 +1521,15 @@ uint32_t quad_max_batch() {
   return v;
 }
 
+// ... and of the wide table (24 .. 63 MSMs of 16384 buckets; CAPGPU_MSM_QUAD_MAX_WIDE, 0: never)
+uint32_t quad_max_batch_wide() {
+  static const uint32_t v = [] {
+    const char* e = getenv("CAPGPU_MSM_QUAD_MAX_WIDE");
+    const int x = e ? atoi(e) : 63;
+    return (uint32_t)(x < 0 ? 0 : x);
+  }();
+  return v;
+}
 // bucket sets the grid form takes: 2^k buckets, 2 <= k <= 14, both grid dimensions <= 128 (CAPGPU_MSM_GRID_REDUCE=0: off)
 bool use_grid_reduce(uint32_t half) {
   static const bool on = [] {
@@ -1806,11 +1818,21 @@ uint32_t choose_item_len(size_t entries, size_t buckets) {
     const char* e = getenv("CAPGPU_MSM_ITEM_SMALL");
     return !e || atoi(e) != 0;
   }();
-  if (tune_small && buckets && buckets <= 8192 && entries >= buckets) {  // (1 or 2 MSMs; with 5 the items get long and a
-                                                                         // lone wave cannot hide its gathers: measured worse)
+  static const size_t small_waves = [] {  // experiment: waves of items per SIMD the small launches aim at
+    const char* e = getenv("CAPGPU_MSM_ITEM_WAVES");
+    const int x = e ? atoi(e) : 1;
+    return (size_t)(x >= 1 && x <= 8 ? x : 1);
+  }();
+  static const size_t small_buckets = [] {  // experiment: the largest bucket set (all MSMs of the launch) the rule takes
+    const char* e = getenv("CAPGPU_MSM_ITEM_SMALL_BUCKETS");
+    const int x = e ? atoi(e) : 8192;
+    return (size_t)(x >= 0 ? x : 8192);
+  }();
+  if (tune_small && buckets && buckets <= small_buckets && entries >= buckets) {  // (1 or 2 MSMs; with 5 the items get long
+                                                                   // and a lone wave cannot hide its gathers: measured worse)
     const double avg = (double)entries / (double)buckets;
     const double hi = avg + 4.0 * sqrt(avg);
-    const size_t m = std::max<size_t>(1, 65536 / buckets);
+    const size_t m = std::max<size_t>(1, 65536 * small_waves / buckets);
     const size_t l = (size_t)ceil(hi / (double)m);
     return (uint32_t)std::min<size_t>(std::max<size_t>(l, 8), cap);
   }
@@ -2136,7 +2158,7 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
     const size_t avg_items = (t.entries / total_buckets + item_len - 1) / item_len;
     const size_t want = avg_items * 3 / 2;
     // small launches on the narrow table: the tails run on quads (see msm_combine_quad)
-    const bool quad = !out_pair && use_grid_reduce(half) && half <= 4096 && sb <= quad_max_batch();
+    const bool quad = !out_pair && use_grid_reduce(half) && sb <= (half <= 4096 ? quad_max_batch() : quad_max_batch_wide());
     if (avg_items <= 1 && total_buckets >= 65536) {
       // buckets of (almost always) ONE item - a few dozen MSMs on the wide table: msm_accumulate wrote those buckets
       // itself, and eight lanes per bucket would be five million idle threads (a 40-MSM launch: 300 us of them); one
@@ -2173,8 +2195,12 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
         launch("msm_reduce_grid", s16 ? msm_reduce_grid_quad<16> : msm_reduce_grid_quad<8>,
                dim3((unsigned)(((size_t)sb * nsum * qs * 4 + kThreads - 1) / kThreads)), dim3(kThreads), 0, stream,
                (const g1_xyzz*)t.buckets, half, lo_bits, sb, t.partial, fin_count);
-        launch("msm_reduce_grid_final", msm_reduce_grid_final_quad, dim3(sb, 2), dim3(256), 0, stream,
-               (const g1_xyzz*)t.partial, half, lo_bits, fin, fin_count, out, out_part);
+        if (half <= 4096)
+          launch("msm_reduce_grid_final", msm_reduce_grid_final_quad<64>, dim3(sb, 2), dim3(256), 0, stream,
+                 (const g1_xyzz*)t.partial, half, lo_bits, fin, fin_count, out, out_part);
+        else
+          launch("msm_reduce_grid_final", msm_reduce_grid_final_quad<128>, dim3(sb, 2), dim3(512), 0, stream,
+                 (const g1_xyzz*)t.partial, half, lo_bits, fin, fin_count, out, out_part);
         return;
       }
       const uint32_t slices = grid_slices(sb, nsum, std::min(half >> lo_bits, 1u << lo_bits));
