@@ -1511,6 +1511,90 @@ __global__ __launch_bounds__(4 * TERMS) void msm_reduce_grid_final_quad(const g1
     else out[b] = G1S::to_jac_ext(r);
   }
 }
+// msm_reduce_final on quads: 64 quads per entry (one workgroup of 256 lanes), the lane loop of the one-lane kernel per
+// quad, the suffix sums and the closing sum through LDS.  The additions are calls here (nine registers per operand: they
+// travel in registers), one copy of the code for the kernel's eight call sites.
+__device__ __noinline__ fl quad_add_call(fl a, fl b) {
+  QD::add(a, b, QuadSlow());
+  return a;
+}
+__device__ __noinline__ fl quad_dbl_call(fl a) {
+  QD::dbl(a);
+  return a;
+}
+__device__ fl quad_mul_small(const fl& p, uint32_t k) {
+  fl r = quad_zero();
+  bool started = false;
+  for (int bit = 31; bit >= 0; bit--) {
+    if (started) r = quad_dbl_call(r);
+    if ((k >> bit) & 1) {
+      r = quad_add_call(r, p);
+      started = true;
+    }
+  }
+  return r;
+}
+__global__ __launch_bounds__(256) void msm_reduce_final_quad(const g1_xyzz* __restrict__ seg_pts, uint32_t seg_len,
+                                                            uint32_t nseg, g1_jac* __restrict__ out,
+                                                            g1_xyzz* __restrict__ out_part,
+                                                            g1_xyzz* __restrict__ out_pair) {
+  __shared__ fl ex[2][64][4];
+  const uint32_t b = blockIdx.x, lane = threadIdx.x >> 2, c = threadIdx.x & 3;
+  const uint32_t q = (nseg + 63) / 64;
+  const uint32_t s_lo = lane * q;
+  uint32_t s_hi = s_lo + q;
+  if (s_hi > nseg) s_hi = nseg;
+  const g1_xyzz* sp = seg_pts + 2 * (size_t)b * nseg;
+  fl S = quad_zero(), T = quad_zero(), A = quad_zero();
+#pragma unroll 1
+  for (uint32_t s = s_hi; s > s_lo;) {
+    s--;
+    const fl ls = quad_load(&sp[2 * s]), lt = quad_load(&sp[2 * s + 1]);
+    T = quad_add_call(T, S);  // every segment above s gains one more unit of weight
+    S = quad_add_call(S, ls);
+    A = quad_add_call(A, lt);
+  }
+  // S = sum S_s, T = sum (s - s_lo) S_s, A = sum T_s over the quad's segments; inclusive suffix sums of S over the quads
+  fl suf = S;
+  uint32_t buf = 0;
+#pragma unroll 1
+  for (uint32_t d = 1; d < 64; d <<= 1) {
+    ex[buf][lane][c] = suf;
+    __syncthreads();
+    if (lane + d < 64) suf = quad_add_call(suf, ex[buf][lane + d][c]);
+    buf ^= 1;
+  }
+  const fl all = suf;  // quad 0: the sum of every segment
+  if (lane == 0) suf = quad_zero();
+  // per quad: A + seg_len * (T + q * suf); their sum over the workgroup is the result
+  fl r = quad_add_call(T, quad_mul_small(suf, q));
+  r = quad_add_call(quad_mul_small(r, seg_len), A);
+#pragma unroll 1
+  for (uint32_t d = 32; d >= 1; d >>= 1) {
+    ex[buf][lane][c] = r;
+    __syncthreads();
+    if (lane < d) r = quad_add_call(r, ex[buf][lane + d][c]);
+    buf ^= 1;
+  }
+  if (lane == 0) {
+    if (out_pair) {
+      quad_store(&out_pair[2 * (size_t)b], all);
+      quad_store(&out_pair[2 * (size_t)b + 1], r);
+    } else if (out_part) {
+      quad_store(&out_part[b], r);
+    } else {
+      const g1x p = QD::gather(r);
+      if (c == 0) out[b] = G1S::to_jac_ext(p);
+    }
+  }
+}
+bool quad_reduce_final() {  // CAPGPU_MSM_QUAD_FINAL=0: the one-lane msm_reduce_final
+  static const bool on = [] {
+    const char* e = getenv("CAPGPU_MSM_QUAD_FINAL");
+    return !e || atoi(e) != 0;
+  }();
+  return on;
+}
 // launches the quad tails take: up to this many MSMs (CAPGPU_MSM_QUAD_MAX; 0: never)
 uint32_t quad_max_batch() {
   static const uint32_t v = [] {
@@ -1521,11 +1605,13 @@ uint32_t quad_max_batch() {
   return v;
 }
 
-// ... and of the wide table (24 .. 63 MSMs of 16384 buckets; CAPGPU_MSM_QUAD_MAX_WIDE, 0: never)
+// ... and of the wide table (24 MSMs of 16384 buckets and up; CAPGPU_MSM_QUAD_MAX_WIDE, 0: never).  Beyond 63 MSMs the
+// alternative is the running-sum reduction, whose 64-bucket segments fill the chip only from about 250 MSMs on: launches
+// of 65 - 100 MSMs (batches of 13 - 20 proofs) are 7 - 9 % faster on the quad grid, from about 130 on there is no difference.
 uint32_t quad_max_batch_wide() {
   static const uint32_t v = [] {
     const char* e = getenv("CAPGPU_MSM_QUAD_MAX_WIDE");
-    const int x = e ? atoi(e) : 63;
+    const int x = e ? atoi(e) : 130;  // (measured: tools/gpujob_quadwide2.sh)
     return (uint32_t)(x < 0 ? 0 : x);
   }();
   return v;
@@ -2118,7 +2204,11 @@ struct Tail {
 void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, hipStream_t stream) {
   const uint32_t half = t.half, sb = t.sb, item_len = t.item_len;
   const uint32_t seg_len = t.seg_len ? t.seg_len : reduce_seg_len_for(half, sb);
-  const bool segments = t.seg_len != 0 || use_segment_reduce(half, sb);
+  // small and middling launches: the tails run on quads (see msm_combine_quad) - also where the running sums would
+  // otherwise take over with too few segments to fill the chip (CAPGPU_MSM_QUAD_MAX_WIDE beyond 63)
+  const bool quad = !out_pair && t.seg_len == 0 && use_grid_reduce(half) &&
+                    sb <= (half <= 4096 ? quad_max_batch() : quad_max_batch_wide());
+  const bool segments = t.seg_len != 0 || (use_segment_reduce(half, sb) && !quad);
   const uint32_t total_buckets = half * sb;
   launch("msm_scan_items", msm_scan<1>, dim3(sb), dim3(1024), 0, stream, (const uint32_t*)t.counts, t.item_off, half,
          t.totals, item_len);
@@ -2150,15 +2240,17 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
     const uint32_t rnseg = (rhalf + seg_len - 1) / seg_len;
     launch("msm_reduce_segments", msm_reduce_segments, dim3((rnseg * rsb + kThreads - 1) / kThreads), dim3(kThreads), 0,
            stream, (const g1_xyzz*)t.buckets, rhalf, seg_len, rnseg, rsb, t.partial);
-    launch("msm_reduce_final", msm_reduce_final, dim3(rsb), dim3(64), 0, stream, (const g1_xyzz*)t.partial, seg_len, rnseg,
-           out, out_part, out_pair);
+    if (quad_reduce_final())
+      launch("msm_reduce_final", msm_reduce_final_quad, dim3(rsb), dim3(256), 0, stream, (const g1_xyzz*)t.partial, seg_len,
+             rnseg, out, out_part, out_pair);
+    else
+      launch("msm_reduce_final", msm_reduce_final, dim3(rsb), dim3(64), 0, stream, (const g1_xyzz*)t.partial, seg_len, rnseg,
+             out, out_part, out_pair);
   } else {
     // G lanes per bucket: the smallest power of two that holds a bucket's items with some room for the spread of the
     // bucket sizes (a bucket with more items than lanes loops), so that the shuffle tree is no deeper than needed
     const size_t avg_items = (t.entries / total_buckets + item_len - 1) / item_len;
     const size_t want = avg_items * 3 / 2;
-    // small launches on the narrow table: the tails run on quads (see msm_combine_quad)
-    const bool quad = !out_pair && use_grid_reduce(half) && sb <= (half <= 4096 ? quad_max_batch() : quad_max_batch_wide());
     if (avg_items <= 1 && total_buckets >= 65536) {
       // buckets of (almost always) ONE item - a few dozen MSMs on the wide table: msm_accumulate wrote those buckets
       // itself, and eight lanes per bucket would be five million idle threads (a 40-MSM launch: 300 us of them); one
@@ -2311,8 +2403,13 @@ int msm_run_deep(const MsmBases& bases, const Plan& pl, size_t offset, const fe*
   g1_xyzz* pairs = pts(L.pairs);
   run_tail(t, nullptr, nullptr, pairs, stream);
   // reduction entry e holds buckets e * 4096 ..: total = sum_e T_e + 4096 * sum_e e * S_e
-  launch("msm_reduce_final", msm_reduce_final, dim3(1), dim3(64), 0, stream, (const g1_xyzz*)pairs, kDeepReduceBuckets,
-         (uint32_t)(((size_t)1 << K) / kDeepReduceBuckets), d_out, (g1_xyzz*)nullptr, (g1_xyzz*)nullptr);
+  if (quad_reduce_final())
+    launch("msm_reduce_final", msm_reduce_final_quad, dim3(1), dim3(256), 0, stream, (const g1_xyzz*)pairs,
+           kDeepReduceBuckets, (uint32_t)(((size_t)1 << K) / kDeepReduceBuckets), d_out, (g1_xyzz*)nullptr,
+           (g1_xyzz*)nullptr);
+  else
+    launch("msm_reduce_final", msm_reduce_final, dim3(1), dim3(64), 0, stream, (const g1_xyzz*)pairs, kDeepReduceBuckets,
+           (uint32_t)(((size_t)1 << K) / kDeepReduceBuckets), d_out, (g1_xyzz*)nullptr, (g1_xyzz*)nullptr);
   return 0;
 }
 
