@@ -29,7 +29,7 @@ def binaries(tmp_path_factory, request):
     out = tmp_path_factory.mktemp("f29" + request.param)
     cxx = _cxx()
     bins = {}
-    for name in ("field29_check", "curve29_check"):
+    for name in ("field29_check", "curve29_check", "quad_check"):
         exe = str(out / name)
         flags = ["-DCAP_FL_COLWISE"] if request.param == "colwise" else ["-DCAP_FL_ROWWISE"]
         subprocess.check_call([cxx, "-O1", "-std=c++17"] + flags + [os.path.join(CPP, name + ".cpp"), "-o", exe])
@@ -100,7 +100,7 @@ def sanitized(tmp_path_factory):
     ign = out / "ignore.txt"
     ign.write_text("src:*/field.hpp\nsrc:*/curve.hpp\n")
     bins = {}
-    for name in ("curve29_check", "madd_check"):
+    for name in ("curve29_check", "madd_check", "quad_check"):
         exe = str(out / name)
         subprocess.check_call([CLANG, "-O1", "-std=c++17", "-fsanitize=unsigned-integer-overflow",
                                f"-fsanitize-ignorelist={ign}", "-fno-sanitize-recover=all",
@@ -127,4 +127,12 @@ def test_no_integer_wraps_under_the_sanitizer(sanitized):
 
 def test_curve29_against_saturated_curve_code(binaries):
     out = subprocess.run([binaries["curve29_check"]], capture_output=True, text=True)
+    assert out.returncode == 0 and "bad=0" in out.stdout, out.stdout[-500:] + out.stderr[-500:]
+
+
+def test_quad_point_arithmetic_on_simulated_lanes(binaries):
+    """quad29.hpp - one XYZZ point spread over four lanes, additions four multiplications deep (the tails of the small MSM
+    launches) - on four simulated lanes with the bound assertions on, against the one-lane G1LT::add / dbl: single
+    operations, chains fed back through the memory image, a tree, infinity, P + P and P - P."""
+    out = subprocess.run([binaries["quad_check"]], capture_output=True, text=True)
     assert out.returncode == 0 and "bad=0" in out.stdout, out.stdout[-500:] + out.stderr[-500:]

@@ -263,6 +263,44 @@ def test_msm_special_cases_inside_one_bucket(cg, n, batch):
     cg.srs_free(h)
 
 
+@pytest.mark.parametrize("batch", [1, 5, 40, 140])
+def test_msm_special_cases_between_buckets(cg, batch):
+    """Equal, opposite and empty BUCKET sums: what the tails of a launch - bucket = sum of its items, row / column sums of
+    the bucket grid, the weighted sums, the running sums and their finish - have to get right after the accumulation loop.
+    Small launches run these tails on quads (one point per four lanes, quad29.hpp), whose general case (P + P, P - P) is an
+    out-of-line path that random data never takes.  Bases are drawn from {P, -P, Q, infinity} only and the scalars are
+    small, so neighbouring buckets, whole rows and columns of the grid, and the items of one bucket hold the same point,
+    opposite points or nothing.  batch 1 / 5: narrow table (4096 buckets, 64 x 64 grid); 40: wide table (128 x 128 grid);
+    140: wide table, running sums (msm_reduce_segments / msm_reduce_final)."""
+    p_k, q_k = 1234567, 7654321
+    P_, Q_ = bn.g1_mul(bn.G1_GEN, p_k), bn.g1_mul(bn.G1_GEN, q_k)
+    kinds = [(P_, p_k), (bn.g1_neg(P_), bn.R - p_k), (Q_, q_k), (None, 0)]
+    rng = np.random.default_rng(77)
+    n = 4096
+    which = rng.integers(0, 4, n)
+    which[:600] = 0                                   # 600 copies of P ...
+    bases = cr.points_to_array([kinds[w][0] for w in which])
+    h = cg.srs_upload(bases)
+    scs, want = [], []
+    for b in range(min(batch, 6)):
+        ks = rng.integers(0, 1 << 14, n)
+        ks[:600] = 1 if b % 2 == 0 else 3             # ... in one bucket: its work items are equal points
+        if b == 1:
+            ks[600:] = rng.choice([1, 2, 65, 66, 129, 130, 4097], n - 600)   # neighbours, same row, same column
+        if b == 2:
+            ks[:] = 0
+            ks[[0, 1]] = [1, 2]                       # P in buckets 0 and 1 only: a row sum P + P, nothing else
+        sc = np.zeros((n, 4), np.uint64)
+        sc[:, 0] = ks
+        scs.append(sc)
+        want.append(sum(int(k) * kinds[w][1] for k, w in zip(ks, which)) % bn.R)
+    got = [cg.msm_g1(h, scs[0])] if batch == 1 else cg.msm_g1_batch(h, [scs[i % len(scs)] for i in range(batch)])
+    for i, g in enumerate(got):
+        w = want[i % len(scs)]
+        assert cr.affine_to_ints(cr.g1_to_affine(g)) == (bn.g1_mul(bn.G1_GEN, w) if w else None), (batch, i)
+    cg.srs_free(h)
+
+
 def test_msm_batch_run_in_slices(cg, tau, monkeypatch):
     """Batches whose sort tables would outgrow 32-bit counters are run in slices of the batch (msm.hip: batch_slice);
     at test sizes the slicing is forced through CAPGPU_MSM_SLICE.  Results must not depend on it - for plain batches
