@@ -47,6 +47,21 @@ uint32_t max_tile_log() {
   return v;
 }
 
+// A launch of a few transforms (a single proof's: 1 .. 15 arrays of 2^15 .. 2^16 elements) makes fewer 1024-element tiles
+// than the chip has CUs, and a pass then lasts as long as ONE workgroup takes for its tile: such launches get tiles of 512
+// or 256 elements - twice / four times the workgroups, each half / a quarter as long.  (For launches that fill the chip the
+// smaller tiles are slower - narrower column tiles, more twiddle traffic: round-4 log - and are never chosen.)
+uint32_t tile_log_for(uint32_t log_n, uint32_t count) {
+  static const bool adapt = [] {
+    const char* e = getenv("CAPGPU_NTT_TILE_ADAPT");
+    return !e || atoi(e) != 0;
+  }();
+  uint32_t tl = max_tile_log();
+  if (!adapt) return tl;
+  while (tl > 8 && (((uint64_t)count << log_n) >> tl) < 256) tl--;
+  return tl;
+}
+
 struct PassParams {
   const fe* in;
   fe* out;
@@ -603,6 +618,7 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
     // n = 1: forward is the identity (5^0 = 1); inverse multiplies by 1^-1 = 1.
     return 0;
   }
+  const uint32_t tile_log = tile_log_for(log_n, count);
   // digit split
   uint32_t lg[3] = {0, 0, 0};
   int passes;
@@ -673,7 +689,7 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
   for (int d = 0; d < passes - 1; d++) {
     uint32_t log_len = lg[d];
     uint32_t log_s = log_m - log_len;
-    uint32_t log_c = max_tile_log() > log_len ? max_tile_log() - log_len : 0;
+    uint32_t log_c = tile_log > log_len ? tile_log - log_len : 0;
     if (log_c > log_s) log_c = log_s;
     if (log_c > 4) log_c = 4;
     p.in = cur_in;
@@ -698,7 +714,7 @@ int ntt_run(const NttDomain& dom, const NttSmallTables& small, fe* data, fe* scr
     uint32_t log_len = lg[2];
     uint32_t log_n1 = passes >= 2 ? lg[0] : 0;
     uint32_t log_n2 = passes == 3 ? lg[1] : 0;
-    uint32_t log_c = max_tile_log() > log_len ? max_tile_log() - log_len : 0;
+    uint32_t log_c = tile_log > log_len ? tile_log - log_len : 0;
     if (log_c > log_n1) log_c = log_n1;
     if (log_c > 4) log_c = 4;
     p.in = cur_in;
