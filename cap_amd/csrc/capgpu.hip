@@ -706,10 +706,12 @@ int capgpu_init(const int* device_ids, int n_devices) {
   std::vector<bool> secondary;  // the extra contexts of CAPGPU_CONTEXTS_PER_DEVICE: they share their device's tables
   {
     const char* pe = getenv("CAPGPU_CONTEXTS_PER_DEVICE");
-    // default: ONE bound device gets two contexts - two batches (the halves of a dealt host batch, two gathered batches
-    // of coalesced calls) overlap on it, one's latency-bound launches and host transcript phases under the other's
-    // issue-bound kernels: +1.3 % .. +3.8 % proofs/s at batch 256, +5 % at batch 64; several devices get one context each
-    const int per = pe ? std::min(std::max(atoi(pe), 1), 8) : (ids.size() == 1 ? 2 : 1);
+    // default: ONE bound device gets four contexts - batches overlap on it, one's copies, latency-bound launches and
+    // host transcript phases under the others' issue-bound kernels.  A dealt host batch is cut in two (+1.3 % .. +3.8 %
+    // proofs/s at batch 256, +5 % at batch 64; plonk.hip: deal_max_parts); the gathered batches of coalesced single-proof
+    // calls use all four (64 closed-loop callers: 1040-1090 proofs/s on two contexts, 1130-1186 on four, 1100-1110 on six or
+    // eight).  Secondary contexts share their device's tables; several devices get one context each
+    const int per = pe ? std::min(std::max(atoi(pe), 1), 8) : (ids.size() == 1 ? 4 : 1);
     std::vector<int> x;
     for (int d : ids)
       for (int k = 0; k < per; k++) {

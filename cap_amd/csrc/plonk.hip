@@ -1476,9 +1476,27 @@ static int deal_min() {  // proofs a part must hold at least (smaller batches st
   const int x = e ? atoi(e) : 8;
   return x >= 1 ? x : 8;
 }
+// ... and at most two parts per DEVICE (CAPGPU_DEAL_PARTS_PER_DEVICE): two halves of a batch overlap on a GPU - one's
+// copies, latency-bound launches and transcript steps under the other's issue-bound kernels - but four quarters are smaller
+// launches for nothing (256 host-resident proofs on a device with four contexts: 1274 proofs/s as two parts, 1200 as four).
+// The contexts beyond two are there for the coalescer's gathered batches (capgpu_init).
+static size_t deal_max_parts(size_t contexts) {
+  static const size_t per_device = [] {
+    const char* e = getenv("CAPGPU_DEAL_PARTS_PER_DEVICE");
+    const int x = e ? atoi(e) : 2;
+    return (size_t)(x >= 1 ? x : 2);
+  }();
+  std::vector<int> seen;
+  for (size_t i = 0; i < contexts; i++) {
+    const int d = rt().ctxs[i]->device;
+    if (std::find(seen.begin(), seen.end(), d) == seen.end()) seen.push_back(d);
+  }
+  const size_t devices = std::max<size_t>(seen.size(), 1);
+  return devices * std::min<size_t>(per_device, std::max<size_t>(contexts / devices, 1));
+}
 static int deal(int count, const std::function<int(int first, int cnt)>& part) {
   const size_t S = num_contexts();
-  const size_t parts = std::min<size_t>(S, (size_t)std::max(count / deal_min(), 1));
+  const size_t parts = std::min<size_t>(std::min<size_t>(S, deal_max_parts(S)), (size_t)std::max(count / deal_min(), 1));
   // Mode A (capgpu_plonk_shard_msm): the ranks of the communicator prove the same batch in lock step, so the batch stays
   // whole and on the communicator's context - cut over contexts, one part would run unsharded and which proofs meet in
   // an exchange would depend on a cursor the ranks do not share (pick_context sends it there)
@@ -1489,10 +1507,24 @@ static int deal(int count, const std::function<int(int first, int cnt)>& part) {
   }
   std::vector<int> rcs(parts, CAPGPU_OK);
   std::vector<std::string> errs(parts);
+  // which contexts: the idle ones first, in slot order (a lone caller keeps to the same - warm - contexts call after call;
+  // concurrent callers find different ones), the round-robin cursor for the rest
   const uint32_t start = rt().rr.fetch_add((uint32_t)parts, std::memory_order_relaxed);
+  std::vector<size_t> pick;
+  for (size_t i = 0; i < S && pick.size() < parts; i++) {
+    std::recursive_mutex& m = rt().ctxs[i]->mu;
+    if (m.try_lock()) {
+      m.unlock();
+      pick.push_back(i);
+    }
+  }
+  for (size_t k = 0; pick.size() < parts && k < S; k++) {
+    const size_t i = (start + k) % S;
+    if (std::find(pick.begin(), pick.end(), i) == pick.end()) pick.push_back(i);
+  }
   auto body = [&](size_t i) {
     const int first = (int)((uint64_t)count * i / parts), last = (int)((uint64_t)count * (i + 1) / parts);
-    ScopedCtx sc(*rt().ctxs[(start + i) % S]);
+    ScopedCtx sc(*rt().ctxs[pick[i]]);
     rcs[i] = part(first, last - first);
     if (rcs[i]) errs[i] = last_error();
   };
@@ -1833,23 +1865,44 @@ int capgpu_plonk_prove_ex(uint64_t pk_handle, const uint64_t* wires, const uint6
       second.assign(reqs.begin() + first, reqs.end());
       reqs.resize(first);
     }
+    // Each part's callers are released when THEIR part is done (CAPGPU_COALESCE_EARLY=0: when both are, as before): the
+    // callers of the shorter part come back, are gathered and start on the freed context while the longer part still runs.
+    static const bool early = [] {
+      const char* e = getenv("CAPGPU_COALESCE_EARLY");
+      return !e || atoi(e) != 0;
+    }();
     std::thread helper;
     if (c2)
-      helper = std::thread([&second, c2] {
-        ScopedCtx sc(*c2);
-        Entry elk(*c2);
-        run_coalesced(second);
+      helper = std::thread([&second, c2, &co] {
+        {
+          ScopedCtx sc(*c2);
+          Entry elk(*c2);
+          run_coalesced(second);
+        }
+        if (early) {
+          std::lock_guard<std::mutex> g(co.mu);
+          for (ProveReq* r : second) r->done = true;  // (a request is not touched again once it is marked: its caller returns)
+          co.cv.notify_all();
+        }
       });
     {
       ScopedCtx sc(*c);
       run_coalesced(reqs);  // re-enters the (recursive) context lock this thread holds
     }
     c->mu.unlock();
+    if (early) {
+      lk.lock();
+      for (ProveReq* r : reqs) r->done = true;
+      co.cv.notify_all();
+      lk.unlock();
+    }
     if (helper.joinable()) helper.join();
     lk.lock();
-    for (ProveReq* r : reqs) r->done = true;
-    for (ProveReq* r : second) r->done = true;
-    co.cv.notify_all();
+    if (!early) {
+      for (ProveReq* r : reqs) r->done = true;
+      for (ProveReq* r : second) r->done = true;
+      co.cv.notify_all();
+    }
   }
   if (req.rc != CAPGPU_OK) set_error("%s", req.err.c_str());
   return req.rc;

@@ -25,9 +25,9 @@ from tests import helpers as H
 pytestmark = pytest.mark.gpu
 
 A_SEQ, B_SEQ = 0x1234567890ABCDEF1234567890ABCDEF % bn.R, 0xFEDCBA0987654321FEDCBA % bn.R
-# contexts a plain cg.init(0) gives in this environment: two on one bound device unless CAPGPU_CONTEXTS_PER_DEVICE says
+# contexts a plain cg.init(0) gives in this environment: four on one bound device unless CAPGPU_CONTEXTS_PER_DEVICE says
 # otherwise (the suite is also run with 1)
-AMBIENT_CONTEXTS = max(int(os.environ.get("CAPGPU_CONTEXTS_PER_DEVICE", "2") or 2), 1)
+AMBIENT_CONTEXTS = max(int(os.environ.get("CAPGPU_CONTEXTS_PER_DEVICE", "4") or 4), 1)
 
 
 @pytest.fixture(scope="module")

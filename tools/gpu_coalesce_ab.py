@@ -2,7 +2,8 @@
 """Same-box A/B of the call coalescer under closed-loop callers (round 4): 64 host threads, each calling
 capgpu_plonk_prove_ex for one proof (host wires) again as soon as it has the last one - the reference's rayon pattern
 (src/utils/params_builder.rs:194-226).  CAPGPU_COALESCE_SPLIT = eighths of a gathered batch that go to the first of two
-free contexts (4 = even halves, the round-3 behaviour; 3 = the default).  One JSON line per configuration, each in a
+free contexts (4 = even halves, the round-3 behaviour; 3 = the default); CAPGPU_COALESCE_EARLY = 0: the callers of both
+parts of a cut batch are released together (the behaviour before the second half of round 4).  One JSON line per configuration, each in a
 process of its own.
     python tools/gpu_coalesce_ab.py [calls_per_thread]"""
 import ctypes
@@ -85,8 +86,12 @@ if __name__ == "__main__":
         child(int(sys.argv[sys.argv.index("--child") + 1]))
     else:
         per = sys.argv[1] if len(sys.argv) > 1 else "8"
-        for name, env in (("even_halves", {"CAPGPU_COALESCE_SPLIT": "4"}), ("three_eighths", {"CAPGPU_COALESCE_SPLIT": "3"}),
-                          ("quarter", {"CAPGPU_COALESCE_SPLIT": "2"}), ("one_context", {"CAPGPU_CONTEXTS_PER_DEVICE": "1"})):
+        for name, env in (("late_release", {"CAPGPU_COALESCE_EARLY": "0"}), ("default", {}),
+                          ("even_halves", {"CAPGPU_COALESCE_SPLIT": "4"}), ("quarter", {"CAPGPU_COALESCE_SPLIT": "2"}),
+                          ("three_contexts", {"CAPGPU_CONTEXTS_PER_DEVICE": "3"}),
+                          ("four_contexts", {"CAPGPU_CONTEXTS_PER_DEVICE": "4"}),
+                          ("one_context", {"CAPGPU_CONTEXTS_PER_DEVICE": "1"}), ("late_release", {"CAPGPU_COALESCE_EARLY": "0"}),
+                          ("default", {})):
             e = dict(os.environ)
             e.update(env)
             e["CAPGPU_AB_NAME"] = name
