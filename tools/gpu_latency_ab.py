@@ -5,6 +5,7 @@ benches/transfer.rs:103-105), small batches, and single MSMs, with the round-4 m
   CAPGPU_MSM_GRID_REDUCE     2-D grid bucket reduction for small batches (0 = bit planes)
   CAPGPU_PERM_INV_ON_DEVICE  round 2's inversion on a device thread (1) instead of the host (0)
   CAPGPU_MSM_SMALL_C / _MAX  window bits of the small-launch table (0 = none) and the largest launch, in MSMs, that takes it
+  CAPGPU_MSM_QUAD_MAX / _QUAD_MAX_WIDE / _QUAD_FINAL   the tails of small launches on quads (0 = the one-lane kernels)
 Every configuration runs in a process of its own (the switches are read once).  One JSON line per configuration.
 
     python tools/gpu_latency_ab.py [--quick]          (driver)
@@ -30,6 +31,8 @@ CONFIGS = [
                       "CAPGPU_MSM_SMALL_C": "0"}),
     ("round4_small_table_c11", {"CAPGPU_MSM_SMALL_C": "11"}),
     ("round4_small_table_c12", {"CAPGPU_MSM_SMALL_C": "12"}),
+    ("round4_one_lane_tails", {"CAPGPU_MSM_QUAD_MAX": "0", "CAPGPU_MSM_QUAD_MAX_WIDE": "0", "CAPGPU_MSM_QUAD_FINAL": "0",
+                               "CAPGPU_NTT_TILE_ADAPT": "0"}),
     ("round4", {}),
 ]
 R3 = {"CAPGPU_GRAPH_MAX_BATCH": "0", "CAPGPU_MSM_GRID_REDUCE": "0", "CAPGPU_PERM_INV_ON_DEVICE": "1", "CAPGPU_MSM_SMALL_C": "0"}
@@ -93,7 +96,7 @@ def main():
     if "--child" in sys.argv:
         return child()
     quick = "--quick" in sys.argv
-    for name, env in ([CONFIGS[0], CONFIGS[4]] + CONFIGS[-1:] if quick else CONFIGS):
+    for name, env in ([CONFIGS[0], CONFIGS[4]] + CONFIGS[-2:] if quick else CONFIGS):
         e = dict(os.environ)
         e.update(env)
         e["CAPGPU_AB_NAME"] = name
