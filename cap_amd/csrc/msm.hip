@@ -1846,7 +1846,7 @@ uint32_t reduce_seg_len(uint32_t half) {
   if (half >= 16384) return 64;  // wide windows: 256 segments per entry keep msm_reduce_final at 4 segments per lane
   return half >= 1024 ? 16u : (half >= 64 ? half / 64 : 1u);
 }
-// ... sized to the launch (round-4 experiment, CAPGPU_MSM_SEG_TUNE=1; off by default).  Every msm_reduce_segments thread
+// ... sized to the launch (round-4 experiment; see the default below).  Every msm_reduce_segments thread
 // does the same work - 2 * seg_len dependent additions - and the kernel holds two waves per SIMD (226 VGPRs): 131072
 // threads at a time; a launch of 1280 MSMs with 256 segments each is 2.5 such "rounds".  Choosing the segment length that
 // minimises rounds * 2 * seg_len plus the one-wave finish (1280 MSMs: 82 buckets, 200 segments; 256 MSMs: 32) was
@@ -1854,12 +1854,15 @@ uint32_t reduce_seg_len(uint32_t half) {
 // (tools/gpujob_segtune.sh) - the chip does not run this kernel in lock-step rounds.
 constexpr uint32_t kSegLenMin = 32, kSegLenMax = 128;
 uint32_t reduce_seg_len_for(uint32_t half, uint32_t sb) {
-  static const bool tune = [] {
+  // CAPGPU_MSM_SEG_TUNE: 1 = every launch, 0 = none; default: launches of up to 512 MSMs, whose segments all fit the chip at
+  // once - there the shorter chains do pay (batch 64, 320-MSM launches: 52.1 -> 50.9 ms, tools/gpujob_segtune2.sh; batches of
+  // 27 - 51: no difference either way)
+  static const int tune = [] {
     const char* e = getenv("CAPGPU_MSM_SEG_TUNE");
-    return e && atoi(e) != 0;
+    return e ? (atoi(e) != 0 ? 1 : 0) : -1;
   }();
   const uint32_t base = reduce_seg_len(half);
-  if (!tune || half < 16384 || sb == 0) return base;
+  if (tune == 0 || (tune < 0 && sb > 512) || half < 16384 || sb == 0) return base;
   const uint64_t slots = 2ull * 1024 * 64;  // threads of msm_reduce_segments the chip holds at once
   uint32_t best = base;
   uint64_t best_cost = ~0ull;
