@@ -56,15 +56,19 @@ def kernel_blocks(lines, mangled_re):
     start = [i for i, ln in enumerate(lines) if re.match(mangled_re, ln)][0]
     end = [i for i in range(start, len(lines)) if lines[i].strip().startswith(".Lfunc_end")][0]
     blocks, cur = [], None
-    cur = {"label": "entry", "header": False, "marked": False, "ops": []}
+    cur = {"label": "entry", "header": False, "marked": False, "ops": [], "loop": None}
     blocks.append(cur)
     for ln in lines[start + 1:end]:
         s = ln.strip()
         if re.match(r"^\.LBB\d+_\d+:", s) or s.startswith("; %bb."):
-            cur = {"label": s.split(":")[0].replace("; ", ""), "header": "Loop Header: Depth=1" in s, "marked": False, "ops": []}
+            inside = re.search(r"in Loop: Header=(BB\d+_\d+)", s)
+            cur = {"label": s.split(":")[0].replace("; ", ""), "header": "Loop Header: Depth=" in s, "marked": False, "ops": [],
+                   "loop": ".L" + inside.group(1) if inside else None}
             blocks.append(cur)
         elif "madd_acc: common path" in s:
             cur["marked"] = True
+        elif s.startswith(";") and "Loop Header: Depth=" in s:   # (a nested loop's header comment follows its label line)
+            cur["header"] = True
         elif s and not s.startswith((".", ";", "//")):
             cur["ops"].append(s.split()[0])
     return blocks
@@ -86,10 +90,13 @@ blocks = kernel_blocks(msm, r"^_ZN3cap12_GLOBAL__N_114msm_accumulate.*:\s*")
 # G1L::madd_acc marks with an asm comment - everything after the test.  (Round 3 first took "the largest block" here, which
 # is the general addition G1L::add_mixed - the fallback for a bucket still at infinity - with 64 x 32-bit products that the
 # common path does not have.)
-ih = [i for i, b in enumerate(blocks) if b["header"]][0]
 im = [i for i, b in enumerate(blocks) if b["marked"]]
 assert len(im) == 1, "expected exactly one marked block in msm_accumulate"
 im = im[0]
+# the header of the loop over a work item's entries: the innermost loop the marked block belongs to (since the kernel became
+# a persistent launch that loop sits inside the loop over chunks of items, and it has small loops of its own inside - the
+# exact zero test's - which the common path does not enter)
+ih = [i for i, b in enumerate(blocks) if b["label"] == blocks[im]["loop"]][0]
 ip = max(i for i in range(ih, im) if sum(op.startswith("v_mad_u64") for op in blocks[i]["ops"]) >= 300)
 path = [b for b in blocks[ih:ip] if len(b["ops"]) < 150 and "v_mad_i64_i32" not in b["ops"]] + [blocks[ip], blocks[im]]
 mix = mix_of(path)
@@ -116,8 +123,9 @@ def shares(lines, mangled_re, name):
 ntt = assembly("ntt.hip")
 plonk = assembly("plonk.hip")
 others = {}
-for lines, pat, name in ((ntt, r"^_ZN3cap\S*12ntt_col_pass\S*:\s*", "ntt_col_pass"),
-                         (ntt, r"^_ZN3cap\S*12ntt_row_pass\S*:\s*", "ntt_row_pass"),
+# (the one-tile-per-workgroup instantiations of the NTT passes: template argument false)
+for lines, pat, name in ((ntt, r"^_ZN3cap\S*12ntt_col_passILb0E\S*:\s*", "ntt_col_pass"),
+                         (ntt, r"^_ZN3cap\S*12ntt_row_passILb0E\S*:\s*", "ntt_row_pass"),
                          (plonk, r"^_ZN3cap\S*10k_quotient\S*:\s*", "k_quotient"),
                          (msm, r"^_ZN3cap12_GLOBAL__N_119msm_reduce_segments\S*:\s*", "msm_reduce_segments")):
     try:
