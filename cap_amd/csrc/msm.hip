@@ -831,6 +831,7 @@ __global__ __launch_bounds__(1024) void msm_item_bases(const uint32_t* __restric
   if (threadIdx.x == 0) {
     item_base[batch] = carry_s;
     item_base[batch + 1] = 0;  // chunk counter of a dynamic msm_accumulate launch
+    item_base[batch + 2] = 0;  // length of msm_combine's list of heavy buckets
   }
 }
 
@@ -1105,11 +1106,20 @@ __global__ __launch_bounds__(kThreads) void msm_combine(const g1_xyzz* __restric
                                                         const uint32_t* __restrict__ item_off,
                                                         const uint32_t* __restrict__ item_base, uint32_t half,
                                                         uint32_t total_buckets, uint32_t item_len,
-                                                        g1_xyzz* __restrict__ buckets) {
+                                                        g1_xyzz* __restrict__ buckets, uint32_t heavy_min,
+                                                        uint32_t* __restrict__ heavy_list,
+                                                        uint32_t* __restrict__ heavy_count) {
   uint32_t gb = blockIdx.x * blockDim.x + threadIdx.x;
   if (gb >= total_buckets) return;
   uint32_t items = (counts[gb] + item_len - 1) / item_len;
   if (items == 1) return;  // written by msm_accumulate
+  // A bucket of many items (a skewed scalar distribution; the deep table's top window with its digits spread over the
+  // bucket range: 66 items in one bucket of every 512) is not walked here - one long lane per wave, 5.7 ms at 2^24 points -
+  // but handed to msm_combine_heavy, 32 lanes per bucket.
+  if (heavy_list && items >= heavy_min) {
+    heavy_list[atomicAdd(heavy_count, 1u)] = gb;
+    return;
+  }
   uint32_t first = item_base[gb / half] + item_off[gb];
   g1x acc = G1L::inf();
   if (items) {
@@ -1377,6 +1387,16 @@ __device__ __forceinline__ void quad_store(g1_xyzz* p, const fl& v) {
 }
 // the value of the quad `d` quads up the wave
 __device__ __forceinline__ fl quad_shfl_down(const fl& a, int d) { return shfl_down_fl(a, 4 * d); }
+// the additions as calls (nine registers per operand: they travel in registers): one copy of the code for all the call
+// sites of a kernel
+__device__ __noinline__ fl quad_add_call(fl a, fl b) {
+  QD::add(a, b, QuadSlow());
+  return a;
+}
+__device__ __noinline__ fl quad_dbl_call(fl a) {
+  QD::dbl(a);
+  return a;
+}
 
 // bucket = sum of its work items, GQ quads per bucket (msm_combine_wave's job: there eight lanes hold eight items and a
 // three-level tree adds them; here two quads - the same eight lanes - take the items in turn and one level joins them)
@@ -1412,6 +1432,43 @@ __global__ __launch_bounds__(kThreads) void msm_combine_quad(const g1_xyzz* __re
     if (lane < (uint32_t)d) QD::add(acc, o, QuadSlow());
   }
   if (lane == 0 && items != 1) quad_store(&buckets[gb], acc);
+}
+
+// the buckets msm_combine left on its list (those of kHeavyItems items and more): eight quads per bucket, a fixed grid that
+// walks the list
+constexpr uint32_t kHeavyItems = 12;
+__global__ __launch_bounds__(kThreads) void msm_combine_heavy(const g1_xyzz* __restrict__ item_pts,
+                                                              const uint32_t* __restrict__ counts,
+                                                              const uint32_t* __restrict__ item_off,
+                                                              const uint32_t* __restrict__ item_base, uint32_t half,
+                                                              uint32_t item_len, const uint32_t* __restrict__ heavy_list,
+                                                              const uint32_t* __restrict__ heavy_count,
+                                                              g1_xyzz* __restrict__ buckets) {
+  constexpr uint32_t GQ = 8;
+  const uint32_t quad = (blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+  const uint32_t group = quad / GQ, lane = quad % GQ, groups = (gridDim.x * blockDim.x) / (4 * GQ);
+  const uint32_t n_heavy = *heavy_count;
+  for (uint32_t w = group; w < n_heavy; w += groups) {  // (uniform over the 32 lanes of a group)
+    const uint32_t gb = heavy_list[w];
+    const uint32_t items = (counts[gb] + item_len - 1) / item_len;
+    const uint32_t first = item_base[gb / half] + item_off[gb];
+    fl acc = lane < items ? quad_load(&item_pts[first + lane]) : quad_zero();
+    if (lane + GQ < items) {
+      fl cur = quad_load(&item_pts[first + lane + GQ]);
+#pragma unroll 1
+      for (uint32_t j = lane + GQ; j < items; j += GQ) {
+        const fl nxt = quad_load(&item_pts[first + (j + GQ < items ? j + GQ : j)]);
+        acc = quad_add_call(acc, cur);
+        cur = nxt;
+      }
+    }
+#pragma unroll 1
+    for (int d = GQ / 2; d >= 1; d >>= 1) {
+      const fl o = quad_shfl_down(acc, d);
+      if (lane < (uint32_t)d) acc = quad_add_call(acc, o);
+    }
+    if (lane == 0) quad_store(&buckets[gb], acc);
+  }
 }
 
 // msm_reduce_grid on quads: `slices` quads per row / column sum
@@ -1512,16 +1569,8 @@ __global__ __launch_bounds__(4 * TERMS) void msm_reduce_grid_final_quad(const g1
   }
 }
 // msm_reduce_final on quads: 64 quads per entry (one workgroup of 256 lanes), the lane loop of the one-lane kernel per
-// quad, the suffix sums and the closing sum through LDS.  The additions are calls here (nine registers per operand: they
-// travel in registers), one copy of the code for the kernel's eight call sites.
-__device__ __noinline__ fl quad_add_call(fl a, fl b) {
-  QD::add(a, b, QuadSlow());
-  return a;
-}
-__device__ __noinline__ fl quad_dbl_call(fl a) {
-  QD::dbl(a);
-  return a;
-}
+// quad, the suffix sums and the closing sum through LDS.  The additions are calls here (quad_add_call), one copy of the
+// code for the kernel's eight call sites.
 __device__ fl quad_mul_small(const fl& p, uint32_t k) {
   fl r = quad_zero();
   bool started = false;
@@ -1726,18 +1775,27 @@ struct Plan {
 // Scalars are < 2^254 (canonical; msm_digits_local folds larger inputs by r first), so the top window of the deep table
 // holds top_bits = 254 - c (W - 1) of its c bits and its digit is at most 2^top_bits (with the carry from below).
 // Shifted left by (c - 1) - top_bits it still fits the 2^(c-1) buckets and lands on every 2^shift-th of them.
-// OFF by default (CAPGPU_MSM_DEEP_SHIFT=1 switches it on): measured in round 4 at 2^24 points (tools/gpujob_deepshift.sh,
-// profiles/deepshift_r04.jsonl) the shift does what it was meant to - msm_deep_sort<1> 2.21 -> 1.08 ms at c = 22, the
-// crowded bins gone - and c = 22 does shorten the accumulation (15.34 -> 14.38 ms: 12 digits instead of 13), but the
-// 4096 buckets that hold the top window's n / 4096 entries each are now one in every 512 instead of 4096 in a row, and
-// msm_combine - one thread per bucket, serial over the bucket's ~66 work items - runs one long lane per wave: 0.2 -> 5.7
-// ms.  With a lane-parallel combine for those buckets the total would be ~18.0 ms against 18.3 ms for c = 20 unshifted
-// (2^21 buckets cost +0.5 ms in sorts and reductions): not pursued.  c = 20 with the shift: 18.87 against 18.33 ms.
-uint32_t deep_top_shift(uint32_t c, uint32_t windows) {
+// First measured in round 4 at 2^24 points (tools/gpujob_deepshift.sh, profiles/deepshift_r04.jsonl): the shift does what
+// it was meant to - msm_deep_sort<1> 2.21 -> 1.08 ms at c = 22, the crowded bins gone - and c = 22 does shorten the
+// accumulation (12 digits instead of 13), but the 4096 buckets that hold the top window's n / 4096 entries each are now one
+// in every 512 instead of 4096 in a row, and msm_combine - one thread per bucket, serial over the bucket's ~66 work items -
+// ran one long lane per wave: 0.2 -> 5.7 ms.  With those buckets on a list of their own, 32 lanes each (msm_combine_heavy:
+// 0.05 ms), c = 22 with the shift is the default from 2^23 points on: 2^24 points 18.17 -> 17.25 ms, 2^23 9.75 -> 9.43 ms,
+// 2^22 5.34 -> 5.29 ms (tools/gpujob_deepwide.sh; the 2^21 buckets cost +0.5 ms in sorts and reductions).  c = 20 with the
+// shift: 18.87 against 18.33 ms - the shift is for the 22-bit windows only.
+bool deep_wide_default() {  // CAPGPU_MSM_DEEP_WIDE=0: c = 20, unshifted, for every table (the plan until the end of round 4)
   static const bool on = [] {
-    const char* e = getenv("CAPGPU_MSM_DEEP_SHIFT");
-    return e && atoi(e) != 0;
+    const char* e = getenv("CAPGPU_MSM_DEEP_WIDE");
+    return !e || atoi(e) != 0;
   }();
+  return on;
+}
+uint32_t deep_top_shift(uint32_t c, uint32_t windows) {
+  static const int env = [] {
+    const char* e = getenv("CAPGPU_MSM_DEEP_SHIFT");
+    return e ? (atoi(e) != 0 ? 1 : 0) : -1;
+  }();
+  const bool on = env >= 0 ? env == 1 : (c == 22 && deep_wide_default());  // default: with the 22-bit windows only
   const int top_bits = 254 - (int)c * ((int)windows - 1);
   if (!on || top_bits <= 0 || top_bits >= (int)c - 1) return 0;
   return (uint32_t)((int)c - 1 - top_bits);
@@ -1747,7 +1805,10 @@ uint32_t deep_c(size_t n) {
     const int x = atoi(e);
     if (x >= 17 && x <= 22) return (uint32_t)x;  // (c = 16 has 17 windows: one more than the entry's window field holds)
   }
-  (void)n;
+  // c = 22 with the shifted top window for tables of 2^23 points and more (CAPGPU_MSM_DEEP_C / _DEEP_SHIFT override both):
+  // 12 digits per scalar instead of 13; below that the sorts and reductions of 2^21 buckets cost what the shorter
+  // accumulation saves (see deep_top_shift)
+  if (n >= ((size_t)1 << 23) && deep_wide_default()) return 22u;
   return 20u;  // (c = 17 measured at 2^19 .. 2^21 points: 1.57 / 2.20 / 3.75 ms against 1.47 / 2.07 / 3.26 ms for c = 20)
 }
 bool deep_enabled() {
@@ -1953,7 +2014,7 @@ WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t sb, uint32_t
   }
   L.max_items = per * sb / choose_item_len(per * sb, half * sb) + half * sb;  // sum ceil(cnt/L) <= entries/L + buckets
   L.item_off = o;    o = align_up(o + sizeof(uint32_t) * half * sb, 256);
-  L.item_base = o;   o = align_up(o + sizeof(uint32_t) * ((size_t)sb + 2), 256);
+  L.item_base = o;   o = align_up(o + sizeof(uint32_t) * ((size_t)sb + 3), 256);
   L.totals = o;      o = align_up(o + sizeof(uint32_t) * sb, 256);
   L.item_bucket = o; o = align_up(o + sizeof(uint32_t) * L.max_items, 256);
   L.item_sub = o;    o = align_up(o + sizeof(uint32_t) * L.max_items, 256);
@@ -2009,7 +2070,7 @@ DeepLayout deep_layout(const Plan& pl, size_t n) {
   L.partial = take(sizeof(g1_xyzz) * (size_t)L.sbp * 2 * (kDeepEntryBuckets / kDeepSegLen));  // (S, T) per segment
   L.pairs = take(sizeof(g1_xyzz) * 2 * (nb / kDeepReduceBuckets));
   L.item_off = take(4 * nb);
-  L.item_base = take(4 * ((size_t)L.sbp + 2));
+  L.item_base = take(4 * ((size_t)L.sbp + 3));
   L.totals = take(4 * (size_t)L.sbp);
   L.item_bucket = take(4 * L.max_items);
   L.item_sub = take(4 * L.max_items);
@@ -2235,10 +2296,25 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
            (const uint32_t*)t.item_off, (const uint32_t*)t.item_base, (const uint32_t*)t.item_bucket,
            (const uint32_t*)t.item_sub, t.per, half, sb, item_len, dynamic ? 1u : 0u, t.item_pts, t.buckets);
   }
-  if (segments) {
+  // bucket = sum of its items, one thread per bucket; the few buckets of many items go to a list (msm_accumulate's item
+  // list, dead by now, holds it; its length sits behind the item bases) and get 32 lanes each
+  auto combine_per_bucket = [&] {
+    static const bool heavy = [] {
+      const char* e = getenv("CAPGPU_MSM_HEAVY_COMBINE");
+      return !e || atoi(e) != 0;
+    }();
+    uint32_t* heavy_list = heavy && t.max_items > 0 ? t.item_bucket : nullptr;
+    uint32_t* heavy_count = t.item_base + sb + 2;
     launch("msm_combine", msm_combine, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0, stream,
            (const g1_xyzz*)t.item_pts, (const uint32_t*)t.counts, (const uint32_t*)t.item_off,
-           (const uint32_t*)t.item_base, half, total_buckets, item_len, t.buckets);
+           (const uint32_t*)t.item_base, half, total_buckets, item_len, t.buckets, kHeavyItems, heavy_list, heavy_count);
+    if (heavy_list)
+      launch("msm_combine_heavy", msm_combine_heavy, dim3(512), dim3(kThreads), 0, stream, (const g1_xyzz*)t.item_pts,
+             (const uint32_t*)t.counts, (const uint32_t*)t.item_off, (const uint32_t*)t.item_base, half, item_len,
+             (const uint32_t*)heavy_list, (const uint32_t*)heavy_count, t.buckets);
+  };
+  if (segments) {
+    combine_per_bucket();
     const uint32_t rhalf = t.reduce_half ? t.reduce_half : half, rsb = total_buckets / rhalf;
     const uint32_t rnseg = (rhalf + seg_len - 1) / seg_len;
     launch("msm_reduce_segments", msm_reduce_segments, dim3((rnseg * rsb + kThreads - 1) / kThreads), dim3(kThreads), 0,
@@ -2258,9 +2334,7 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
       // buckets of (almost always) ONE item - a few dozen MSMs on the wide table: msm_accumulate wrote those buckets
       // itself, and eight lanes per bucket would be five million idle threads (a 40-MSM launch: 300 us of them); one
       // thread per bucket walks the rare second item
-      launch("msm_combine", msm_combine, dim3((total_buckets + kThreads - 1) / kThreads), dim3(kThreads), 0, stream,
-             (const g1_xyzz*)t.item_pts, (const uint32_t*)t.counts, (const uint32_t*)t.item_off,
-             (const uint32_t*)t.item_base, half, total_buckets, item_len, t.buckets);
+      combine_per_bucket();
     } else if (quad && want <= 32) {
       // (the same 8, 16 or 32 lanes per bucket as msm_combine_wave would take: two, four or eight quads)
       const uint32_t GQ = want <= 8 ? 2u : (want <= 16 ? 4u : 8u);

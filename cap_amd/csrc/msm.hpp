@@ -53,14 +53,15 @@ struct MsmBases {
   // per-bucket combine of four times as many work items outweighs the shorter bucket reduction; msm.hip: small_c).
   uint32_t c0 = 0, windows0 = 0;
   g1_affine* ext0 = nullptr;
-  // Third table for long single MSMs (>= 2^20 points, see msm.hip "deep sort"): windows of 18-22 bits on ONE bucket set
-  // shared by all points - 12-15 digits per scalar instead of 17.  Null when not built.
+  // Third table for long single MSMs (>= 2^19 points, see msm.hip "deep sort"): windows of 20 bits (22 from 2^23 points on)
+  // on ONE bucket set shared by all points - 13 (12) digits per scalar instead of 17.  Null when not built.
   uint32_t c3 = 0, windows3 = 0;
   g1_affine* ext3 = nullptr;
-  // Experiment (CAPGPU_MSM_DEEP_SHIFT=1; 0 by default): the top window of the deep table holds only 254 - c3 (W3 - 1)
-  // scalar bits, so its digits all fall into the lowest 2^top_bits buckets - 32 of the 16384 sort bins at c3 = 22.  With
-  // the shift the table stores the top window's points 2^top_shift3 times smaller and the digit is multiplied by
-  // 2^top_shift3: the same multiples, spread over the whole bucket range (msm.hip: deep_top_shift, with the measurement).
+  // With 22-bit windows (tables of >= 2^23 points; CAPGPU_MSM_DEEP_SHIFT forces it on or off): the top window of the deep
+  // table holds only 254 - c3 (W3 - 1) scalar bits, so its digits would all fall into the lowest 2^top_bits buckets - 32 of
+  // the 16384 sort bins at c3 = 22.  With the shift the table stores the top window's points 2^top_shift3 times smaller and
+  // the digit is multiplied by 2^top_shift3: the same multiples, spread over the whole bucket range (msm.hip:
+  // deep_top_shift, with the measurement).
   uint32_t top_shift3 = 0;
 };
 
