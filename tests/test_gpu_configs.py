@@ -1,6 +1,6 @@
 """BASELINE.json's configurations at their full sizes, under `-m gpu` (round-1 VERDICT "untested configs"):
 
-* config 5 and the whole single-MSM path above 2^18 points (now a batch of sub-MSMs on the c = 15 table): 2^19, 2^20, 2^22 and 2^24 points,
+* config 5 and the whole single-MSM path above 2^18 points (the deep plan: one bucket set, 20- or 22-bit windows): 2^19, 2^20, 2^22 and 2^24 points,
   checked exactly with the known-scalar identity  sum k_i [a + i b]G = [a sum k_i + b sum i k_i] G  (SURVEY 8c.3);
 * the same MSM cut into 8 point ranges on one device (what 8 ranks do) against the unsharded result;
 * n = 2^16 proofs: the reference's own bench depth (TREE_DEPTH = 26, src/bench_utils/mod.rs:42, benches/transfer.rs:54-73)
@@ -39,6 +39,16 @@ def test_single_msm_above_2p18_known_scalar_identity(cg, log_n):
     sc[2] = cr.int_to_limbs(bn.R - 1)
     got = cr.affine_to_ints(cr.g1_to_affine(cg.msm_g1(h, sc)))
     assert got == expected_affine_seq(sc)
+    if log_n == 24:
+        # config 5's plan, pinned: one bucket set, 22-bit windows (12 digits), the top window's digits spread over it
+        p = cg.msm_plan(h, n, 1)
+        assert (p["c"], p["windows"], p["sort"]) == (22, 12, "deep"), p
+        # ... and a shorter range of the same table (the crowded buckets of the shifted top window are then fewer entries
+        # each: the list of heavy buckets is shorter or empty) against the same identity
+        m, off = (1 << 23) + 4321, 99
+        got = cr.affine_to_ints(cr.g1_to_affine(cg.msm_g1(h, sc[:m], offset=off)))
+        s0, s1 = bu.weighted_scalar_sums(sc[:m], off)
+        assert got == bn.g1_mul(bn.G1_GEN, (A_SEQ * s0 + B_SEQ * s1) % bn.R)
     if log_n <= 20:
         # ragged size + base offset on the same table: the tail tile is partly empty
         m, off = n - 12345, 777
