@@ -136,3 +136,13 @@ def test_quad_point_arithmetic_on_simulated_lanes(binaries):
     operations, chains fed back through the memory image, a tree, infinity, P + P and P - P."""
     out = subprocess.run([binaries["quad_check"]], capture_output=True, text=True)
     assert out.returncode == 0 and "bad=0" in out.stdout, out.stdout[-500:] + out.stderr[-500:]
+
+
+def test_host_multiplication_and_inversion_match_the_device_forms(tmp_path):
+    """field.hpp on the host: 64-bit-limb CIOS and the Euclidean inversion (the prover's scalars between the rounds, the
+    verifier) against the 32-bit-limb CIOS and the Fermat inversion the device code runs - the same bits for any 256-bit
+    inputs, both fields, edge values included."""
+    exe = str(tmp_path / "field_host_check")
+    subprocess.check_call([_cxx(), "-O2", "-std=c++17", os.path.join(CPP, "field_host_check.cpp"), "-o", exe])
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0 and "bad=0" in out.stdout, out.stdout[-500:] + out.stderr[-500:]
