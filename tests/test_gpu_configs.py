@@ -41,8 +41,12 @@ def test_single_msm_above_2p18_known_scalar_identity(cg, log_n):
     assert got == expected_affine_seq(sc)
     if log_n == 24:
         # config 5's plan, pinned: one bucket set, 22-bit windows (12 digits), the top window's digits spread over it
+        import os
         p = cg.msm_plan(h, n, 1)
-        assert (p["c"], p["windows"], p["sort"]) == (22, 12, "deep"), p
+        if os.environ.get("CAPGPU_MSM_DEEP_WIDE", "1") != "0" and not os.environ.get("CAPGPU_MSM_DEEP_C"):
+            assert (p["c"], p["windows"], p["sort"]) == (22, 12, "deep"), p
+        else:                                            # (the suite is also run with the earlier plan forced)
+            assert p["sort"] == "deep", p
         # ... and a shorter range of the same table (the crowded buckets of the shifted top window are then fewer entries
         # each: the list of heavy buckets is shorter or empty) against the same identity
         m, off = (1 << 23) + 4321, 99
