@@ -859,19 +859,22 @@ __global__ __launch_bounds__(1024) void msm_sort_items(const uint32_t* __restric
   // Even batch entries list their items longest first, odd ones shortest first.  Workgroups go to the 8 XCDs
   // round-robin and a batch entry's item range is a whole number of workgroups at the prover's sizes, so with one
   // direction only, XCD 0 would receive the longest workgroup of every entry and XCD 7 the shortest.
-  if (threadIdx.x == 0) {
-    uint32_t acc = 0;
-    if (b & 1) {
-      for (int l = 0; l <= (int)kMaxItemLen; l++) {
-        cursor[l] = acc;
-        acc += hist[l];
-      }
-    } else {
-      for (int l = (int)kMaxItemLen; l >= 0; l--) {
-        cursor[l] = acc;
-        acc += hist[l];
-      }
+  // (an exclusive scan of the 513 length classes by the whole workgroup - one thread walking them took 15 of the
+  // kernel's 22-32 us, on the path of every launch)
+  {
+    __shared__ uint32_t scan[1024];
+    const uint32_t t = threadIdx.x;
+    const uint32_t l = (b & 1) ? t : kMaxItemLen - t;  // the class this thread holds, in listing order (t > 512: none)
+    const uint32_t v = t <= kMaxItemLen ? hist[l] : 0;
+    scan[t] = v;
+    __syncthreads();
+    for (uint32_t d = 1; d < 1024; d <<= 1) {
+      const uint32_t add = t >= d ? scan[t - d] : 0;
+      __syncthreads();
+      scan[t] += add;
+      __syncthreads();
     }
+    if (t <= kMaxItemLen) cursor[l] = scan[t] - v;
   }
   __syncthreads();
   const uint32_t ib = item_base[b];
