@@ -77,6 +77,10 @@ extern "C" {
     pub fn capgpu_memcpy_h2d(dev_dst: *mut c_void, host_src: *const c_void, bytes: usize) -> c_int;
     pub fn capgpu_memcpy_d2h(host_dst: *mut c_void, dev_src: *const c_void, bytes: usize) -> c_int;
     pub fn capgpu_sync() -> c_int;
+    pub fn capgpu_timer_begin() -> c_int;
+    pub fn capgpu_timer_end(ms_out: *mut f64) -> c_int;
+    pub fn capgpu_context_count(count_out: *mut c_int) -> c_int;
+    pub fn capgpu_physical_device_count(count_out: *mut c_int) -> c_int;
     pub fn capgpu_set_stream(hip_stream: *mut c_void) -> c_int;
     // ---- SRS
     pub fn capgpu_srs_upload(bases: *const c_void, n: usize, stride_bytes: usize, coords_montgomery: c_int,

@@ -825,6 +825,9 @@ void capgpu_shutdown(void) {
       }
       c.pool.reset();
       c.prove_graphs.reset();
+      if (c.tm0) hipEventDestroy(c.tm0);
+      if (c.tm1) hipEventDestroy(c.tm1);
+      c.tm0 = c.tm1 = nullptr;
       if (c.own_stream) hipStreamDestroy(c.own_stream);
       if (c.copy_stream) hipStreamDestroy(c.copy_stream);
       c.own_stream = c.stream = c.copy_stream = nullptr;
@@ -840,6 +843,17 @@ void capgpu_shutdown(void) {
 int capgpu_device_count(int* count_out) {
   if (!count_out) return CAPGPU_ERR_INVALID_ARG;
   *count_out = rt().initialised.load() ? (int)num_contexts() : 0;
+  return CAPGPU_OK;
+}
+int capgpu_context_count(int* count_out) { return capgpu_device_count(count_out); }
+int capgpu_physical_device_count(int* count_out) {
+  if (!count_out) return CAPGPU_ERR_INVALID_ARG;
+  *count_out = 0;
+  if (!rt().initialised.load()) return CAPGPU_OK;
+  std::vector<int> seen;
+  for (auto& c : rt().ctxs)
+    if (std::find(seen.begin(), seen.end(), c->device) == seen.end()) seen.push_back(c->device);
+  *count_out = (int)seen.size();
   return CAPGPU_OK;
 }
 int capgpu_set_device(int slot) {
@@ -913,6 +927,39 @@ int capgpu_sync(void) {
   CAP_CHECK_INIT();
   Entry lk(ctx());
   CAP_HIP(hipStreamSynchronize(ctx().stream));
+  return CAPGPU_OK;
+}
+// device time of whatever the calling thread's context executes between the two calls: HIP events on ITS stream
+// ("hipEvent around device section"); a pair per context, created on first use
+int capgpu_timer_begin(void) {
+  CAP_CHECK_INIT();
+  Context& c = ctx();
+  Entry lk(c);
+  if (!c.tm0) {
+    CAP_HIP(hipEventCreate(&c.tm0));
+    CAP_HIP(hipEventCreate(&c.tm1));
+  }
+  CAP_HIP(hipEventRecord(c.tm0, c.stream));
+  return CAPGPU_OK;
+}
+int capgpu_timer_end(double* ms_out) {
+  CAP_CHECK_INIT();
+  Context& c = ctx();
+  hipEvent_t e0, e1;
+  {
+    Entry lk(c);
+    if (!c.tm0 || !ms_out) {
+      set_error("capgpu_timer_end: no capgpu_timer_begin on this context (or null output)");
+      return CAPGPU_ERR_INVALID_ARG;
+    }
+    CAP_HIP(hipEventRecord(c.tm1, c.stream));
+    e0 = c.tm0;
+    e1 = c.tm1;
+  }
+  CAP_HIP(hipEventSynchronize(e1));  // not under the context lock: other threads may enqueue meanwhile
+  float ms = 0;
+  CAP_HIP(hipEventElapsedTime(&ms, e0, e1));
+  *ms_out = (double)ms;
   return CAPGPU_OK;
 }
 int capgpu_set_stream(void* hip_stream) {

@@ -94,6 +94,7 @@ struct Context {
   hipStream_t own_stream = nullptr;
   hipStream_t copy_stream = nullptr;  // H2D of host-resident witnesses (plonk.hip), created on first use
   hipStream_t stream = nullptr;  // the stream work is enqueued on (own_stream unless capgpu_set_stream)
+  hipEvent_t tm0 = nullptr, tm1 = nullptr;  // capgpu_timer_begin / _end
   NttSmallTables small;
   std::map<uint32_t, NttDomain> domains;
   std::map<uint32_t, Ntt3Domain> domains3;  // N = 3 * 2^log_m (the prover's quotient domain)

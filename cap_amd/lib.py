@@ -100,6 +100,24 @@ def device_count() -> int:
     return n.value
 
 
+def physical_device_count() -> int:
+    """distinct HIP devices behind the contexts (device_count() counts CONTEXTS: four on one bound GPU by default)"""
+    out = ctypes.c_int(0)
+    check(load().capgpu_physical_device_count(ctypes.byref(out)))
+    return out.value
+
+
+def timer_begin():
+    check(load().capgpu_timer_begin())
+
+
+def timer_end() -> float:
+    """milliseconds of device time on the calling thread's context since timer_begin (HIP events on its stream)"""
+    out = ctypes.c_double(0)
+    check(load().capgpu_timer_end(ctypes.byref(out)))
+    return out.value
+
+
 def set_device(slot: int):
     """bind the calling thread to context `slot` (-1: unbind)"""
     check(load().capgpu_set_device(int(slot)))
@@ -544,6 +562,19 @@ def plonk_prove(pk_handle: int, wires: np.ndarray, pub_inputs: np.ndarray, blind
                                        ctypes.c_size_t(mlen), _p(blinders), ctypes.c_int(_form(input_form)),
                                        ctypes.byref(proof)))
     return proof
+
+
+def has_lagrange_commit() -> bool:
+    """the library can take round 1's wire commitments from the witness columns (Lagrange-form commit key per proving key)"""
+    return hasattr(load(), "capgpu_plonk_set_wire_commit")
+
+
+def plonk_set_wire_commit_from_evals(on):
+    """True: wire commitments as MSMs of the witness VALUES on the key's Lagrange-form commit key; False: from the
+    coefficients (jf-plonk's way); None: the library default.  Same group elements, same proof bytes."""
+    if not has_lagrange_commit():
+        return
+    check(load().capgpu_plonk_set_wire_commit(ctypes.c_int(-1 if on is None else (1 if on else 0))))
 
 
 def plonk_set_coalescing(window_us: int, max_batch: int = 0):

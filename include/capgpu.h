@@ -106,8 +106,12 @@ extern "C" {
  * a host-buffer batch is cut in two, gathered batches of coalesced calls use all four) and 1 per device otherwise.  One process per GPU (torchrun) keeps working: each process binds one device
  * and the ranks meet through capgpu_comm_* ("multi-GPU" below).  Idempotent: a second call is a no-op. */
 int capgpu_init(const int* device_ids, int n_devices);
-/* number of device contexts bound by capgpu_init (0 before it) */
+/* number of device CONTEXTS bound by capgpu_init (0 before it): the range of capgpu_set_device's slots.  NOT a GPU
+ * count - one bound GPU has four contexts by default; capgpu_context_count is the same number under its proper name,
+ * capgpu_physical_device_count the number of distinct HIP devices behind them. */
 int capgpu_device_count(int* count_out);
+int capgpu_context_count(int* count_out);
+int capgpu_physical_device_count(int* count_out);
 /* Binds the CALLING THREAD to context `slot` (0 .. count - 1): its *_dev calls, capgpu_malloc / memcpy / sync and its
  * host-buffer calls then all run there.  slot = -1 (the default of every thread) unbinds: device-pointer calls use slot
  * 0, host-buffer calls are dealt by the library. */
@@ -133,6 +137,11 @@ int capgpu_free(void* dev_ptr);
 int capgpu_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes);
 int capgpu_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);
 int capgpu_sync(void);
+/* Device time, in milliseconds, of the work the calling thread's context executes between the two calls (HIP events on
+ * its stream; _end waits for that work).  SURVEY 8d's "hipEvent around device section": bench.py times its MSM / NTT
+ * legs with it.  One pair per context: a second _begin restarts the measurement. */
+int capgpu_timer_begin(void);
+int capgpu_timer_end(double* ms_out);
 /* Run all subsequent work on the caller's hipStream_t (e.g. torch's current stream); NULL
  * restores the library's own stream. */
 int capgpu_set_stream(void* hip_stream);
