@@ -94,6 +94,14 @@ extern "C" {
     pub fn capgpu_srs_free(handle: u64) -> c_int;
     // ---- MSM
     pub fn capgpu_msm_g1(srs_handle: u64, offset: usize, scalars: *const u64, n: usize, out_xyz: *mut u64) -> c_int;
+    pub fn capgpu_msm_g1_lagrange(
+        srs_handle: u64,
+        log_n: u32,
+        scalars: *const u64,
+        count: usize,
+        scalars_montgomery: c_int,
+        out_xyz: *mut u64,
+    ) -> c_int;
     pub fn capgpu_msm_g1_batch(srs_handle: u64, offsets: *const usize, scalars: *const *const u64, ns: *const usize,
                                count: c_int, out_xyz: *mut u64) -> c_int;
     pub fn capgpu_msm_g1_dev(srs_handle: u64, offset: usize, d_scalars: *const c_void, scalar_stride: usize, n: usize,
@@ -141,6 +149,7 @@ extern "C" {
                               ext_msg: *const u8, ext_msg_len: usize, blinders: *const u64,
                               proof_out: *mut capgpu_proof) -> c_int;
     pub fn capgpu_plonk_set_coalescing(window_us: u32, max_batch: u32) -> c_int;
+    pub fn capgpu_plonk_set_wire_commit(mode: c_int) -> c_int;
     pub fn capgpu_plonk_graph_stats(segments_captured_out: *mut u64, segments_replayed_out: *mut u64) -> c_int;
     pub fn capgpu_plonk_coalescing_stats(batches_out: *mut u64, proofs_out: *mut u64) -> c_int;
     pub fn capgpu_plonk_prove_batch(pk_handle: u64, count: c_int, wires: *const u64, pub_inputs: *const u64,

@@ -13,6 +13,7 @@
 
 #include "context.hpp"
 #include "curve29.hpp"
+#include "lagrange.hpp"
 #include "launch.hpp"
 #include "params.hpp"
 
@@ -501,6 +502,37 @@ int find_srs(uint64_t h, const MsmBases** out) {
     return CAPGPU_ERR_INVALID_ARG;
   }
   *out = &it->second->bases;
+  return CAPGPU_OK;
+}
+
+int find_lagrange(uint64_t h, uint32_t log_n, const MsmBases** out) {
+  const MsmBases* B = nullptr;
+  int rc = find_srs(h, &B);
+  if (rc) return rc;
+  Context& c = ctx();
+  SrsEntry* e = c.srs.find(h)->second.get();
+  std::lock_guard<std::mutex> lk(e->lag_mu);
+  auto it = e->lagrange.find(log_n);
+  if (it == e->lagrange.end()) {
+    if (B->n < ((size_t)1 << log_n) + 2) {
+      set_error("capgpu: SRS %llu has %zu points, the Lagrange-form commit key of a 2^%u domain needs %zu",
+                (unsigned long long)h, B->n, log_n, ((size_t)1 << log_n) + 2);
+      return CAPGPU_ERR_INVALID_ARG;
+    }
+    if (c.capturing) {
+      set_error("capgpu: Lagrange-form commit key requested inside a stream capture");
+      return CAPGPU_ERR_INVALID_ARG;
+    }
+    std::unique_ptr<MsmBases> L(new MsmBases);
+    rc = lagrange_build(*B, log_n, L.get(), c.stream);
+    if (rc) return hip_fail((hipError_t)rc, "lagrange_build");
+    if ((rc = take_launch_error())) {
+      msm_free_bases(L.get());
+      return rc;
+    }
+    it = e->lagrange.emplace(log_n, std::move(L)).first;
+  }
+  *out = it->second.get();
   return CAPGPU_OK;
 }
 
@@ -1545,6 +1577,34 @@ int capgpu_msm_g1_batch(uint64_t srs_handle, const size_t* offsets, const uint64
 int capgpu_msm_g1(uint64_t srs_handle, size_t offset, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]) {
   const uint64_t* sp[1] = {scalars};
   return capgpu_msm_g1_batch(srs_handle, &offset, sp, &n, 1, out_xyz);
+}
+
+// KZG commitment of a polynomial given by its VALUES on the 2^log_n-th roots of unity (+ the two blinders of jf-plonk's
+// wire polynomials): an MSM on the Lagrange-form commit key (lagrange.hip), the form round 1 of the prover uses
+int capgpu_msm_g1_lagrange(uint64_t srs_handle, uint32_t log_n, const uint64_t* scalars, size_t count,
+                           int scalars_montgomery, uint64_t out_xyz[12]) {
+  CAP_CHECK_INIT();
+  const size_t n = (size_t)1 << (log_n & 31);
+  if (!scalars || !out_xyz || log_n > 26 || count == 0 || count > n + 2) {
+    set_error("capgpu_msm_g1_lagrange: bad argument (1 .. 2^log_n + 2 scalars, log_n <= 26)");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  Context& c = pick_context();
+  ScopedCtx sc(c);
+  Entry lk(c);
+  const MsmBases* L = nullptr;
+  int rc = find_lagrange(srs_handle, log_n, &L);
+  if (rc) return rc;
+  if ((rc = scratch_reserve(c.stage_a, sizeof(fe) * count + sizeof(g1_jac) + 256))) return rc;
+  if ((rc = scratch_reserve(c.msm_ws, msm_workspace_bytes(*L, count, 1)))) return rc;
+  g1_jac* d_out = (g1_jac*)c.stage_a.p;
+  fe* d_sc = (fe*)((char*)c.stage_a.p + 256);
+  CAP_HIP(hipMemcpyAsync(d_sc, scalars, sizeof(fe) * count, hipMemcpyHostToDevice, c.stream));
+  rc = msm_run(*L, 0, d_sc, 0, 1, 0, count, 1, scalars_montgomery ? 1 : 0, d_out, c.msm_ws.p, c.msm_ws.cap, c.stream);
+  if (rc) return hip_fail((hipError_t)rc, "msm_run");
+  CAP_HIP(hipMemcpyAsync(out_xyz, d_out, sizeof(g1_jac), hipMemcpyDeviceToHost, c.stream));
+  CAP_HIP(hipStreamSynchronize(c.stream));
+  return take_launch_error();
 }
 
 int capgpu_g1_sum(const uint64_t* points_xyz, size_t n, uint64_t out_xyz[12]) {

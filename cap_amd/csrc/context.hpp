@@ -50,10 +50,17 @@ struct SrsEntry {
   // the open key's gamma_g of that blob (affine, Montgomery words; valid when has_ck_gamma_g)
   g1_affine ck_gamma_g{};
   bool has_ck_gamma_g = false;
+  // Lagrange-form commit keys derived from `bases` (lagrange.hpp), one per domain size a proving key under this SRS
+  // uses; built on first use (find_lagrange), shared by the contexts of this device, never serialized
+  std::mutex lag_mu;
+  std::map<uint32_t, std::unique_ptr<MsmBases>> lagrange;  // log_n -> table of 2^log_n + 2 points
   SrsEntry() = default;
   SrsEntry(const SrsEntry&) = delete;
   SrsEntry& operator=(const SrsEntry&) = delete;
-  ~SrsEntry() { msm_free_bases(&bases); }
+  ~SrsEntry() {
+    for (auto& kv : lagrange) msm_free_bases(kv.second.get());
+    msm_free_bases(&bases);
+  }
 };
 
 // a logical SRS handle: one full table (replicated on demand), or one shard per context
@@ -191,6 +198,9 @@ int register_srs(g1_affine* d_bases, size_t n, uint64_t* handle_out);
 // the full SRS `h` resident on the current context (replicated from its home on first use); sharded handles are refused
 int find_srs(uint64_t h, const MsmBases** out);
 SrsEntry* find_srs_entry(uint64_t h);  // the current context's entry; nullptr when unknown there
+// the Lagrange-form commit key of SRS `h` for a domain of 2^log_n points, resident on the current context's device:
+// built on first use (on the context's stream, synchronously) and kept with the SRS (lagrange.hpp)
+int find_lagrange(uint64_t h, uint32_t log_n, const MsmBases** out);
 // a copy of the registry record (shared ownership of the tables); CAPGPU_ERR_BAD_HANDLE when unknown
 int srs_record(uint64_t h, SrsRecord* out);
 // proving keys: register a key created on the current context / find (replicate) one / drop everywhere

@@ -90,11 +90,12 @@ struct ProveGraphSig {
   int form = 0;
   bool multi = false;
   const void *d_wires = nullptr, *ws = nullptr, *msm_ws = nullptr, *ntt_scratch = nullptr, *bases = nullptr;
+  const void* lagrange = nullptr;  // the Lagrange-form commit key round 1 commits on (null: from coefficients)
   hipStream_t stream = nullptr;
   bool operator==(const ProveGraphSig& o) const {
     return key_uid == o.key_uid && srs == o.srs && P == o.P && num_inputs == o.num_inputs && form == o.form &&
            multi == o.multi && d_wires == o.d_wires && ws == o.ws && msm_ws == o.msm_ws && ntt_scratch == o.ntt_scratch &&
-           bases == o.bases && stream == o.stream;
+           bases == o.bases && lagrange == o.lagrange && stream == o.stream;
   }
 };
 struct ProveGraphSet {
@@ -409,6 +410,21 @@ int compute_pk_coset(hipStream_t s, const ProvingKey& K, fe* dst) {
   return run_ntt3_fwd(s, K.log_m, dst, 18, NttIo{K.coef, K.ps, 0, K.n, 1, K.m, 0, 1});
 }
 
+// Round 1's wire commitments: from the wire polynomials' coefficients (jf-plonk's way: KZG10::commit under
+// src/proof/transfer.rs:181-186) or from the witness VALUES on the Lagrange-form commit key of the domain (lagrange.hip) -
+// the same group elements, the same proof bytes; a CAP witness is mostly zeros, booleans and small limbs, whose MSM scalars
+// have one non-zero digit or none.  capgpu_plonk_set_wire_commit: 0 coefficients, 1 evaluations, -1 the default
+// (evaluations; CAPGPU_WIRE_COMMIT=coeffs turns it off for the process).
+std::atomic<int> g_wire_commit{-1};
+bool wire_commit_from_evals() {
+  static const int env_default = [] {
+    const char* e = getenv("CAPGPU_WIRE_COMMIT");
+    return (e && (!strcmp(e, "coeffs") || !strcmp(e, "0"))) ? 0 : 1;
+  }();
+  const int m = g_wire_commit.load(std::memory_order_relaxed);
+  return (m < 0 ? env_default : m) != 0;
+}
+
 // The stream the chunks of host-resident wire columns are copied on: a copy on the launch stream itself would queue up
 // behind the kernels of the chunk before it (calls are serialised by the process lock; created on first use).
 hipStream_t h2d_stream() {
@@ -487,6 +503,10 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   const MsmBases* B = nullptr;
   int rc = find_srs(K.srs_handle, &B);
   if (rc) return rc;
+  // the Lagrange-form commit key (built on the first proof of this domain size under this SRS if preprocess did not);
+  // sharded commitment MSMs (mode A of config 4) cut the monomial key by point range: they keep the coefficient form
+  const MsmBases* Lag = nullptr;
+  if (wire_commit_from_evals() && !comm_shard_prover() && (rc = find_lagrange(K.srs_handle, K.log_n, &Lag))) return rc;
   // workspace
   const bool coeffs = form == CAPGPU_INPUT_COEFFS;
   if ((rc = scratch_reserve(c.prove_ws, carve(nullptr, K, P, num_inputs, coeffs).total))) return rc;
@@ -512,6 +532,7 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
     sig.msm_ws = c.msm_ws.p;
     sig.ntt_scratch = c.ntt_scratch.p;
     sig.bases = B->ext;
+    sig.lagrange = Lag ? Lag->ext : nullptr;
     sig.stream = s;
     gs = graph_set_for(c, sig);
   }
@@ -590,6 +611,18 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   // padded copies); k_blind sets the 8-element tail of every wire polynomial (two blinders, six zeros)
   // kernels of one chunk of proofs [p0, p0 + cnt): interpolation (or, from coefficient-form input, the copy into place
   // and the forward transform round 2 reads), blinding, and - when the batch is chunked - the chunk's commitments
+  // the five commitments of proofs [p0, p0 + cnt): MSMs of the blinded polynomials' n + 2 coefficients on the monomial key,
+  // or - same group elements - of each column's n VALUES followed by its two blinders on the Lagrange-form key.  The
+  // scalars of the second form are staged in the coset area, which round 3 fills only after these MSMs are through.
+  auto commit_wires = [&](uint32_t p0, uint32_t cnt) -> int {
+    g1_jac* out = w.comms + (size_t)p0 * NW;
+    if (!Lag) return run_msm(s, *B, w.wpoly + (size_t)p0 * NW * ps, ps, 1, 0, n + 2, cnt * NW, out);
+    fe* stage = w.coset + (size_t)p0 * NW * (n + 2);
+    const fe* ev = (coeffs ? (const fe*)w.wev : d_wires) + (size_t)p0 * NW * n;
+    launch("k_stage_evals", k_stage_evals, dim3(cdiv(n + 2, kThreads), cnt * NW), dim3(kThreads), 0, s, ev, n,
+           (const fe*)(w.d_blind + (size_t)p0 * 13), (uint32_t)NW, stage);
+    return run_msm(s, *Lag, stage, n + 2, 1, 0, n + 2, cnt * NW, out);
+  };
   auto r1_chunk_kernels = [&](uint32_t p0, uint32_t cnt, bool commit) -> int {
     const size_t wo = (size_t)p0 * NW * n;
     fe* wp = w.wpoly + (size_t)p0 * NW * ps;
@@ -602,7 +635,7 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
     }
     launch("k_blind", k_blind<1>, dim3(cnt * NW), dim3(64), 0, s, wp, ps, n, (const fe*)(w.d_blind + (size_t)p0 * 13),
            (uint32_t)NW, 0u, 2u, cnt * NW);
-    if (commit && (r = run_msm(s, *B, wp, ps, 1, 0, n + 2, cnt * NW, w.comms + (size_t)p0 * NW))) return r;
+    if (commit && (r = commit_wires(p0, cnt))) return r;
     return CAPGPU_OK;
   };
   auto r1_tail_kernels = [&]() -> int {
@@ -612,7 +645,7 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
     } else {
       CAP_HIP(hipMemsetAsync(w.pi, 0, sizeof(fe) * (size_t)P * n, s));
     }
-    if (chunks == 1 && (r = run_msm(s, *B, w.wpoly, ps, 1, 0, n + 2, P * NW, w.comms))) return r;
+    if (chunks == 1 && (r = commit_wires(0, P))) return r;
     return CAPGPU_OK;
   };
   for (uint32_t ck = 0; ck < chunks; ck++) {
@@ -1180,6 +1213,12 @@ int capgpu_plonk_preprocess_ex(uint64_t srs_handle, size_t n, size_t num_inputs,
   batch_to_affine(hj, ha);
   key_set_vk(*K, ha);
   if (vk_out) *vk_out = K->vk;
+  // the Lagrange-form commit key of this domain under this SRS (round 1's wire commitments; built once per pair and kept
+  // with the SRS): made here so that the first proof does not pay for it
+  if (wire_commit_from_evals() && !comm_shard_prover()) {
+    const MsmBases* Lag = nullptr;
+    if ((rc = find_lagrange(srs_handle, K->log_n, &Lag))) return rc;
+  }
   *pk_handle_out = register_key(K);
   return take_launch_error();
 }
@@ -1919,6 +1958,15 @@ int capgpu_plonk_set_coalescing(uint32_t window_us, uint32_t max_batch) {
   std::lock_guard<std::mutex> lk(co.mu);
   co.window_us = window_us;
   co.max_batch = max_batch ? max_batch : 256;
+  return CAPGPU_OK;
+}
+
+int capgpu_plonk_set_wire_commit(int mode) {
+  if (mode < -1 || mode > 1) {
+    set_error("capgpu_plonk_set_wire_commit: mode must be -1 (default), 0 (coefficients) or 1 (evaluations)");
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  g_wire_commit.store(mode);
   return CAPGPU_OK;
 }
 

@@ -63,6 +63,18 @@ __global__ void k_blind(fe* __restrict__ polys, size_t stride, size_t n, const f
   p[n + t] = SET_TAIL ? b : Fr::add(p[n + t], b);
 }
 
+// round 1, commitments from evaluations (lagrange.hip): the MSM scalars of wire column q are its n values followed by
+// its two blinders - commit(w + (b0 + b1 X)(X^n - 1)) = sum_j w_j [L_j] + b0 [tau^n - 1] + b1 [tau^(n+1) - tau]
+__global__ __launch_bounds__(kThreads) void k_stage_evals(const fe* __restrict__ evals /*[count][n]*/, size_t n,
+                                                          const fe* __restrict__ blinders, uint32_t inner,
+                                                          fe* __restrict__ dst /*[count][n + 2]*/) {
+  const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t q = blockIdx.y;
+  if (j >= n + 2) return;
+  dst[(size_t)q * (n + 2) + j] =
+      j < n ? evals[(size_t)q * n + j] : blinders[(size_t)(q / inner) * 13 + (size_t)(q % inner) * 2 + (j - n)];
+}
+
 // round 2: per-row numerator / denominator of the permutation grand product
 //   num_j = prod_i (w_i + beta k_i omega^j + gamma),   den_j = prod_i (w_i + beta sigma_i(omega^j) + gamma)
 // On the lazy field.  All inputs are in arkworks' form (x * 2^256); a lazy product of two such values is x y 2^256 / 2^5,

@@ -262,6 +262,15 @@ def msm_g1(handle: int, scalars: np.ndarray, offset: int = 0) -> np.ndarray:
     return out
 
 
+def lagrange_commit(handle: int, log_n: int, scalars_mont: np.ndarray) -> np.ndarray:
+    """KZG commitment from VALUES on the 2^log_n domain (+ up to two blinders): MSM on the Lagrange-form commit key"""
+    sc = np.ascontiguousarray(scalars_mont, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros(12, np.uint64)
+    check(load().capgpu_msm_g1_lagrange(ctypes.c_uint64(handle), ctypes.c_uint32(log_n), _p(sc), ctypes.c_size_t(sc.shape[0]),
+                                        1, _p(out)))
+    return out
+
+
 def msm_g1_batch(handle: int, scalar_list, offsets=None) -> np.ndarray:
     cnt = len(scalar_list)
     arrs = [np.ascontiguousarray(s, dtype=np.uint64).reshape(-1, 4) for s in scalar_list]

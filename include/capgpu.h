@@ -176,6 +176,14 @@ int capgpu_srs_free(uint64_t handle);
  * additions were made in, which on the device varies from run to run (bucket lists are filled with atomics): compare
  * results in affine form (X / Z^2, Y / Z^3), as every caller of the reference does through into_affine(). */
 int capgpu_msm_g1(uint64_t srs_handle, size_t offset, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]);
+/* The same commitment from a polynomial's VALUES: out = sum_{j < n} s_j [L_j(tau)] G + s_n [tau^n - 1] G +
+ * s_(n+1) [tau^(n+1) - tau] G, n = 2^log_n, L_j the Lagrange basis of the n-th roots of unity; `count` <= n + 2 scalars
+ * (the last two slots are the blinders of a jf-plonk wire polynomial (b0 + b1 X)(X^n - 1)); scalars_montgomery != 0:
+ * arkworks' Fr memory form.  Equals capgpu_msm_g1 on the coefficients ark-poly's ifft makes of the values - the form
+ * round 1 of the prover commits in (capgpu_plonk_set_wire_commit).  The Lagrange-form commit key is derived from the
+ * SRS on first use (the SRS must hold n + 2 points) and kept with it. */
+int capgpu_msm_g1_lagrange(uint64_t srs_handle, uint32_t log_n, const uint64_t* scalars, size_t count,
+                           int scalars_montgomery, uint64_t out_xyz[12]);
 int capgpu_msm_g1_batch(uint64_t srs_handle, const size_t* offsets, const uint64_t* const* scalars,
                         const size_t* ns, int count, uint64_t* out_xyz /* count*12 */);
 /* Device-resident form: d_scalars = count arrays of n scalars, scalar_stride elements apart;
@@ -317,6 +325,17 @@ int capgpu_plonk_prove(uint64_t pk_handle, const uint64_t* wires, const uint64_t
  * device is busy with a previous batch - are gathered (up to max_batch; 0 = 256) and proved as ONE device batch; each caller receives its own proof and its own return code
  * (an unsatisfied witness fails only its owner).  window_us = 0 switches it off. */
 int capgpu_plonk_set_coalescing(uint32_t window_us, uint32_t max_batch);
+/* How round 1 computes the five wire commitments.  jf-plonk commits to each blinded wire polynomial through its n + 2
+ * COEFFICIENTS (KZG10::commit under src/proof/transfer.rs:181-186).  The same group element is
+ *     sum_j w_j [L_j(tau)] G + b0 [tau^n - 1] G + b1 [tau^(n+1) - tau] G
+ * - an MSM of the column's n VALUES and its two blinders on the Lagrange-form commit key of the domain, which the
+ * library derives from the SRS once per (SRS, domain size) by a group inverse transform (cap_amd/csrc/lagrange.hip;
+ * 2 x 64 B x (n + 2) x 18-20 window rows of device memory, built by capgpu_plonk_preprocess or by the first proof).  The
+ * witness values of a CAP circuit are mostly zeros, booleans and range-check limbs (src/circuit/transfer.rs:53-193): as
+ * MSM scalars they have at most one non-zero digit where a coefficient has seventeen.  Proof bytes are identical.
+ * mode: 1 = from evaluations (the default), 0 = from coefficients, -1 = back to the default (CAPGPU_WIRE_COMMIT=coeffs
+ * makes 0 the process default).  Process-wide; takes effect with the next prove call. */
+int capgpu_plonk_set_wire_commit(int mode);
 /* device batches run and proofs made through the coalescer so far */
 int capgpu_plonk_coalescing_stats(uint64_t* batches_out, uint64_t* proofs_out);
 /* Small batches (count <= CAPGPU_GRAPH_MAX_BATCH, default 16; 0 switches it off) replay their kernel schedule as

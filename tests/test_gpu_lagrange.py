@@ -1,0 +1,116 @@
+"""Round 1's wire commitments taken from the witness VALUES on the Lagrange-form commit key (cap_amd/csrc/lagrange.hip,
+include/capgpu.h: capgpu_plonk_set_wire_commit) are the group elements jf-plonk gets from the coefficients
+(KZG10::commit under src/proof/transfer.rs:181-186): the proofs must be the same bytes in both modes, for every input
+form, batch shape and witness distribution - and those bytes are the ones the C oracle (reference schedule) produces."""
+import numpy as np
+import pytest
+
+from cap_amd import bench_utils as bu
+from oracle import capref as cr
+from tests import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _default_mode_after(cg):
+    yield
+    cg.plonk_set_wire_commit_from_evals(None)
+
+
+def both_modes(cg, fn):
+    out = []
+    for mode in (False, True):
+        cg.plonk_set_wire_commit_from_evals(mode)
+        out.append([bytes(p) for p in fn()])
+    return out
+
+
+@pytest.mark.parametrize("log_n,nin,P", [(4, 1, 1), (5, 3, 2), (8, 0, 7), (10, 27, 3), (13, 7, 20)])
+def test_same_proofs_from_evaluations_and_from_coefficients(cg, tau, log_n, nin, P):
+    assert cg.has_lagrange_commit()
+    sc = bu.synthetic_circuit(log_n, nin, seed=90 + log_n)
+    n = sc.n
+    h = cg.srs_generate(tau, n + 3)
+    pk, _ = cg.plonk_preprocess(h, n, nin, sc.selectors_mont(), sc.sigma_mont())
+    ws, ps = sc.witnesses_mont([500 + p for p in range(P)])
+    bls = np.stack([bu.to_mont_array(bu.blinders(900 + p)) for p in range(P)])
+    a, b = both_modes(cg, lambda: cg.plonk_prove_batch(pk, ws, ps, bls, b"memo", P))
+    assert a == b
+    # pinned against the C oracle, so that "the same" means "the right" bytes
+    key = cr.PlonkKey(cg.srs_download(h, 0, n + 3), n, nin, sc.selectors_mont(), sc.sigma_mont())
+    rc, comms, evals = key.prove(ws[0], ps[0], bls[0], b"memo")
+    cg.plonk_set_wire_commit_from_evals(True)
+    first = cg.plonk_prove_batch(pk, ws[:1], ps[:1], bls[:1], b"memo", 1)[0]
+    assert rc == 0 and bytes(first) == b[0] and H.proof_points(first) == H.cref_proof_points(comms, evals)
+    # coefficient-form input: the values the commitments are taken from are the forward transform made on the device
+    d = cg.DevBuf.from_numpy(ws)
+    cg.ntt_fr_dev(d, log_n, count=5 * P, inverse=True)
+    wc = d.to_numpy().reshape(ws.shape)
+    d.free()
+    c0, c1 = both_modes(cg, lambda: cg.plonk_prove_batch(pk, wc, ps, bls, b"memo", P, input_form="coeffs"))
+    assert c0 == a and c1 == a
+    # device-resident, twice (the second call of a small batch replays captured graphs), and single calls
+    d = cg.DevBuf.from_numpy(ws)
+    for _ in range(3):
+        assert both_modes(cg, lambda: cg.plonk_prove_batch_dev(pk, d, ps, bls, b"memo", P)) == [a, a]
+    d.free()
+    assert both_modes(cg, lambda: [cg.plonk_prove(pk, ws[P - 1], ps[P - 1], bls[P - 1], b"memo")]) == [[a[P - 1]]] * 2
+    cg.plonk_free_key(pk)
+    cg.srs_free(h)
+
+
+def test_degenerate_columns(cg, tau):
+    """scalar sets a uniform witness never produces: whole columns of zeros / ones / one repeated value (every entry of an
+    MSM in one bucket, or none at all), all-zero blinders; commitments only (the circuit is not satisfied, so the proof
+    stops at the quotient - the wire commitments are what differs between the modes and they come out first)"""
+    log_n, n = 9, 1 << 9
+    h = cg.srs_generate(tau, n + 3)
+    L = cg.load()
+    import ctypes
+    srs = cg.srs_download(h, 0, n + 3)
+    rng = np.random.default_rng(7)
+    one = bu.to_mont_array([1])[0]
+    big = bu.to_mont_array([bu.R - 1])[0]
+    cols = [np.zeros((n, 4), np.uint64), np.tile(one, (n, 1)), np.tile(big, (n, 1)),
+            bu.to_mont_array([int(x) for x in rng.integers(0, 2, n)]),
+            bu.to_mont_array([int(x) for x in rng.integers(0, 1 << 63, n)])]
+    for blind in ([0, 0], [1, bu.R - 1], [12345678901234567890, 98765432109876543210987654321]):
+        bl = bu.to_mont_array(blind)
+        for col in cols:
+            # what jf-plonk commits to: the blinded polynomial's n + 2 coefficients on the monomial key
+            coef = cr.ntt_fr(col.copy(), log_n, True, False).reshape(n, 4)
+            cf = H.fr_to_ints(coef) + [0, 0]
+            cf[0] = (cf[0] - blind[0]) % bu.R
+            cf[1] = (cf[1] - blind[1]) % bu.R
+            cf[n] = (cf[n] + blind[0]) % bu.R
+            cf[n + 1] = (cf[n + 1] + blind[1]) % bu.R
+            want = cr.g1_to_affine(cr.msm_g1(srs[:n + 2], bu.to_canonical_array(cf)))
+            got = cr.g1_to_affine(cg.lagrange_commit(h, log_n, np.concatenate([col, bl])))
+            assert np.array_equal(got, want)
+    cg.srs_free(h)
+
+
+def test_cap_shaped_witness_full_size(cg, tau):
+    """the CAP-shaped model circuit at n = 2^15 (bench.py: realistic_witness): heavy buckets (thousands of ones in one
+    column), zeros, 64-bit values - both modes, batch of 6 distinct witnesses, one proof against the C oracle"""
+    sc = bu.cap_like_circuit("transfer_2x2", seed=7)
+    n, nin, P = sc.n, sc.num_inputs, 6
+    h = cg.srs_generate(tau, n + 3)
+    pk, _ = cg.plonk_preprocess(h, n, nin, sc.selectors_mont(), sc.sigma_mont())
+    ws, ps = sc.witnesses_mont([70 + p for p in range(P)], verify=True)
+    bls = np.stack([bu.to_mont_array(bu.blinders(40 + p)) for p in range(P)])
+    a, b = both_modes(cg, lambda: cg.plonk_prove_batch(pk, ws, ps, bls, b"note", P))
+    assert a == b and len(set(a)) == P
+    key = cr.PlonkKey(cg.srs_download(h, 0, n + 3), n, nin, sc.selectors_mont(), sc.sigma_mont())
+    rc, comms, evals = key.prove(ws[1], ps[1], bls[1], b"note")
+    cg.plonk_set_wire_commit_from_evals(True)
+    pr = cg.plonk_prove_batch(pk, ws[1:2], ps[1:2], bls[1:2], b"note", 1)[0]
+    assert rc == 0 and bytes(pr) == b[1] and H.proof_points(pr) == H.cref_proof_points(comms, evals)
+    # a batch large enough for the wide-window table and the running-sum reduction (>= 24 MSMs per launch: P >= 5)
+    P2 = 40
+    idx = np.arange(P2) % P
+    big = both_modes(cg, lambda: cg.plonk_prove_batch(pk, ws[idx], ps[idx], bls[idx], b"note", P2))
+    assert big[0] == big[1] and big[0][:P] == a
+    cg.plonk_free_key(pk)
+    cg.srs_free(h)
