@@ -332,16 +332,22 @@ pub struct ProvingKey {
     pub num_inputs: usize,
 }
 impl ProvingKey {
-    /// `PlonkKzgSnark::preprocess(srs, circuit)`.  `selectors`: the 13 selector POLYNOMIALS (q_lc x4, q_mul x2,
-    /// q_hash x4, q_o, q_c, q_ecc), `sigma`: the 5 extended-permutation polynomials - n coefficients each, column-major,
-    /// Montgomery words: `arkworks::poly_columns(&circuit.compute_selector_polynomials()?, n)` and
-    /// `..compute_extended_permutation_polynomials()`, passed through as jf-relation computed them (no transform on the
-    /// CPU; the device evaluates sigma where round 2 needs its values).
+    /// `PlonkKzgSnark::preprocess(srs, circuit)` from the circuit's tables of VALUES on the domain
+    /// (`CAPGPU_INPUT_EVALS`): `selectors` = 13 columns (q_lc x4, q_mul x2, q_hash x4, q_o, q_c, q_ecc), `sigma` = the 5
+    /// extended-permutation columns, n values each, column-major, Montgomery words.  This name has meant EVALUATIONS
+    /// since round 1 and keeps meaning it: a caller holding jf-relation's polynomials uses `preprocess_coeffs` - the two
+    /// forms cannot be told apart from the data, so the form is in the function name, not in a default.
     pub fn preprocess(srs: &Srs, n: usize, num_inputs: usize, selectors: &[[u64; 4]], sigma: &[[u64; 4]]) -> Result<ProvingKey> {
-        Self::preprocess_form(srs, n, num_inputs, selectors, sigma, CAPGPU_INPUT_COEFFS)
+        Self::preprocess_form(srs, n, num_inputs, selectors, sigma, CAPGPU_INPUT_EVALS)
     }
-    /// The same from the circuit's tables of VALUES on the domain (`input_form` = `CAPGPU_INPUT_EVALS`), for a caller
-    /// that holds those instead of polynomials.
+    /// The same from POLYNOMIALS in coefficient form (`CAPGPU_INPUT_COEFFS`):
+    /// `arkworks::poly_columns(&circuit.compute_selector_polynomials()?, n)` and
+    /// `..compute_extended_permutation_polynomials()`, passed through as jf-relation computed them (no transform on the
+    /// CPU; the device evaluates sigma where round 2 needs its values).  Same key bytes as `preprocess` on the values.
+    pub fn preprocess_coeffs(srs: &Srs, n: usize, num_inputs: usize, selector_polys: &[[u64; 4]], sigma_polys: &[[u64; 4]]) -> Result<ProvingKey> {
+        Self::preprocess_form(srs, n, num_inputs, selector_polys, sigma_polys, CAPGPU_INPUT_COEFFS)
+    }
+    /// Either form, stated explicitly (`CAPGPU_INPUT_EVALS` / `CAPGPU_INPUT_COEFFS`).
     pub fn preprocess_form(srs: &Srs, n: usize, num_inputs: usize, selectors: &[[u64; 4]], sigma: &[[u64; 4]],
                            input_form: c_int) -> Result<ProvingKey> {
         assert_eq!(selectors.len(), NUM_SELECTORS * n);
@@ -355,13 +361,19 @@ impl ProvingKey {
         Ok(ProvingKey { handle, vk, domain_size: n, num_inputs })
     }
     /// `PlonkKzgSnark::prove::<_, _, SolidityTranscript>(rng, circuit, pk, Some(ext_msg))` for one note: callable from
-    /// any thread; with coalescing on, concurrent calls share device batches.  `wires`: the 5 UNBLINDED wire
-    /// polynomials, n coefficients each - `arkworks::poly_columns(&circuit.compute_wire_polynomials()?, n)`;
-    /// `blinders`: 13 `Fr::rand(rng)` draws in jf-plonk's order (2 per wire polynomial, then 3).
+    /// any thread; with coalescing on, concurrent calls share device batches.  `wires`: the 5 finalised wire COLUMNS, n
+    /// VALUES each (`CAPGPU_INPUT_EVALS` - what this name has always taken); `blinders`: 13 `Fr::rand(rng)` draws in
+    /// jf-plonk's order (2 per wire polynomial, then 3).
     pub fn prove(&self, wires: &[[u64; 4]], pub_inputs: &[[u64; 4]], ext_msg: &[u8], blinders: &[[u64; 4]; 13]) -> Result<capgpu_proof> {
-        self.prove_form(wires, pub_inputs, ext_msg, blinders, CAPGPU_INPUT_COEFFS)
+        self.prove_form(wires, pub_inputs, ext_msg, blinders, CAPGPU_INPUT_EVALS)
     }
-    /// The same from the 5 finalised wire COLUMNS (n values each): `input_form` = `CAPGPU_INPUT_EVALS`.
+    /// The same from the 5 UNBLINDED wire POLYNOMIALS, n coefficients each (`CAPGPU_INPUT_COEFFS`) -
+    /// `arkworks::poly_columns(&circuit.compute_wire_polynomials()?, n)`: what a jf-relation caller holds.  Same proof
+    /// bytes as `prove` on the values.
+    pub fn prove_coeffs(&self, wire_polys: &[[u64; 4]], pub_inputs: &[[u64; 4]], ext_msg: &[u8], blinders: &[[u64; 4]; 13]) -> Result<capgpu_proof> {
+        self.prove_form(wire_polys, pub_inputs, ext_msg, blinders, CAPGPU_INPUT_COEFFS)
+    }
+    /// Either form, stated explicitly.
     pub fn prove_form(&self, wires: &[[u64; 4]], pub_inputs: &[[u64; 4]], ext_msg: &[u8], blinders: &[[u64; 4]; 13],
                       input_form: c_int) -> Result<capgpu_proof> {
         assert_eq!(wires.len(), NUM_WIRE_TYPES * self.domain_size);
@@ -426,6 +438,21 @@ pub mod arkworks {
     ///   let wires     = poly_columns(&circuit.compute_wire_polynomials()?, n);                  // 5 x n (per proof)
     /// A memcpy of 5 n field elements per proof - against the 10 n-point FFTs per proof the evaluation form used to
     /// cost this shim (5 here to undo jf-relation's interpolation, 5 on the device to redo it).
+    /// The evaluation-form columns (`CAPGPU_INPUT_EVALS`) of a family of polynomials: one n-point FFT each on the CPU.
+    /// Kept for callers written against rounds 1-3 of this crate; new code passes `poly_columns` to the `_coeffs` entry
+    /// points and lets the device do the transform.
+    #[deprecated(note = "pass poly_columns(..) to preprocess_coeffs / prove_coeffs instead: no CPU transform")]
+    pub fn circuit_columns(polys: &[DensePolynomial<Fr>], n: usize) -> Vec<[u64; 4]> {
+        use ark_poly::{EvaluationDomain, Radix2EvaluationDomain};
+        let domain = Radix2EvaluationDomain::<Fr>::new(n).expect("power-of-two domain");
+        let mut out = vec![[0u64; 4]; polys.len() * n];
+        for (i, p) in polys.iter().enumerate() {
+            for (j, v) in domain.fft(&p.coeffs).iter().enumerate() {
+                out[i * n + j] = fr_words(v);
+            }
+        }
+        out
+    }
     pub fn poly_columns(polys: &[DensePolynomial<Fr>], n: usize) -> Vec<[u64; 4]> {
         let mut out = vec![[0u64; 4]; polys.len() * n];
         for (i, p) in polys.iter().enumerate() {

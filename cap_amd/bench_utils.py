@@ -52,12 +52,23 @@ def _witgen():
         L.capwit_fill_many.restype = ctypes.c_int
         L.capwit_value_classes.argtypes = [vp, u64, vp]
         L.capwit_value_classes.restype = None
+        L.capwit_msm_work.argtypes = [vp, u64, u32, vp, vp]
+        L.capwit_msm_work.restype = None
         _WITGEN = L
     return _WITGEN
 
 
 def _vp(a: np.ndarray):
     return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def msm_work(scalars_mont: np.ndarray, c: int = 15):
+    """(bucket-list entries, non-empty buckets) of ONE MSM on these scalars with signed base-2^c digits on a shared bucket
+    set - msm.hip's digit rule; mixed additions of its accumulation = entries - non-empty buckets"""
+    a = np.ascontiguousarray(scalars_mont, dtype=np.uint64).reshape(-1, 4)
+    e, b = np.zeros(1, np.uint64), np.zeros(1, np.uint64)
+    _witgen().capwit_msm_work(_vp(a), a.shape[0], c, _vp(e), _vp(b))
+    return int(e[0]), int(b[0])
 
 
 def value_classes(wires_mont: np.ndarray) -> dict:

@@ -928,7 +928,7 @@ __global__ __launch_bounds__(kThreads) CAP_ACC_ATTR void msm_accumulate(const g1
                                                            const uint32_t* __restrict__ item_bucket,
                                                            const uint32_t* __restrict__ item_sub, size_t per,
                                                            uint32_t half, uint32_t batch, uint32_t item_len,
-                                                           uint32_t dynamic, g1_xyzz* __restrict__ item_pts,
+                                                           uint32_t* chunk_counter, g1_xyzz* __restrict__ item_pts,
                                                            g1_xyzz* __restrict__ buckets) {
   // Grid-stride over the items: with a grid of a few workgroups per CU (accumulate_persistent) a workgroup walks chunk
   // b, b + G, b + 2G, ... itself instead of being dispatched once per chunk.  G is a multiple of 8, so a chunk stays on the
@@ -937,8 +937,10 @@ __global__ __launch_bounds__(kThreads) CAP_ACC_ATTR void msm_accumulate(const g1
   __shared__ uint32_t chunk_s;
   for (uint32_t round = 0;; round++) {
     uint32_t it;
-    if (dynamic) {  // the next chunk of 256 items from a counter: a workgroup that finishes early takes more
-      if (threadIdx.x == 0) chunk_s = atomicAdd(const_cast<uint32_t*>(item_base) + batch + 1, 1u);
+    if (chunk_counter) {  // the next chunk of 256 items from a counter: a workgroup that finishes early takes more
+      // (the counter is the word behind the item bases - zeroed with them - passed as a pointer of its own: item_base
+      // is const __restrict__ and must not be written through)
+      if (threadIdx.x == 0) chunk_s = atomicAdd(chunk_counter, 1u);
       __syncthreads();
       const uint32_t chunk = chunk_s;
       __syncthreads();
@@ -2297,7 +2299,8 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
     launch("msm_accumulate", msm_accumulate, dim3(wgs), dim3(at),
            accumulate_lds_bytes(), stream, t.ext, (const uint32_t*)t.sorted, (const uint32_t*)t.counts, (const uint32_t*)t.offsets,
            (const uint32_t*)t.item_off, (const uint32_t*)t.item_base, (const uint32_t*)t.item_bucket,
-           (const uint32_t*)t.item_sub, t.per, half, sb, item_len, dynamic ? 1u : 0u, t.item_pts, t.buckets);
+           (const uint32_t*)t.item_sub, t.per, half, sb, item_len, dynamic ? t.item_base + sb + 1 : (uint32_t*)nullptr,
+           t.item_pts, t.buckets);
   }
   // bucket = sum of its items, one thread per bucket; the few buckets of many items go to a list (msm_accumulate's item
   // list, dead by now, holds it; its length sits behind the item bases) and get 32 lanes each

@@ -276,3 +276,38 @@ void capwit_value_classes(const uint64_t* vals, uint64_t count, uint64_t* out) {
     else out[3]++;
   }
 }
+
+/* Work of one MSM on these scalars with signed base-2^c digits on a shared bucket set (msm.hip: msm_digit): the number of
+ * non-zero digits (= bucket-list entries) and of non-empty buckets; mixed additions = entries - non-empty buckets.
+ * vals: Montgomery [count][4]; c <= 24. */
+void capwit_msm_work(const uint64_t* vals, uint64_t count, uint32_t c, uint64_t* entries_out, uint64_t* buckets_out) {
+  const uint32_t half = 1u << (c - 1), mask = (1u << c) - 1, windows = (254 + c - 1) / c;
+  uint8_t* hit = (uint8_t*)calloc((size_t)half + 1, 1);
+  uint64_t entries = 0, buckets = 0;
+  fr one = {{1, 0, 0, 0}};
+  for (uint64_t i = 0; i < count; i++) {
+    fr k = f_mul((const fr*)(vals + 4 * i), &one);
+    uint32_t carry = 0;
+    for (uint32_t w = 0; w < windows; w++) {
+      const uint32_t bit = w * c, limb = bit >> 6, off = bit & 63;
+      uint64_t v = limb < 4 ? k.v[limb] >> off : 0;
+      if (off + c > 64 && limb + 1 < 4) v |= k.v[limb + 1] << (64 - off);
+      uint32_t d = ((uint32_t)v & mask) + carry;
+      carry = 0;
+      if (d > half) {
+        d = (1u << c) - d;
+        carry = 1;
+      }
+      if (d) {
+        entries++;
+        if (hit && !hit[d]) {
+          hit[d] = 1;
+          buckets++;
+        }
+      }
+    }
+  }
+  free(hit);
+  *entries_out = entries;
+  *buckets_out = buckets;
+}

@@ -3,6 +3,7 @@
 Same names and argument meaning as `/root/reference/src/proof/`:
   universal_setup       src/proof/mod.rs:59-69     (SRS = powers of tau in G1; synthetic tau here)
   load_srs              src/proof/mod.rs:74-109    (degree bound, SHA-256 integrity check, the whole CRS file loaded)
+  universal_setup_for_staging  src/proof/mod.rs:121-141  (bn254: alias of load_srs, rng ignored)
   preprocess            src/proof/transfer.rs:124-155, mint.rs:69-93, freeze.rs:93-121
   prove                 src/proof/transfer.rs:159-188, mint.rs:97-120, freeze.rs:125-158
   verify                src/proof/transfer.rs:192-212, mint.rs:124-140, freeze.rs:162-178
@@ -136,6 +137,13 @@ def load_srs(max_degree: int, crs_bytes: bytes, expected_sha256: bytes = AZTEC_C
         return UniversalSrs(handle, _lib.srs_size(handle) - 1, h, beta_h)
     except _lib.CapGpuError as e:
         raise TxnApiError.FailedSnark(f"Failed to load SRS: {e}") from e
+
+
+def universal_setup_for_staging(max_degree: int, _rng, crs_bytes: bytes,
+                                expected_sha256: bytes = AZTEC_CRS_SHA256) -> UniversalSrs:
+    """src/proof/mod.rs:121-141: under the reference's default feature (bn254) the unified staging API ignores its rng
+    and loads Aztec's CRS - an alias of load_srs (the other feature branch generates a fresh SRS: universal_setup)."""
+    return load_srs(max_degree, crs_bytes, expected_sha256)
 
 
 def preprocess(srs: UniversalSrs, n: int, num_inputs: int, selectors: np.ndarray, sigma_evals: np.ndarray,

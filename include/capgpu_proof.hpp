@@ -7,6 +7,7 @@
 //   capgpu::proof::load_srs                   src/proof/mod.rs:74-109   (the bytes of data/aztec-crs-131072.bin - an
 //                                             ark-serialized UniversalSrs, src/proof/mod.rs:106 - handed in by the caller:
 //                                             the reference embeds them with include_bytes!, its tree does not ship them)
+//   capgpu::proof::universal_setup_for_staging src/proof/mod.rs:121-141  (bn254: an alias of load_srs, rng ignored)
 //   capgpu::proof::{transfer,mint,freeze}::preprocess   src/proof/transfer.rs:124-155, mint.rs:69-93, freeze.rs:93-121
 //   capgpu::proof::{transfer,mint,freeze}::prove        src/proof/transfer.rs:159-188, mint.rs:97-120, freeze.rs:125-158
 //   capgpu::proof::{transfer,mint,freeze}::verify       src/proof/transfer.rs:192-212, mint.rs:124-140, freeze.rs:162-178
@@ -246,6 +247,15 @@ inline Result<UniversalSrs> load_srs(size_t max_degree, const std::vector<uint8_
   capgpu_srs_size(h, &n);
   s.max_degree = n ? n - 1 : 0;
   return s;
+}
+
+// src/proof/mod.rs:121-141: "a unified API for SRS generation for testing/staging" - under the reference's default
+// feature (bn254, the one this library implements) it IGNORES its rng and loads Aztec's CRS: a one-line alias of
+// load_srs.  The rng parameter is kept (any type, unused) so that call sites read like the reference's.
+template <class Rng>
+inline Result<UniversalSrs> universal_setup_for_staging(size_t max_degree, Rng& /*rng*/, const std::vector<uint8_t>& crs_bytes,
+                                                        const std::array<uint8_t, 32>& expected_sha256 = aztec_crs_sha256()) {
+  return load_srs(max_degree, crs_bytes, expected_sha256);
 }
 
 namespace detail_snark {

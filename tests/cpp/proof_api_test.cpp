@@ -289,6 +289,15 @@ int main(int argc, char** argv) {
       panicked = true;
     }
     ASSERT(panicked);
+    // universal_setup_for_staging (src/proof/mod.rs:121-141): the bn254 branch is load_srs, its rng is not touched
+    {
+      int untouched_rng = 7;
+      auto staged = proof::universal_setup_for_staging(max_degree, untouched_rng, crs, digest);
+      ASSERT(staged.is_ok() && untouched_rng == 7);
+      if (staged.is_ok()) ASSERT(staged.unwrap().max_degree == max_degree && staged.unwrap().h == universal_param.h);
+      auto staged_big = proof::universal_setup_for_staging(((size_t)1 << 17) + 1, untouched_rng, crs, digest);
+      ASSERT(staged_big.is_err());
+    }
     auto loaded = proof::load_srs(max_degree, crs, digest);
     ASSERT(loaded.is_ok());
     if (loaded.is_ok()) {

@@ -403,6 +403,10 @@ def test_load_srs_mirror(cg, tau):
     srs = capproof.load_srs(20, blob, hashlib.sha256(blob).digest())
     assert srs.max_degree == 34 and cg.srs_size(srs.handle) == 35
     cg.srs_free(srs.handle)
+    # src/proof/mod.rs:121-141: the staging API of the default (bn254) feature is load_srs with its rng ignored
+    srs2 = capproof.universal_setup_for_staging(20, object(), blob, hashlib.sha256(blob).digest())
+    assert srs2.max_degree == 34
+    cg.srs_free(srs2.handle)
 
 
 def test_load_srs_guards_run_before_any_device_work():
@@ -418,6 +422,11 @@ def test_load_srs_guards_run_before_any_device_work():
     with pytest.raises(AssertionError, match="Mismatched sha256sum digest"):
         capproof.load_srs(100, bytes(bad), hashlib.sha256(blob).digest())
     assert capproof.AZTEC_CRS_SHA256.hex() == "6b81e75fb9c14fd0e58fb2b29e48978cdad5511503685a61f1391dc4a4fc7cbf"
+    # universal_setup_for_staging (src/proof/mod.rs:121-141) is the same function: same guards, rng untouched
+    with pytest.raises(capproof.TxnApiError, match="only supports 2\\^17"):
+        capproof.universal_setup_for_staging((1 << 17) + 1, None, blob, hashlib.sha256(blob).digest())
+    with pytest.raises(AssertionError, match="Mismatched sha256sum digest"):
+        capproof.universal_setup_for_staging(1 << 17, None, blob)
 
 
 @pytest.mark.gpu
