@@ -829,6 +829,7 @@ void capgpu_shutdown(void) {
       (void)hipSetDevice(c.device);
       (void)hipStreamSynchronize(c.stream);
       if (c.copy_stream) (void)hipStreamSynchronize(c.copy_stream);
+      if (c.side_stream) (void)hipStreamSynchronize(c.side_stream);
     }
     {
       std::map<uint64_t, std::shared_ptr<ScalarSet>> sets;
@@ -862,7 +863,11 @@ void capgpu_shutdown(void) {
       c.tm0 = c.tm1 = nullptr;
       if (c.own_stream) hipStreamDestroy(c.own_stream);
       if (c.copy_stream) hipStreamDestroy(c.copy_stream);
-      c.own_stream = c.stream = c.copy_stream = nullptr;
+      if (c.side_stream) hipStreamDestroy(c.side_stream);
+      if (c.ev_fork) hipEventDestroy(c.ev_fork);
+      if (c.ev_join) hipEventDestroy(c.ev_join);
+      c.ev_fork = c.ev_join = nullptr;
+      c.own_stream = c.stream = c.copy_stream = c.side_stream = nullptr;
       c.initialised = false;
     }
     R.initialised.store(false, std::memory_order_release);

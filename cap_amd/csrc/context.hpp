@@ -100,6 +100,9 @@ struct Context {
   bool primary = true;  // the first context of its capgpu_init entry: the ones a sharded SRS is cut over
   hipStream_t own_stream = nullptr;
   hipStream_t copy_stream = nullptr;  // H2D of host-resident witnesses (plonk.hip), created on first use
+  // small batches: round 1's interpolations and coset transforms beside its commitment MSMs (plonk.hip: side_stream)
+  hipStream_t side_stream = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t stream = nullptr;  // the stream work is enqueued on (own_stream unless capgpu_set_stream)
   hipEvent_t tm0 = nullptr, tm1 = nullptr;  // capgpu_timer_begin / _end
   NttSmallTables small;

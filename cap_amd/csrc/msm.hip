@@ -159,7 +159,15 @@ __global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __re
                                                              uint32_t top_shift,
                                                              uint32_t* __restrict__ table,
                                                              uint32_t* __restrict__ tloc,
-                                                             uint32_t* __restrict__ chunks) {
+                                                             uint32_t* __restrict__ chunks,
+                                                             uint32_t* __restrict__ sync_a, uint32_t n_a,
+                                                             uint32_t* __restrict__ sync_b, uint32_t n_b) {
+  // the flag words of this launch's chained kernels (msm_scan_chained, msm_items): zeroed here, by the first kernel of
+  // the launch, so that no separate memset sits on the path of a small MSM
+  if (blockIdx.x == 0) {
+    for (uint32_t j = threadIdx.x; j < n_a; j += kDigitThreads) sync_a[j] = 0;
+    for (uint32_t j = threadIdx.x; j < n_b; j += kDigitThreads) sync_b[j] = 0;
+  }
   // sub_bits == 0: the tile is sorted by bucket.  sub_bits > 0 (two-level sort for wide windows): it is sorted by
   // bin = bucket >> sub_bits only, and the low bucket bits ride in bits 24..30 of the entry for msm_sort_level2.
   extern __shared__ uint32_t lds[];
@@ -270,22 +278,6 @@ __global__ __launch_bounds__(kDigitThreads) void msm_digits_local(const fe* __re
   for (uint32_t e = threadIdx.x; e < total; e += kDigitThreads) dst[e] = buf[e];
 }
 
-// bucket list ranges from the scanned [bucket][tile] table
-__global__ __launch_bounds__(kThreads) void msm_bucket_ranges(const uint32_t* __restrict__ table,
-                                                              const uint32_t* __restrict__ off2, uint32_t half,
-                                                              uint32_t nblk, uint32_t total_buckets,
-                                                              uint32_t* __restrict__ counts,
-                                                              uint32_t* __restrict__ offsets) {
-  uint32_t gb = blockIdx.x * blockDim.x + threadIdx.x;
-  if (gb >= total_buckets) return;
-  uint32_t bucket = gb % half;
-  size_t row = (size_t)gb * nblk;
-  uint32_t o = off2[row];
-  uint32_t next = bucket + 1 < half ? off2[row + nblk] : off2[row + nblk - 1] + table[row + nblk - 1];
-  offsets[gb] = o;
-  counts[gb] = next - o;
-}
-
 // K4: every (bucket, tile) run of a tile-sorted chunk is copied to its final place; runs of one bucket from
 // consecutive tiles are adjacent in the destination, so consecutive threads write consecutive bytes.
 __global__ __launch_bounds__(kThreads) void msm_scatter_runs(const uint32_t* __restrict__ chunks,
@@ -295,12 +287,20 @@ __global__ __launch_bounds__(kThreads) void msm_scatter_runs(const uint32_t* __r
                                                              uint32_t half, uint32_t nblk, uint32_t windows,
                                                              size_t total_rows, size_t srs_n, size_t offset,
                                                              size_t n_sub, uint32_t parts,
-                                                             uint32_t* __restrict__ sorted) {
+                                                             uint32_t* __restrict__ sorted,
+                                                             uint32_t* __restrict__ counts,
+                                                             uint32_t* __restrict__ offsets) {
   size_t row = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // (b * half + bucket) * nblk + blk
   if (row >= total_rows) return;
   uint32_t cnt = table[row];
-  if (cnt == 0) return;
   uint32_t blk = (uint32_t)(row % nblk);
+  if (blk == 0) {  // the bucket's list range (what msm_bucket_ranges was a launch of its own for)
+    const uint32_t gb = (uint32_t)(row / nblk), o = off2[row];
+    const uint32_t next = gb % half + 1 < half ? off2[row + nblk] : off2[row + nblk - 1] + table[row + nblk - 1];
+    offsets[gb] = o;
+    counts[gb] = next - o;
+  }
+  if (cnt == 0) return;
   uint32_t b = (uint32_t)(row / ((size_t)half * nblk));
   const uint32_t* src = chunks + ((size_t)b * nblk + blk) * ((size_t)kDigitTile * windows) + tloc[row];
   uint32_t* dst = sorted + (size_t)b * per + off2[row];
@@ -759,6 +759,82 @@ __global__ __launch_bounds__(1024) void msm_scan_add(uint32_t* __restrict__ offs
   for (uint32_t i = sg * kScanSeg + threadIdx.x; i < (sg + 1) * kScanSeg && i < nb; i += 1024) off[i] += base;
 }
 
+// ---- chained forms for small launches (round 5) ------------------------------------------------------------------
+// A single 2^17-point MSM spent 0.14 of its 0.49 ms in nine short launches in front of the accumulation - digits, three
+// scan kernels, ranges, scatter, item scan, item bases, item sort - each ~6 us of launch and drain for a few microseconds
+// of work.  The three scan kernels become ONE (every segment publishes its total behind a flag and adds up the totals
+// of the segments before it: a chained scan), the ranges ride in the scatter kernel, and the three item kernels become
+// ONE (msm_items).  Workgroups take their index from a ticket counter, so a workgroup only ever waits for workgroups
+// that are already running; the flag words are zeroed by msm_digits_local, the first kernel of the launch.
+constexpr uint32_t kFlag = 0x80000000u;  // totals stay below 2^31 (batch_slice keeps every per-launch counter in 31 bits)
+
+// exclusive prefix of `v` over the 1024 threads of a workgroup (wave shuffles + one pass over the 16 wave totals);
+// returns the prefix, *total = the sum.  sh: 17 words.
+__device__ __forceinline__ uint32_t block_scan_1024(uint32_t v, uint32_t* sh, uint32_t* total) {
+  const uint32_t lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  uint32_t inc = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const uint32_t o = __shfl_up(inc, d);
+    if ((int)lane >= d) inc += o;
+  }
+  __syncthreads();  // (sh may still be read from a previous call)
+  if (lane == 63) sh[wave] = inc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t run = 0;
+    for (int w = 0; w < 16; w++) {
+      const uint32_t x = sh[w];
+      sh[w] = run;
+      run += x;
+    }
+    sh[16] = run;
+  }
+  __syncthreads();
+  *total = sh[16];
+  return sh[wave] + inc - v;
+}
+// sum over j < count of the totals published in state[j] (spinning until each is there); all 1024 threads call it
+__device__ __forceinline__ uint32_t chained_base(const uint32_t* state, uint32_t count, uint32_t* sh) {
+  uint32_t acc = 0;
+  for (uint32_t j = threadIdx.x; j < count; j += 1024) {
+    uint32_t x;
+    do {
+      x = __hip_atomic_load(&state[j], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT);
+    } while (!(x & kFlag));
+    acc += x & ~kFlag;
+  }
+  uint32_t tot;
+  (void)block_scan_1024(acc, sh, &tot);
+  return tot;
+}
+// exclusive scan of nb counters per batch entry in ONE launch: grid = nseg * batch workgroups of 8192 counters
+__global__ __launch_bounds__(1024) void msm_scan_chained(const uint32_t* __restrict__ counts, uint32_t* __restrict__ offsets,
+                                                         uint32_t nb, uint32_t nseg, uint32_t* state /*[batch][nseg]*/,
+                                                         uint32_t* ticket) {
+  __shared__ uint32_t sh[17];
+  __shared__ uint32_t tk;
+  if (threadIdx.x == 0) tk = atomicAdd(ticket, 1u);
+  __syncthreads();
+  const uint32_t b = tk / nseg, sg = tk % nseg;
+  const uint32_t* cnt = counts + (size_t)b * nb;
+  uint32_t* off = offsets + (size_t)b * nb;
+  const uint32_t idx0 = sg * kScanSeg + threadIdx.x * 8;
+  uint32_t v[8], run = 0;
+#pragma unroll
+  for (uint32_t t = 0; t < 8; t++) {
+    v[t] = run;
+    run += idx0 + t < nb ? cnt[idx0 + t] : 0;
+  }
+  uint32_t total;
+  const uint32_t pre = block_scan_1024(run, sh, &total);
+  if (threadIdx.x == 0) __hip_atomic_store(&state[(size_t)b * nseg + sg], total | kFlag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  const uint32_t base = chained_base(state + (size_t)b * nseg, sg, sh);
+#pragma unroll
+  for (uint32_t t = 0; t < 8; t++)
+    if (idx0 + t < nb) off[idx0 + t] = base + pre + v[t];
+}
+
 // bucket = sum of its work items, G lanes per bucket: lanes take items, a shuffle tree adds them up.  For the
 // small-batch path, where there are too few buckets for one thread each (one thread per bucket is then a serial chain
 // on a handful of waves: 1.2 ms for 2^17 points).
@@ -891,6 +967,86 @@ __global__ __launch_bounds__(1024) void msm_sort_items(const uint32_t* __restric
       }
     }
     uint32_t pos = ib + atomicAdd(&cursor[q], items - r);
+    for (uint32_t k = r; k < items; k++) {
+      item_bucket[pos + k - r] = gb;
+      item_sub[pos + k - r] = k;
+    }
+  }
+}
+
+// msm_scan<1> + msm_item_bases + msm_sort_items in ONE launch (see "chained forms" above): workgroup b scans the item
+// counts of its batch entry (-> item_off), publishes the entry's total behind a flag, adds up the totals of the entries
+// before it (-> item_base[b]) and lays down its length-sorted item list.  state: [batch] flag words + the ticket counter
+// at [batch], zeroed by msm_digits_local.
+__global__ __launch_bounds__(1024) void msm_items(const uint32_t* __restrict__ counts, uint32_t half, uint32_t item_len,
+                                                  uint32_t batch, uint32_t* __restrict__ item_off,
+                                                  uint32_t* __restrict__ item_base, uint32_t* state,
+                                                  uint32_t* __restrict__ item_bucket, uint32_t* __restrict__ item_sub) {
+  __shared__ uint32_t hist[kMaxItemLen + 1];
+  __shared__ uint32_t cursor[kMaxItemLen + 1];
+  __shared__ uint32_t sh[17];
+  __shared__ uint32_t tk;
+  if (threadIdx.x == 0) tk = atomicAdd(state + batch, 1u);
+  for (uint32_t l = threadIdx.x; l <= kMaxItemLen; l += 1024) hist[l] = 0;
+  __syncthreads();
+  const uint32_t b = tk;
+  const uint32_t* cnt_b = counts + (size_t)b * half;
+  // item counts per bucket: exclusive scan in bucket order (8 consecutive buckets per thread and slab) + length histogram
+  uint32_t carry = 0;
+  for (uint32_t base = 0; base < half; base += 1024 * 8) {
+    const uint32_t j0 = base + threadIdx.x * 8;
+    uint32_t v[8], run = 0;
+#pragma unroll
+    for (uint32_t t = 0; t < 8; t++) {
+      const uint32_t cnt = j0 + t < half ? cnt_b[j0 + t] : 0;
+      const uint32_t items = (cnt + item_len - 1) / item_len;
+      v[t] = run;
+      run += items;
+      if (cnt) {
+        const uint32_t q = cnt / items, r = cnt - q * items;
+        if (r) atomicAdd(&hist[q + 1], r);
+        atomicAdd(&hist[q], items - r);
+      }
+    }
+    uint32_t tot;
+    const uint32_t pre = block_scan_1024(run, sh, &tot);
+#pragma unroll
+    for (uint32_t t = 0; t < 8; t++)
+      if (j0 + t < half) item_off[(size_t)b * half + j0 + t] = carry + pre + v[t];
+    carry += tot;
+  }
+  if (threadIdx.x == 0) __hip_atomic_store(&state[b], carry | kFlag, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+  // cursors of the length classes: even entries list their items longest first, odd ones shortest first (msm_sort_items)
+  {
+    const uint32_t t = threadIdx.x;
+    const uint32_t l = (b & 1) ? t : kMaxItemLen - t;
+    const uint32_t v = t <= kMaxItemLen ? hist[l] : 0;
+    uint32_t tot;
+    const uint32_t pre = block_scan_1024(v, sh, &tot);
+    if (t <= kMaxItemLen) cursor[l] = pre;
+  }
+  const uint32_t ib = chained_base(state, b, sh);  // (ends with barriers: the cursors are visible)
+  if (threadIdx.x == 0) {
+    item_base[b] = ib;
+    if (b + 1 == batch) {
+      item_base[batch] = ib + carry;
+      item_base[batch + 1] = 0;  // chunk counter of a dynamic msm_accumulate launch
+      item_base[batch + 2] = 0;  // length of msm_combine's list of heavy buckets
+    }
+  }
+  for (uint32_t j = threadIdx.x; j < half; j += 1024) {
+    const uint32_t gb = b * half + j;
+    const uint32_t cnt = cnt_b[j];
+    if (cnt == 0) continue;
+    const uint32_t items = (cnt + item_len - 1) / item_len, q = cnt / items, r = cnt - q * items;
+    if (r) {
+      const uint32_t pos = ib + atomicAdd(&cursor[q + 1], r);
+      for (uint32_t k = 0; k < r; k++) {
+        item_bucket[pos + k] = gb;
+        item_sub[pos + k] = k;
+      }
+    }
+    const uint32_t pos = ib + atomicAdd(&cursor[q], items - r);
     for (uint32_t k = r; k < items; k++) {
       item_bucket[pos + k - r] = gb;
       item_sub[pos + k - r] = k;
@@ -1994,6 +2150,14 @@ uint32_t choose_item_len(size_t entries, size_t buckets) {
   size_t l = entries / ((size_t)1 << 19);
   return (uint32_t)std::min<size_t>(std::max<size_t>(l, std::min<size_t>(floor_len, cap)), cap);
 }
+// the chained forms of the small kernels in front of the accumulation (CAPGPU_MSM_CHAINED=0: the separate launches)
+bool chained_enabled() {
+  static const bool on = [] {
+    const char* e = getenv("CAPGPU_MSM_CHAINED");
+    return !e || atoi(e) != 0;
+  }();
+  return on;
+}
 // sb = sub-MSMs of the launch (batch * parts), n = points per sub-MSM
 WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t sb, uint32_t sub_bits, bool has_parts) {
   WsLayout L{};
@@ -2020,7 +2184,7 @@ WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t sb, uint32_t
   L.max_items = per * sb / choose_item_len(per * sb, half * sb) + half * sb;  // sum ceil(cnt/L) <= entries/L + buckets
   L.item_off = o;    o = align_up(o + sizeof(uint32_t) * half * sb, 256);
   L.item_base = o;   o = align_up(o + sizeof(uint32_t) * ((size_t)sb + 3), 256);
-  L.totals = o;      o = align_up(o + sizeof(uint32_t) * sb, 256);
+  L.totals = o;      o = align_up(o + sizeof(uint32_t) * ((size_t)sb + 1), 256);  // (+ 1: msm_items' ticket counter)
   L.item_bucket = o; o = align_up(o + sizeof(uint32_t) * L.max_items, 256);
   L.item_sub = o;    o = align_up(o + sizeof(uint32_t) * L.max_items, 256);
   L.item_pts = o;    o = align_up(o + sizeof(g1_xyzz) * L.max_items, 256);
@@ -2031,7 +2195,7 @@ WsLayout ws_layout(uint32_t c, uint32_t windows, size_t n, uint32_t sb, uint32_t
   L.chunks = o;      o = align_up(o + sizeof(uint32_t) * (size_t)kDigitTile * windows * L.nblk * sb, 256);
   {
     size_t rows = std::max<size_t>(bins * L.nblk, half);
-    L.seg_tot = o;   o = align_up(o + sizeof(uint32_t) * ((rows + kScanSeg - 1) / kScanSeg) * sb, 256);
+    L.seg_tot = o;   o = align_up(o + sizeof(uint32_t) * (((rows + kScanSeg - 1) / kScanSeg) * sb + 1), 256);  // (+ 1: ticket)
   }
   L.part_pts = o;    o = align_up(o + sizeof(g1_xyzz) * (has_parts ? sb : 0), 256);
   L.total = o;
@@ -2076,7 +2240,7 @@ DeepLayout deep_layout(const Plan& pl, size_t n) {
   L.pairs = take(sizeof(g1_xyzz) * 2 * (nb / kDeepReduceBuckets));
   L.item_off = take(4 * nb);
   L.item_base = take(4 * ((size_t)L.sbp + 3));
-  L.totals = take(4 * (size_t)L.sbp);
+  L.totals = take(4 * ((size_t)L.sbp + 1));
   L.item_bucket = take(4 * L.max_items);
   L.item_sub = take(4 * L.max_items);
   L.item_pts = take(sizeof(g1_xyzz) * L.max_items);
@@ -2269,6 +2433,7 @@ struct Tail {
   // != 0 (with seg_len): the reduction sees the bucket array as entries of this many buckets - smaller than `half`, which
   // sizes the length-sorted item lists - so that the one-wave finish of an entry is a short chain
   uint32_t reduce_half = 0;
+  bool chained = false;  // the item kernels as one chained launch (msm_items); the digits kernel zeroed t.totals[0 .. sb]
 };
 void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, hipStream_t stream) {
   const uint32_t half = t.half, sb = t.sb, item_len = t.item_len;
@@ -2279,11 +2444,16 @@ void run_tail(const Tail& t, g1_jac* out, g1_xyzz* out_part, g1_xyzz* out_pair, 
                     sb <= (half <= 4096 ? quad_max_batch() : quad_max_batch_wide());
   const bool segments = t.seg_len != 0 || (use_segment_reduce(half, sb) && !quad);
   const uint32_t total_buckets = half * sb;
-  launch("msm_scan_items", msm_scan<1>, dim3(sb), dim3(1024), 0, stream, (const uint32_t*)t.counts, t.item_off, half,
-         t.totals, item_len);
-  launch("msm_item_bases", msm_item_bases, dim3(1), dim3(1024), 0, stream, (const uint32_t*)t.totals, sb, t.item_base);
-  launch("msm_sort_items", msm_sort_items, dim3(sb), dim3(1024), 0, stream, (const uint32_t*)t.counts,
-         (const uint32_t*)t.item_base, half, item_len, t.item_bucket, t.item_sub);
+  if (t.chained) {  // (t.totals: the flag words msm_digits_local zeroed)
+    launch("msm_items", msm_items, dim3(sb), dim3(1024), 0, stream, (const uint32_t*)t.counts, half, item_len, sb, t.item_off,
+           t.item_base, t.totals, t.item_bucket, t.item_sub);
+  } else {
+    launch("msm_scan_items", msm_scan<1>, dim3(sb), dim3(1024), 0, stream, (const uint32_t*)t.counts, t.item_off, half,
+           t.totals, item_len);
+    launch("msm_item_bases", msm_item_bases, dim3(1), dim3(1024), 0, stream, (const uint32_t*)t.totals, sb, t.item_base);
+    launch("msm_sort_items", msm_sort_items, dim3(sb), dim3(1024), 0, stream, (const uint32_t*)t.counts,
+           (const uint32_t*)t.item_base, half, item_len, t.item_bucket, t.item_sub);
+  }
   if (t.max_items > 0) {
     const unsigned at = accumulate_threads();
     unsigned wgs = (unsigned)((t.max_items + at - 1) / at);
@@ -2449,7 +2619,8 @@ int msm_run_deep(const MsmBases& bases, const Plan& pl, size_t offset, const fe*
                           : msm_digits_local<22, true>;
     const size_t lds_bytes = sizeof(uint32_t) * (2 * (size_t)S1 + (size_t)kDigitTile * W);
     launch("msm_digits_local", kern, dim3(nblk), dim3(kDigitThreads), lds_bytes, stream, d_scalars, (size_t)0, 1u,
-           (size_t)0, n, n, 1u, montgomery, c, W, nblk, 1u, pl.sub_bits, bases.top_shift3, table, tloc, chunks);
+           (size_t)0, n, n, 1u, montgomery, c, W, nblk, 1u, pl.sub_bits, bases.top_shift3, table, tloc, chunks,
+           (uint32_t*)nullptr, 0u, u32(L.totals), chained_enabled() ? L.sbp + 1 : 0u);
   }
   scan(table, off2, (size_t)S1 * nblk);
   // level 2: (super-bin, group of tiles) sorted by the middle key bits, written back in super-bin-major order
@@ -2483,6 +2654,7 @@ int msm_run_deep(const MsmBases& bases, const Plan& pl, size_t offset, const fe*
   t.planes = 15;  // (unused: the deep plan reduces by running sums)
   t.seg_len = kDeepSegLen;
   t.reduce_half = kDeepReduceBuckets;
+  t.chained = chained_enabled();
   g1_xyzz* pairs = pts(L.pairs);
   run_tail(t, nullptr, nullptr, pairs, stream);
   // reduction entry e holds buckets e * 4096 ..: total = sum_e T_e + 4096 * sum_e e * S_e
@@ -2518,12 +2690,22 @@ int msm_run_slice(const MsmBases& bases, const Plan& pl, size_t offset, const fe
   const fe* sc0 = d_scalars + (size_t)(first / inner) * outer_stride + (size_t)(first % inner) * inner_stride;
   // exclusive scan of `nb` counters per sub-MSM: one workgroup per entry, or - for a long table - segments in parallel
   uint32_t* seg_tot = reinterpret_cast<uint32_t*>(base + L.seg_tot);
+  const bool chained = chained_enabled();
+  // the long-table scan as one chained launch: its flag words (seg_tot) and ticket are zeroed by the digits kernel
+  auto scan_is_chained = [&](uint32_t nb) {
+    return chained && nb > 4 * kScanSeg && (size_t)((nb + kScanSeg - 1) / kScanSeg) * sb <= 65535;
+  };
   auto scan_counts = [&](const uint32_t* in, uint32_t* out, uint32_t nb) {
     if (nb <= 4 * kScanSeg) {
       launch("msm_scan", msm_scan<0>, dim3(sb), dim3(1024), 0, stream, in, out, nb, (uint32_t*)nullptr, 0u);
       return;
     }
     const uint32_t ns = (nb + kScanSeg - 1) / kScanSeg;
+    if (scan_is_chained(nb)) {
+      launch("msm_scan_chained", msm_scan_chained, dim3(ns * sb), dim3(1024), 0, stream, in, out, nb, ns, seg_tot,
+             seg_tot + (size_t)ns * sb);
+      return;
+    }
     launch("msm_scan_seg", msm_scan_seg, dim3(ns, sb), dim3(1024), 0, stream, in, out, nb, ns, seg_tot);
     launch("msm_scan_tot", msm_scan_tot, dim3(sb), dim3(1024), 0, stream, seg_tot, ns);
     launch("msm_scan_add", msm_scan_add, dim3(ns, sb), dim3(1024), 0, stream, out, nb, ns, (const uint32_t*)seg_tot);
@@ -2557,7 +2739,9 @@ int msm_run_slice(const MsmBases& bases, const Plan& pl, size_t offset, const fe
     launch("msm_digits_local", digits_kernel, dim3(sb == 1 ? nblk : nblk * ((sb + 7) / 8) * 8), dim3(kDigitThreads),
            lds_bytes, stream,
            sc0, outer_stride, inner, inner_stride, n, n_sub, parts, montgomery, c, W, nblk, sb, pl.sub_bits, 0u, table,
-           tloc, chunk_buf);
+           tloc, chunk_buf, seg_tot,
+           scan_is_chained(bins * nblk) ? (uint32_t)(((bins * nblk + kScanSeg - 1) / kScanSeg) * sb + 1) : 0u,
+           reinterpret_cast<uint32_t*>(base + L.totals), chained ? sb + 1 : 0u);
     scan_counts(table, off2, bins * nblk);
     if (pl.sub_bits) {
       // two-level sort: bins are finished per workgroup straight from the tile chunks
@@ -2565,12 +2749,11 @@ int msm_run_slice(const MsmBases& bases, const Plan& pl, size_t offset, const fe
              (const uint32_t*)table, (const uint32_t*)tloc, (const uint32_t*)off2, per, bins, nblk, W, pl.sub_bits,
              bases.n, offset, n_sub, parts, counts, offsets, sorted);
     } else {
-      launch("msm_bucket_ranges", msm_bucket_ranges, dim3((total_bins + kThreads - 1) / kThreads), dim3(kThreads), 0,
-             stream, (const uint32_t*)table, (const uint32_t*)off2, bins, nblk, total_bins, counts, offsets);
+      // (the buckets' list ranges - once msm_bucket_ranges, a launch of its own - are written by the rows of tile 0)
       size_t rows = (size_t)total_bins * nblk;
       launch("msm_scatter", msm_scatter_runs, dim3((unsigned)((rows + kThreads - 1) / kThreads)), dim3(kThreads), 0,
              stream, (const uint32_t*)chunk_buf, (const uint32_t*)table, (const uint32_t*)tloc, (const uint32_t*)off2,
-             per, bins, nblk, W, rows, bases.n, offset, n_sub, parts, sorted);
+             per, bins, nblk, W, rows, bases.n, offset, n_sub, parts, sorted, counts, offsets);
     }
   }
   Tail t{};
@@ -2593,6 +2776,7 @@ int msm_run_slice(const MsmBases& bases, const Plan& pl, size_t offset, const fe
   t.sb = sb;
   t.item_len = choose_item_len(per * sb, (size_t)half * sb);
   t.planes = c;
+  t.chained = chained;
   run_tail(t, d_out + first, part_pts, nullptr, stream);
   if (parts > 1)
     launch("msm_sum_parts", msm_sum_parts, dim3(batch), dim3(64), 0, stream, (const g1_xyzz*)part_pts, parts, d_out + first);

@@ -433,6 +433,31 @@ hipStream_t h2d_stream() {
     c.copy_stream = nullptr;
   return c.copy_stream;
 }
+// Small batches leave most of the chip idle during round 1's commitment MSMs (a chain of a dozen short launches per MSM
+// launch): the wire polynomials' interpolation, blinding and coset transforms - which round 3 needs, not the commitments
+// when those are taken from evaluations - run beside them on a side stream of the context (fork / join by events inside
+// segment 0, so a captured graph gets two branches).  CAPGPU_R1_OVERLAP_MAX: largest batch that does so (default 16,
+// 0 = off); large batches fill the chip either way.
+uint32_t r1_overlap_max() {
+  static const uint32_t v = [] {
+    const char* e = getenv("CAPGPU_R1_OVERLAP_MAX");
+    const int x = e ? atoi(e) : 16;
+    return (uint32_t)(x < 0 ? 0 : (x > 4096 ? 4096 : x));
+  }();
+  return v;
+}
+hipStream_t side_stream(Context& c) {
+  if (!c.side_stream) {
+    if (hipStreamCreateWithFlags(&c.side_stream, hipStreamNonBlocking) != hipSuccess) c.side_stream = nullptr;
+    if (c.side_stream && (hipEventCreateWithFlags(&c.ev_fork, hipEventDisableTiming) != hipSuccess ||
+                          hipEventCreateWithFlags(&c.ev_join, hipEventDisableTiming) != hipSuccess)) {
+      (void)hipStreamDestroy(c.side_stream);
+      c.side_stream = nullptr;
+    }
+    (void)hipGetLastError();
+  }
+  return c.side_stream;
+}
 // chunks of proofs the host-resident wire columns of a batch are copied and committed in (round 1 of prove_batch)
 uint32_t h2d_chunks(uint32_t P) {
   static const int forced = [] {
@@ -613,11 +638,11 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   // and the forward transform round 2 reads), blinding, and - when the batch is chunked - the chunk's commitments
   // the five commitments of proofs [p0, p0 + cnt): MSMs of the blinded polynomials' n + 2 coefficients on the monomial key,
   // or - same group elements - of each column's n VALUES followed by its two blinders on the Lagrange-form key.  The
-  // scalars of the second form are staged in the coset area, which round 3 fills only after these MSMs are through.
+  // scalars of the second form are staged in the quotient's array, which round 3 writes long after these MSMs.
   auto commit_wires = [&](uint32_t p0, uint32_t cnt) -> int {
     g1_jac* out = w.comms + (size_t)p0 * NW;
     if (!Lag) return run_msm(s, *B, w.wpoly + (size_t)p0 * NW * ps, ps, 1, 0, n + 2, cnt * NW, out);
-    fe* stage = w.coset + (size_t)p0 * NW * (n + 2);
+    fe* stage = w.t + (size_t)p0 * NW * (n + 2);
     const fe* ev = (coeffs ? (const fe*)w.wev : d_wires) + (size_t)p0 * NW * n;
     launch("k_stage_evals", k_stage_evals, dim3(cdiv(n + 2, kThreads), cnt * NW), dim3(kThreads), 0, s, ev, n,
            (const fe*)(w.d_blind + (size_t)p0 * 13), (uint32_t)NW, stage);
@@ -678,19 +703,59 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
     }
     if (chunks > 1 && (rc = r1_chunk_kernels(p0, p1 - p0, true))) return rc;
   }
+  hipStream_t s2 = nullptr;
+  const bool overlap = chunks == 1 && P <= r1_overlap_max() && !c.prof.on && !comm_shard_prover() && s == c.own_stream &&
+                       (s2 = side_stream(c)) != nullptr;
+  // round 3's coset evaluations of the wire and public-input polynomials (on the 6n quotient domain, straight from
+  // their coefficient arrays: the transform zero-extends them) depend on nothing the transcript still has to produce
+  auto r3_wire_cosets = [&](hipStream_t st) -> int {
+    int r = run_ntt3_fwd(st, K.log_m, w.coset, P * NW, NttIo{w.wpoly, NW * ps, ps, n + 2, NW, 7 * m, m, NW});
+    if (r) return r;
+    return run_ntt3_fwd(st, K.log_m, w.coset + 6 * m, P, NttIo{w.pi, n, 0, n, 1, 7 * m, 0, 1});
+  };
+  auto r1_overlapped = [&]() -> int {
+    int r;
+    // every transform below shares c.ntt_scratch: those of the side stream run in its order, the one in front of the
+    // fork before them.  The largest size is reserved now - a growth later would free a buffer still in use.
+    if ((r = scratch_reserve(c.ntt_scratch, (sizeof(fe) << K.log_m) * 6 * (size_t)P * NW))) return r;
+    auto interpolate_and_blind = [&](hipStream_t st) -> int {
+      int q = CAPGPU_OK;
+      if (coeffs) pad_copy(st, w.wpoly, ps, 0, d_wires, n, 0, 1, P * NW, n, n);
+      else q = run_ntt_from(st, K.log_n, d_wires, n, n, w.wpoly, ps, P * NW, 1, 0);
+      if (q) return q;
+      launch("k_blind", k_blind<1>, dim3(P * NW), dim3(64), 0, st, w.wpoly, ps, n, (const fe*)w.d_blind, (uint32_t)NW, 0u,
+             2u, P * NW);
+      return CAPGPU_OK;
+    };
+    // in front of the fork: what the commitments read
+    if (coeffs && (r = run_ntt_from(s, K.log_n, d_wires, n, n, w.wev, n, P * NW, 0, 0))) return r;
+    if (!Lag && (r = interpolate_and_blind(s))) return r;
+    CAP_HIP(hipEventRecord(c.ev_fork, s));
+    CAP_HIP(hipStreamWaitEvent(s2, c.ev_fork, 0));
+    // side stream: the polynomials and their coset evaluations
+    if (Lag && (r = interpolate_and_blind(s2))) return r;
+    if (num_inputs) {
+      if ((r = run_ntt_from(s2, K.log_n, w.d_pub, num_inputs, num_inputs, w.pi, n, P, 1, 0))) return r;
+    } else {
+      CAP_HIP(hipMemsetAsync(w.pi, 0, sizeof(fe) * (size_t)P * n, s2));
+    }
+    if ((r = r3_wire_cosets(s2))) return r;
+    // main stream: the five commitments
+    if ((r = commit_wires(0, P))) return r;
+    CAP_HIP(hipEventRecord(c.ev_join, s2));
+    CAP_HIP(hipStreamWaitEvent(s, c.ev_join, 0));
+    return CAPGPU_OK;
+  };
   if ((rc = seg(0, [&]() -> int {
+         if (overlap) return r1_overlapped();
          int r = chunks == 1 ? r1_chunk_kernels(0, P, false) : CAPGPU_OK;
          return r ? r : r1_tail_kernels();
        })))
     return rc;
-  // round 3's coset evaluations of the wire and public-input polynomials (on the 6n quotient domain, straight from
-  // their coefficient arrays: the transform zero-extends them) depend on nothing the transcript still has to produce
+  // (enqueued behind the commitments while the host hashes - unless the side stream already ran them beside the MSMs)
   if ((rc = fetch_comms(P * NW, [&]() -> int {
-         return seg(1, [&]() -> int {
-           int r = run_ntt3_fwd(s, K.log_m, w.coset, P * NW, NttIo{w.wpoly, NW * ps, ps, n + 2, NW, 7 * m, m, NW});
-           if (r) return r;
-           return run_ntt3_fwd(s, K.log_m, w.coset + 6 * m, P, NttIo{w.pi, n, 0, n, 1, 7 * m, 0, 1});
-         });
+         if (overlap) return CAPGPU_OK;
+         return seg(1, [&]() -> int { return r3_wire_cosets(s); });
        })))
     return rc;
   std::vector<Chal> chal(P);
