@@ -47,9 +47,17 @@ ScalarSet::~ScalarSet() {
   for (ScalarSlice& sl : slices) {
     if (!sl.d) continue;
     if (sl.slot >= 0 && (size_t)sl.slot < R.ctxs.size()) {
-      Context& c = *R.ctxs[(size_t)sl.slot];
-      ScopedCtx sc(c);
-      (void)hipStreamSynchronize(c.stream);
+      Context& home = *R.ctxs[(size_t)sl.slot];
+      // capgpu_msm_g1_resident lets ANY context of the slice's device run MSMs on it, on that context's own stream, and
+      // returns with the work enqueued: every such stream is drained - under its context's lock, in slot order, so that no
+      // capture or enqueue of another thread is in flight on it - before the memory goes (round-4 ADVICE)
+      for (auto& cp : R.ctxs) {
+        if (cp->device != home.device || !cp->initialised) continue;
+        ScopedCtx sc(*cp);
+        Entry lk(*cp);
+        (void)hipStreamSynchronize(cp->stream);
+      }
+      ScopedCtx sc(home);
       (void)hipFree(sl.d);
     }
     sl.d = nullptr;

@@ -31,6 +31,7 @@
 #include <thread>
 #include <vector>
 
+#include "coalescer.hpp"
 #include "context.hpp"
 #include "host_util.hpp"
 #include "launch.hpp"
@@ -772,6 +773,21 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   });
   CAP_HIP(hipMemcpyAsync(w.chal, chal.data(), sizeof(Chal) * P, hipMemcpyHostToDevice, s));
 
+  // the commitment to z and - independent of it - z's coset evaluations for round 3: one after the other (the second while
+  // the host hashes), or, for the small batches of `overlap`, side by side on the two streams
+  auto z_cosets = [&](hipStream_t st) -> int {
+    return run_ntt3_fwd(st, K.log_m, w.coset + 5 * m, P, NttIo{w.zpoly, ps, 0, n + 3, 1, 7 * m, 0, 1});
+  };
+  auto commit_z = [&]() -> int {
+    if (!overlap) return run_msm(s, *B, w.zpoly, ps, 1, 0, n + 3, P, w.comms);
+    CAP_HIP(hipEventRecord(c.ev_fork, s));
+    CAP_HIP(hipStreamWaitEvent(s2, c.ev_fork, 0));
+    int r = z_cosets(s2);
+    if (r == CAPGPU_OK) r = run_msm(s, *B, w.zpoly, ps, 1, 0, n + 3, P, w.comms);
+    CAP_HIP(hipEventRecord(c.ev_join, s2));
+    CAP_HIP(hipStreamWaitEvent(s, c.ev_join, 0));
+    return r;
+  };
   // ---- round 2: permutation grand product --------------------------------------------------------------
   if ((rc = seg(2, [&]() -> int {
          int r;
@@ -795,7 +811,7 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
                 (const fe*)w.sfx, (const fe*)w.den, (const fe*)w.inv_total, n, w.zpoly, ps);
          if ((r = run_ntt(s, K.log_n, w.zpoly, ps, P, 1, 0))) return r;
          launch("k_blind", k_blind<0>, dim3(P), dim3(64), 0, s, w.zpoly, ps, n, (const fe*)w.d_blind, 1u, 10u, 3u, P);
-         return run_msm(s, *B, w.zpoly, ps, 1, 0, n + 3, P, w.comms);
+         return commit_z();
        })))
     return rc;
   if (!inv_on_device) {
@@ -811,7 +827,9 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
       pref[p] = acc;
       if (!Fr::is_zero(tot[p])) acc = Fr::mul(acc, tot[p]);
     }
-    acc = Fr::inv(acc);
+    // (the product is a function of the secret witness: a fixed-length Fermat chain - 254 squarings whatever the value,
+    // ~20 us once per batch - instead of the variable-time Euclidean Fr::inv the public scalars of the other rounds use)
+    acc = Fr::inv_fermat(acc);
     for (uint32_t p = P; p-- > 0;) {
       if (Fr::is_zero(tot[p])) continue;
       const fe inv_p = Fr::mul(acc, pref[p]);
@@ -825,14 +843,13 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
                   (const fe*)w.sfx, (const fe*)w.den, (const fe*)w.inv_total, n, w.zpoly, ps);
            if ((r = run_ntt(s, K.log_n, w.zpoly, ps, P, 1, 0))) return r;
            launch("k_blind", k_blind<0>, dim3(P), dim3(64), 0, s, w.zpoly, ps, n, (const fe*)w.d_blind, 1u, 10u, 3u, P);
-           return run_msm(s, *B, w.zpoly, ps, 1, 0, n + 3, P, w.comms);
+           return commit_z();
          })))
       return rc;
   }
   if ((rc = fetch_comms(P, [&]() -> int {  // likewise the coset evaluations of z
-         return seg(3, [&]() -> int {
-           return run_ntt3_fwd(s, K.log_m, w.coset + 5 * m, P, NttIo{w.zpoly, ps, 0, n + 3, 1, 7 * m, 0, 1});
-         });
+         if (overlap) return CAPGPU_OK;
+         return seg(3, [&]() -> int { return z_cosets(s); });
        })))
     return rc;
   parallel_for(P, [&](uint32_t p) {
@@ -1132,18 +1149,10 @@ struct ProveReq {
   std::string err;
   bool done = false;
 };
-struct Coalescer {
-  std::mutex mu;
-  std::condition_variable cv;
-  // Calls are gathered per GROUP of proving keys - the keys of one domain size under one SRS, which one device batch
-  // can mix (prove_batch) - so that the transfer, mint and freeze notes the reference proves concurrently
-  // (src/utils/params_builder.rs:194-226) end up in as few batches as their domain sizes allow.
-  std::map<uint64_t, std::vector<ProveReq*>> pending;  // per group
-  std::map<uint64_t, bool> leader;
-  std::map<uint64_t, uint64_t> group_of;               // proving-key handle -> group id (handles are never reused)
-  uint32_t window_us = 0;  // 0 = off
-  uint32_t max_batch = 256;
-  std::atomic<uint64_t> batches{0}, proofs{0};
+// (the gathering protocol - queues, leaders, windows, the cut over two contexts - is coalescer.hpp, which also builds for
+// the host alone and runs under ThreadSanitizer there: tests/cpp/coalescer_tsan.cpp)
+struct Coalescer : CoalescerCore<ProveReq> {
+  std::map<uint64_t, uint64_t> group_of;  // (proving-key handle, input form) -> group id (handles are never reused)
 };
 Coalescer& coalescer() {
   static Coalescer c;
@@ -1905,109 +1914,54 @@ int capgpu_plonk_prove_ex(uint64_t pk_handle, const uint64_t* wires, const uint6
       group = it->second;
     }
   }
-  std::vector<ProveReq*>& q = co.pending[group];
-  q.push_back(&req);
-  if (q.size() >= co.max_batch) co.cv.notify_all();
-  bool waited_window = false;
-  while (!req.done) {
-    const bool queued = std::find(q.begin(), q.end(), &req) != q.end();
-    if (co.leader[group] || !queued) {  // somebody is gathering / proving a batch that holds (or will hold) this request
-      co.cv.wait_for(lk, std::chrono::milliseconds(1), [&] { return req.done; });
-      continue;
-    }
-    // this thread leads the group's next batch: collect for the window, and for as long as every device is busy
-    co.leader[group] = true;
-    if (!waited_window) {
-      // the window restarts while calls keep arriving (threads released by the previous batch come back one by one),
-      // up to 16 windows in all
-      const auto cap = std::chrono::steady_clock::now() + std::chrono::microseconds(16ull * co.window_us);
-      for (size_t seen = q.size();; seen = q.size()) {
-        const bool full =
-            co.cv.wait_for(lk, std::chrono::microseconds(co.window_us), [&] { return q.size() >= co.max_batch; });
-        if (full || q.size() == seen || std::chrono::steady_clock::now() >= cap) break;
-      }
-      waited_window = true;
-    }
+  // what the protocol needs from the runtime: free device contexts and the prover
+  struct Hooks {
     // a free device context: any of the process's (several batches are then in flight, one per context), or the one
-    // this thread bound itself to.  Later arrivals join the queue meanwhile.
-    Context* c = nullptr;
-    for (;;) {
-      const int ss = comm_shard_slot();  // mode A: gathered batches go to the communicator's context, whole
+    // this thread bound itself to; mode A of config 4: gathered batches go to the communicator's context, whole
+    void* acquire() {
+      const int ss = comm_shard_slot();
       const int bound = ss >= 0 && (size_t)ss < num_contexts() ? ss : thread_bound_slot();
       if (bound >= 0) {
         Context* b = rt().ctxs[(size_t)bound].get();
-        if (b->mu.try_lock()) c = b;
-      } else {
-        c = try_acquire_context();
+        return b->mu.try_lock() ? b : nullptr;
       }
-      if (c) break;
-      co.cv.wait_for(lk, std::chrono::microseconds(100));
+      return try_acquire_context();
     }
-    const size_t take = std::min<size_t>(q.size(), co.max_batch);
-    std::vector<ProveReq*> reqs(q.begin(), q.begin() + take);
-    q.erase(q.begin(), q.begin() + take);
-    co.leader[group] = false;
-    lk.unlock();
-    // a second free context takes half of a batch large enough to cut (like deal() does for host batches): the halves
-    // overlap on the device, or run on two devices
-    std::vector<ProveReq*> second;
-    Context* c2 = nullptr;
-    if (reqs.size() >= 2 * (size_t)deal_min() && thread_bound_slot() < 0 && comm_shard_slot() < 0 && num_contexts() > 1 &&
-        (c2 = try_acquire_context()) != nullptr) {
-      c2->mu.unlock();  // the helper thread locks it itself (the lock belongs to the thread that takes it)
-      // The cut is UNEVEN (3/8 : 5/8 by default, CAPGPU_COALESCE_SPLIT = eighths of the first part): callers that come
-      // straight back for their next proof (a rayon loop over notes) would otherwise return together, queue together and
-      // leave the device idle while every next batch is gathered and copied.  Two parts of different size end at
-      // different times; from then on each context runs its own group's batches and one is in flight while the other
-      // is being gathered.
+    void* acquire_second() {
+      if (thread_bound_slot() >= 0 || comm_shard_slot() >= 0 || num_contexts() <= 1) return nullptr;
+      Context* c2 = try_acquire_context();
+      if (c2) c2->mu.unlock();  // the helper thread locks it itself (the lock belongs to the thread that takes it)
+      return c2;
+    }
+    void run(void* ctx, std::vector<ProveReq*>& reqs, bool on_helper) {
+      Context& c = *static_cast<Context*>(ctx);
+      ScopedCtx sc(c);
+      if (on_helper) {
+        Entry elk(c);
+        run_coalesced(reqs);
+      } else {
+        run_coalesced(reqs);  // re-enters the (recursive) context lock this thread holds
+      }
+    }
+    void release(void* ctx) { static_cast<Context*>(ctx)->mu.unlock(); }
+    size_t deal_min() { return (size_t)::deal_min(); }
+    size_t split_eighths() {  // CAPGPU_COALESCE_SPLIT = eighths of the first part
       static const size_t eighths = [] {
         const char* e = getenv("CAPGPU_COALESCE_SPLIT");
         const int x = e ? atoi(e) : 3;
         return (size_t)(x >= 1 && x <= 4 ? x : 3);
       }();
-      const size_t first = std::max<size_t>((size_t)deal_min(), reqs.size() * eighths / 8);
-      second.assign(reqs.begin() + first, reqs.end());
-      reqs.resize(first);
+      return eighths;
     }
-    // Each part's callers are released when THEIR part is done (CAPGPU_COALESCE_EARLY=0: when both are, as before): the
-    // callers of the shorter part come back, are gathered and start on the freed context while the longer part still runs.
-    static const bool early = [] {
-      const char* e = getenv("CAPGPU_COALESCE_EARLY");
-      return !e || atoi(e) != 0;
-    }();
-    std::thread helper;
-    if (c2)
-      helper = std::thread([&second, c2, &co] {
-        {
-          ScopedCtx sc(*c2);
-          Entry elk(*c2);
-          run_coalesced(second);
-        }
-        if (early) {
-          std::lock_guard<std::mutex> g(co.mu);
-          for (ProveReq* r : second) r->done = true;  // (a request is not touched again once it is marked: its caller returns)
-          co.cv.notify_all();
-        }
-      });
-    {
-      ScopedCtx sc(*c);
-      run_coalesced(reqs);  // re-enters the (recursive) context lock this thread holds
+    bool early_release() {  // CAPGPU_COALESCE_EARLY=0: a cut batch's callers return when both parts are done, as before
+      static const bool early = [] {
+        const char* e = getenv("CAPGPU_COALESCE_EARLY");
+        return !e || atoi(e) != 0;
+      }();
+      return early;
     }
-    c->mu.unlock();
-    if (early) {
-      lk.lock();
-      for (ProveReq* r : reqs) r->done = true;
-      co.cv.notify_all();
-      lk.unlock();
-    }
-    if (helper.joinable()) helper.join();
-    lk.lock();
-    if (!early) {
-      for (ProveReq* r : reqs) r->done = true;
-      for (ProveReq* r : second) r->done = true;
-      co.cv.notify_all();
-    }
-  }
+  } hooks;
+  co.submit(lk, req, group, hooks);
   if (req.rc != CAPGPU_OK) set_error("%s", req.err.c_str());
   return req.rc;
 }

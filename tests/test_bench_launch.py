@@ -46,6 +46,23 @@ def test_gpus_2_without_a_launcher_runs_two_ranks():
 
 
 @pytest.mark.gpu
+def test_preflight_stops_a_launch_whose_ranks_share_a_device():
+    """round-4 VERDICT item 7: before anything is timed an N-rank launch proves that every rank has a device of its own
+    (and, under nccl, that RCCL spans all N and peers are reachable) or EVERY rank exits non-zero.  Two ranks on this
+    box's one GPU, with the enforcement forced on: exit code 5, no JSON line; with `--preflight report` the same launch
+    runs and the line carries the finding."""
+    env = {"CAPGPU_ALLOW_DUPLICATE_DEVICES": "1", "CAPGPU_BENCH_PREFLIGHT_FORCE": "1"}
+    r = run_bench(["--gpus", "2", "--no-msm"] + SMALL, env)
+    assert r.returncode != 0 and r.stdout.strip() == "", (r.returncode, r.stdout[-300:])
+    assert "pre-flight" in r.stderr and "share HIP devices" in r.stderr
+    r = run_bench(["--gpus", "2", "--no-msm", "--preflight", "report"] + SMALL, env)
+    assert r.returncode == 0, r.stderr[-1500:]
+    out = json.loads([ln for ln in r.stdout.splitlines() if ln.strip()][-1])
+    assert out["preflight"]["distinct_devices"] is False and out["preflight"]["enforced"] is False
+    assert any("share HIP devices" in p for p in out["preflight"]["problems"])
+
+
+@pytest.mark.gpu
 def test_single_process_model_reports_its_devices():
     r = run_bench(["--single-process", "--devices", "0,0", "--msm-log-n", "15"] + SMALL,
                   {"CAPGPU_ALLOW_DUPLICATE_DEVICES": "1", "CAPGPU_SHARD_MIN_POINTS": "4096"})

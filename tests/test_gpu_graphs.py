@@ -52,8 +52,10 @@ def test_replayed_proofs_are_the_direct_proofs(cg, tau, log_n, nin):
         d.upload(wm)
         got.append(bytes(cg.plonk_prove_batch_dev(pk, d, pm[None], bm[None], b"g", 1)[0]))
     cap1, rep1 = cg.plonk_graph_stats()
-    assert cap1 - cap0 == 8, "the second (or third) call captures the eight segments once"
-    assert rep1 - rep0 >= 8 * 2, "later calls replay them"
+    # (eight segments; six when round 1 runs its transforms on the side stream and segment 1 - the coset transforms
+    # behind the commitments - has nothing left to do: CAPGPU_R1_OVERLAP_MAX)
+    assert cap1 - cap0 in (6, 7, 8), "the second (or third) call captures the segments once"
+    assert rep1 - rep0 >= 6 * 2, "later calls replay them"
     for i in range(3):
         assert got[i] == got[i + 3]
         wm, pm, bm = insts[i]
