@@ -154,6 +154,39 @@ __device__ __forceinline__ void lds_ntt(fl* sh, const fl* __restrict__ tw_small,
     __syncthreads();
   }
   const uint32_t quarter_tile = half_tile >> 1;
+#ifdef CAP_NTT_EXPERIMENT_NO_LDS_ROUNDS
+  // TIMING EXPERIMENT ONLY (wrong results): the radix-4 rounds chained in registers - the same multiplications, twiddle
+  // loads and additions as the real rounds, but no LDS traffic and no barrier between them: what a register-resident
+  // radix-16 / radix-256 round could save at most (round 5, tools/gpujob_r05_nttexp.sh)
+  for (uint32_t g = threadIdx.x; g < quarter_tile; g += kThreads) {
+    const uint32_t c = g & cmask, gg = g >> log_c;
+    uint32_t i0 = (((gg >> s0) << (s0 + 2)) << log_c) + c, st = (1u << s0) << log_c;
+    fl a = sh[i0], b = sh[i0 + st], cc = sh[i0 + 2 * st], d = sh[i0 + 3 * st];
+    for (uint32_t s = s0; s + 1 < log_len; s += 2) {
+      const uint32_t h = 1u << s, pos = gg & (h - 1);
+      fl a1, b1, c1, d1, t;
+      const fl w1 = tw_small[pos << (log_len - 1 - s)];
+      t = Fr29::mul(b, w1);
+      a1 = Fr29::add(a, t);
+      b1 = Fr29::sub2p_lazy(a, t);
+      t = Fr29::mul(d, w1);
+      c1 = Fr29::add(cc, t);
+      d1 = Fr29::sub2p(cc, t);
+      t = Fr29::mul(c1, tw_small[pos << (log_len - 2 - s)]);
+      a = Fr29::normalize(Fr29::add(a1, t));
+      cc = Fr29::sub2p(a1, t);
+      t = Fr29::mul(d1, tw_small[(pos + h) << (log_len - 2 - s)]);
+      b = Fr29::normalize(Fr29::add(b1, t));
+      d = Fr29::sub2p(b1, t);
+    }
+    sh[i0] = a;
+    sh[i0 + st] = b;
+    sh[i0 + 2 * st] = cc;
+    sh[i0 + 3 * st] = d;
+  }
+  __syncthreads();
+  return;
+#endif
   for (uint32_t s = s0; s + 1 < log_len; s += 2) {
     const uint32_t h = 1u << s;
     const uint32_t step = h << log_c;

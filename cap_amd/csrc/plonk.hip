@@ -437,12 +437,13 @@ hipStream_t h2d_stream() {
 // Small batches leave most of the chip idle during round 1's commitment MSMs (a chain of a dozen short launches per MSM
 // launch): the wire polynomials' interpolation, blinding and coset transforms - which round 3 needs, not the commitments
 // when those are taken from evaluations - run beside them on a side stream of the context (fork / join by events inside
-// segment 0, so a captured graph gets two branches).  CAPGPU_R1_OVERLAP_MAX: largest batch that does so (default 16,
-// 0 = off); large batches fill the chip either way.
+// segment 0, so a captured graph gets two branches).  CAPGPU_R1_OVERLAP_MAX: largest batch that does so (default 3, 0 =
+// off).  Measured, same box (profiles/small_launch_ab_r05.txt): batch 1 2.59 -> 2.38 ms, batch 2 3.8 -> 3.7 ms, batch 4
+// even, batches of 8 and 16 1-2 % SLOWER - there the transforms no longer fit beside the MSMs, they only slow them down.
 uint32_t r1_overlap_max() {
   static const uint32_t v = [] {
     const char* e = getenv("CAPGPU_R1_OVERLAP_MAX");
-    const int x = e ? atoi(e) : 16;
+    const int x = e ? atoi(e) : 3;
     return (uint32_t)(x < 0 ? 0 : (x > 4096 ? 4096 : x));
   }();
   return v;
