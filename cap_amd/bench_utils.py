@@ -237,8 +237,11 @@ class SyntheticCircuit:
         return np.concatenate([to_mont_array(col) for col in wires]).reshape(NUM_WIRES, n, 4)
 
 
-def synthetic_circuit(log_n: int, num_inputs: int, seed: int = 2, fill: float = 0.94) -> SyntheticCircuit:
+def synthetic_circuit(log_n: int, num_inputs: int, seed: int = 2, fill: float = 0.94, skew: float = 0.0) -> SyntheticCircuit:
     """Random TurboPlonk circuit on a domain of 2^log_n rows.
+
+    skew > 0: that share of the free variables is drawn as booleans (3 in 4) or 64-bit values (1 in 4) instead of
+    uniformly - witnesses with heavy buckets and sparse digits, for the fuzzers of the commitments taken from evaluations.
 
     rows [0, num_inputs): IO gates (q_o = 1, wire 4 = public input);
     rows [num_inputs, gate_rows): arithmetic / Rescue-power / ECC-product gates whose inputs reuse
@@ -300,8 +303,15 @@ def synthetic_circuit(log_n: int, num_inputs: int, seed: int = 2, fill: float = 
         pool.append(v)
     # permutation: cells of one variable form a cycle; sigma value of cell (i, j) is k_i' * omega^j'
     sigma = _permutation(wv, num_vars, log_n)
+    free_class = None
+    if skew > 0:
+        crng = SplitMix64(seed ^ 0x5EED)
+        free_class = []
+        for _ in free_vars:
+            r = crng.next()
+            free_class.append((VAR_BOOL if (r >> 20) & 3 else VAR_U64) if (r & 0xFFFFF) < skew * (1 << 20) else VAR_UNIFORM)
     return SyntheticCircuit(log_n=log_n, num_inputs=num_inputs, selectors=sel, wire_vars=wv, num_vars=num_vars,
-                            free_vars=free_vars, pub_vars=pub_vars, gate_rows=gate_rows, sigma=sigma)
+                            free_vars=free_vars, pub_vars=pub_vars, gate_rows=gate_rows, sigma=sigma, free_class=free_class)
 
 
 def _permutation(wv, num_vars: int, log_n: int):

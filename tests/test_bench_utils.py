@@ -119,3 +119,32 @@ def test_cap_like_circuit_is_satisfiable_and_cap_shaped():
     uni = bu.synthetic_circuit(9, 27, seed=9)
     assert bu.value_classes(uni.witnesses_mont([1])[0])["full_width"] > 0.85
     assert sc.gadget_rows["padding"] == sc.n - sc.gate_rows and sc.gadget_rows["merkle path"] == 2 * 10 * 156
+
+
+def test_skewed_synthetic_circuits_are_satisfiable():
+    """synthetic_circuit(skew=...): most free variables booleans / 64-bit values, more padding - the witness
+    distributions the fuzzers of the commitments-from-evaluations draw (tools/gpu_fuzz_prover.py)"""
+    for log_n, fill, skew in ((6, 0.3, 0.97), (8, 0.6, 0.5)):
+        sc = bu.synthetic_circuit(log_n, 3, seed=5, fill=fill, skew=skew)
+        w, pubs = sc.witness(9)
+        pl.check_circuit_satisfiability(pl.Circuit(n=sc.n, num_inputs=3, selectors=sc.selectors, sigma=sc.sigma,
+                                                   wires=w, pub_inputs=pubs))
+        wm, _ = sc.witnesses_mont([9], verify=True)
+        assert np.array_equal(wm[0], sc.wires_mont(w))
+        cls = bu.value_classes(wm[0])
+        assert cls["zero"] > 0.3 and cls["full_width"] < 0.6
+    # the counter of an MSM's work agrees with a direct count of signed base-2^c digits
+    vals = [0, 1, 2, (1 << 15) - 1, 1 << 14, (1 << 14) + 1, bu.R - 1, 12345678901234567890123456789]
+    ent, bkt = bu.msm_work(bu.to_mont_array(vals), 15)
+
+    def digits(k, c=15):
+        out, carry = [], 0
+        for wdw in range((254 + c - 1) // c):
+            d = ((k >> (wdw * c)) & ((1 << c) - 1)) + carry
+            carry = 0
+            if d > (1 << (c - 1)):
+                d, carry = (1 << c) - d, 1
+            out.append(d)
+        return out
+    ds = [d for k in vals for d in digits(k) if d]
+    assert ent == len(ds) and bkt == len(set(ds))

@@ -10,7 +10,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_isa_mix_classes_are_priced():
     from cap_amd import lib as cg
-    mix = json.load(open(os.path.join(ROOT, "profiles", "isa_mix_r04.json")))
+    mix = json.load(open(os.path.join(ROOT, "profiles", "isa_mix_r05.json")))
     valu = {k: v for k, v in mix["per_class"].items() if k != "non_valu"}
     assert set(valu) <= set(cg.ISSUE_CLASSES)                       # every class has a measured rate to be priced at
     assert sum(valu.values()) == mix["valu_instructions_per_mixed_addition"]
@@ -56,12 +56,18 @@ def test_issue_rate_microbenchmark(monkeypatch):
         assert 0.6 * floor < r[k] < 1.05 * floor
 
 
-def test_derived_fractions_cannot_exceed_one():
-    """bench.py clamps every fraction-of-a-ceiling it derives (round-3 VERDICT: 1.006 and 1.0013 were reported)"""
+def test_derived_fractions_above_one_are_flagged_not_clamped():
+    """A fraction of a ceiling above 1 means the cost model or the static counters are off (round-3 VERDICT: 1.006 and
+    1.0013 were reported).  Round 4 clamped such values to 1.0; the round-4 ADVICE asked for the raw value and a flag
+    instead: bench.py publishes what it computed and marks the object `model_inconsistent`."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
     bench = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(bench)
-    assert bench._clamp01(1.006) == 1.0 and bench._clamp01(0.93) == 0.93 and bench._clamp01(None) is None
+    d = bench._flag_inconsistent({"issue_frac": 1.006, "frac": 0.93, "x": None}, ("issue_frac", "frac", "x"))
+    assert d["issue_frac"] == 1.006 and d["model_inconsistent"] is True and d["model_inconsistent_fields"] == ["issue_frac"]
+    ok = bench._flag_inconsistent({"issue_frac": 0.9}, ("issue_frac",))
+    assert "model_inconsistent" not in ok
     src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "_clamp01" not in src
     assert "cu_busy_frac\"] / u[\"cu_busy_frac\"]" in src      # busy share normalised kernel / microbenchmark

@@ -1,5 +1,6 @@
 """Differential fuzz of the device prover against the C restatement: random domain sizes, public-input counts,
-batch sizes, messages, single- and mixed-key batches, both input forms of the ABI (tables of values / polynomials in
+batch sizes, messages, witness value distributions (uniform / mostly booleans and small values, varying padding),
+single- and mixed-key batches, both input forms of the ABI (tables of values / polynomials in
 coefficient form, for the keys and for the wires independently), and every batch proved three times (small batches are
 captured as hipGraphs on the second call and replayed on the third: all three must be the same bytes).  python tools/gpu_fuzz_prover.py [rounds] [seed] [big]
 (also run, bounded, by tests/test_gpu_fuzz.py)"""
@@ -43,7 +44,10 @@ def run(rounds=30, seed=1, big=False, max_checked=None, log=print):
         key_coeffs, wire_coeffs = rng.random() < 0.5, rng.random() < 0.5
         for k in range(nkeys):
             ni = rng.randint(0, min(30, n // 2 - 1))
-            sc = bu.synthetic_circuit(log_n, ni, seed=rng.randint(1, 10 ** 6))
+            # (witness value classes too: uniform, or most free variables booleans / 64-bit values, and more or less padding -
+            # the scalars of round 1's commitments from evaluations: heavy buckets, sparse digits, zero columns)
+            sc = bu.synthetic_circuit(log_n, ni, seed=rng.randint(1, 10 ** 6), fill=rng.choice([0.94, 0.94, 0.6, 0.3]),
+                                      skew=rng.choice([0.0, 0.0, 0.5, 0.97]))
             circuits.append(sc)
             if key_coeffs:
                 keys.append(cg.plonk_preprocess(srs, n, ni, coeffs(sc.selectors_mont()), coeffs(sc.sigma_mont()),
