@@ -24,10 +24,10 @@ def test_isa_mix_classes_are_priced():
         sh = mix["other_kernels"][name]["class_share"]
         assert set(sh) <= set(cg.ISSUE_CLASSES) and abs(sum(sh.values()) - 1.0) < 1e-9
         assert 0.6 < sh["v_mad_u64_u32"] < 0.8, name
-    clock = json.load(open(os.path.join(ROOT, "profiles", "clock_r04.json")))["derived"]
+    clock = json.load(open(os.path.join(ROOT, "profiles", "clock_r05.json")))["derived"]
     assert 1.5 < clock["msm_accumulate"]["clock_GHz"] < 2.5 and 0.5 < clock["msm_accumulate"]["cu_busy_frac"] <= 1.02
     # the static passes name the NTT kernels by their template instantiation ("ntt_col_pass<false>"); bench.py accepts both
-    inst = json.load(open(os.path.join(ROOT, "profiles", "inst_counters_r04.json")))["kernels"]
+    inst = json.load(open(os.path.join(ROOT, "profiles", "inst_counters_r05.json")))["kernels"]
     for name in ("ntt_col_pass", "ntt_row_pass", "k_quotient", "msm_reduce_segments"):
         assert any(k.replace("<false>", "") == name for k in clock), name
         assert any(k.replace("<false>", "") == name and "SQ_INSTS_VALU" in v for k, v in inst.items()), name
