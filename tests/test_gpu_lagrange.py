@@ -66,8 +66,6 @@ def test_degenerate_columns(cg, tau):
     stops at the quotient - the wire commitments are what differs between the modes and they come out first)"""
     log_n, n = 9, 1 << 9
     h = cg.srs_generate(tau, n + 3)
-    L = cg.load()
-    import ctypes
     srs = cg.srs_download(h, 0, n + 3)
     rng = np.random.default_rng(7)
     one = bu.to_mont_array([1])[0]
@@ -113,4 +111,27 @@ def test_cap_shaped_witness_full_size(cg, tau):
     big = both_modes(cg, lambda: cg.plonk_prove_batch(pk, ws[idx], ps[idx], bls[idx], b"note", P2))
     assert big[0] == big[1] and big[0][:P] == a
     cg.plonk_free_key(pk)
+    cg.srs_free(h)
+
+
+@pytest.mark.parametrize("log_n", [4, 7])
+def test_lagrange_key_against_the_closed_form(cg, tau, log_n):
+    """With a known tau the Lagrange-form key has a closed form - point j is [L_j(tau)] G with L_j(tau) = omega^j (tau^n - 1)
+    / (n (tau - omega^j)), and the two blinding points are [tau^n - 1] G and [tau^(n+1) - tau] G: checked through unit
+    vectors, independently of any polynomial arithmetic on the device (the transform in lagrange.hip never sees tau)"""
+    from oracle import bn254 as bn
+    n = 1 << log_n
+    h = cg.srs_generate(tau, n + 3)
+    om = bn.root_of_unity(log_n)
+    zh = (pow(tau, n, bn.R) - 1) % bn.R
+    want = [pow(om, j, bn.R) * zh % bn.R * pow(n * (tau - pow(om, j, bn.R)) % bn.R, bn.R - 2, bn.R) % bn.R for j in range(n)]
+    want += [zh, (pow(tau, n + 1, bn.R) - tau) % bn.R]
+    assert sum(want[:n]) % bn.R == 1                             # the Lagrange basis sums to one
+    pts = cr.g1_fixed_base_batch(cr.ints_to_array(want))         # [want_j] G on the CPU
+    one = bu.to_mont_array([1])[0]
+    for j in sorted({0, 1, 2, n // 2, n - 1, n, n + 1}):
+        e = np.zeros((j + 1, 4), np.uint64)
+        e[j] = one
+        got = cr.g1_to_affine(cg.lagrange_commit(h, log_n, e))
+        assert cr.affine_to_ints(got) == cr.affine_to_ints(pts[j]), j
     cg.srs_free(h)
