@@ -45,7 +45,12 @@ def _witgen():
     """cap_amd/libcapwitgen.so (cap_amd/csrc/witgen.c; built by `make -C cap_amd/csrc`): harness code, not the product."""
     global _WITGEN
     if _WITGEN is None:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libcapwitgen.so")
+        here = os.path.dirname(os.path.abspath(__file__))
+        path = os.path.join(here, "libcapwitgen.so")
+        if not os.path.exists(path):          # (normally built by __graft_entry__.build(); one C file, no dependencies)
+            import subprocess
+            subprocess.check_call([os.environ.get("CC", "cc"), "-O2", "-fPIC", "-shared", "-pthread", "-o", path,
+                                   os.path.join(here, "csrc", "witgen.c")])
         L = ctypes.CDLL(path)
         vp, u32, u64 = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint64
         L.capwit_fill_many.argtypes = [u32, u32, u32, u32, vp, vp, vp, vp, u32, vp, u32, u32, ctypes.c_int, vp, vp, vp]
