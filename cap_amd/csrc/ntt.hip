@@ -165,14 +165,34 @@ __device__ __forceinline__ void lds_ntt(fl* sh, const fl* __restrict__ tw_small,
     for (uint32_t s = s0; s + 1 < log_len; s += 2) {
       const uint32_t h = 1u << s, pos = gg & (h - 1);
       fl a1, b1, c1, d1, t;
-      const fl w1 = tw_small[pos << (log_len - 1 - s)];
-      t = Fr29::mul(b, w1);
-      a1 = Fr29::add(a, t);
-      b1 = Fr29::sub2p_lazy(a, t);
-      t = Fr29::mul(d, w1);
-      c1 = Fr29::add(cc, t);
-      d1 = Fr29::sub2p(cc, t);
-      t = Fr29::mul(c1, tw_small[pos << (log_len - 2 - s)]);
+      if (s == 0) {  // (the trivial first round, as in the shipped code: one multiplication for the four elements)
+        if (fl_any(b)) {
+          t = Fr29::weak_reduce(b);
+          a1 = Fr29::add(a, t);
+          b1 = Fr29::sub2p_lazy(a, t);
+        } else {
+          a1 = a;
+          b1 = a;
+        }
+        if (fl_any(d)) {
+          t = Fr29::weak_reduce(d);
+          c1 = Fr29::normalize(Fr29::add(cc, t));
+          d1 = Fr29::sub2p(cc, t);
+        } else {
+          c1 = cc;
+          d1 = cc;
+        }
+        t = Fr29::weak_reduce(c1);
+      } else {
+        const fl w1 = tw_small[pos << (log_len - 1 - s)];
+        t = Fr29::mul(b, w1);
+        a1 = Fr29::add(a, t);
+        b1 = Fr29::sub2p_lazy(a, t);
+        t = Fr29::mul(d, w1);
+        c1 = Fr29::add(cc, t);
+        d1 = Fr29::sub2p(cc, t);
+        t = Fr29::mul(c1, tw_small[pos << (log_len - 2 - s)]);
+      }
       a = Fr29::normalize(Fr29::add(a1, t));
       cc = Fr29::sub2p(a1, t);
       t = Fr29::mul(d1, tw_small[(pos + h) << (log_len - 2 - s)]);
