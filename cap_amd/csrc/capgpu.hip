@@ -125,6 +125,20 @@ int scratch_reserve(Scratch& s, size_t bytes) {
   return CAPGPU_OK;
 }
 
+int pinned_reserve(Context& c, size_t bytes) {
+  if (bytes <= c.pin_cap) return CAPGPU_OK;
+  if (c.pin_host) {
+    CAP_HIP(hipStreamSynchronize(c.stream));
+    CAP_HIP(hipHostFree(c.pin_host));
+    c.pin_host = nullptr;
+    c.pin_cap = 0;
+  }
+  const size_t want = std::max<size_t>(bytes + bytes / 4, (size_t)1 << 16);
+  CAP_HIP(hipHostMalloc(&c.pin_host, want, hipHostMallocDefault));
+  c.pin_cap = want;
+  return CAPGPU_OK;
+}
+
 int get_domain(uint32_t log_n, const NttDomain** out) {
   Context& c = ctx();
   auto it = c.domains.find(log_n);
@@ -864,6 +878,9 @@ void capgpu_shutdown(void) {
         s->p = nullptr;
         s->cap = 0;
       }
+      if (c.pin_host) hipHostFree(c.pin_host);
+      c.pin_host = nullptr;
+      c.pin_cap = 0;
       c.pool.reset();
       c.prove_graphs.reset();
       if (c.tm0) hipEventDestroy(c.tm0);

@@ -111,6 +111,8 @@ struct Context {
   std::map<uint64_t, std::shared_ptr<SrsEntry>> srs;  // logical handle -> the table resident HERE (full or shard)
   std::map<uint64_t, std::shared_ptr<ProvingKey>> keys;
   Scratch ntt_scratch, msm_ws, stage_a, stage_b, prove_ws, gather;
+  void* pin_host = nullptr;  // pinned host memory for the small results a prover round hands back (pinned_reserve)
+  size_t pin_cap = 0;
   std::shared_ptr<ProveGraphCache> prove_graphs;  // created on first use; dropped before the stream at shutdown
   bool capturing = false;  // a stream capture is open on `stream`: scratch buffers must not grow (scratch_reserve refuses)
   std::unique_ptr<HostPool> pool;  // created on first use
@@ -192,6 +194,8 @@ int take_launch_error();                       // CAPGPU_OK, or CAPGPU_ERR_HIP n
 
 // grows (never shrinks) a scratch buffer of the current context; synchronises its stream before freeing the old one
 int scratch_reserve(Scratch& s, size_t bytes);
+// grows (never shrinks) context c's pinned host buffer; synchronises its stream before freeing the old one
+int pinned_reserve(Context& c, size_t bytes);
 // cached domain tables for 2^log_n
 int get_domain(uint32_t log_n, const NttDomain** out);
 int get_domain3(uint32_t log_m, const Ntt3Domain** out);

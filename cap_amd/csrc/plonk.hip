@@ -607,13 +607,30 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   CAP_HIP(hipMemcpyAsync(w.d_blind, blinders, sizeof(fe) * P * 13, hipMemcpyHostToDevice, s));
   CAP_HIP(hipMemsetAsync(w.flags, 0, sizeof(uint32_t) * P, s));
 
-  std::vector<g1_jac> hj;
+  // Results the host needs between the rounds come back into PINNED memory of the context: a device-to-host copy into
+  // pageable memory makes the runtime wait for the stream on the host first and copy through a staging buffer of its own
+  // - two host round trips where one is needed, seven times per proof.
+  g1_jac* hj = nullptr;      // [5 P] commitments of a round
+  fe* h_tot = nullptr;       // [P] grand-product totals out, their inverses back
+  fe* h_evals = nullptr;     // [10 P]
+  uint32_t* h_flags = nullptr;  // [P]
+  {
+    const size_t need = sizeof(g1_jac) * P * NW + sizeof(fe) * P * 11 + sizeof(uint32_t) * P + 1024;
+    if ((rc = pinned_reserve(c, need))) return rc;
+    char* b = (char*)c.pin_host;
+    hj = (g1_jac*)b;
+    b += (sizeof(g1_jac) * P * NW + 255) / 256 * 256;
+    h_tot = (fe*)b;
+    b += (sizeof(fe) * P + 255) / 256 * 256;
+    h_evals = (fe*)b;
+    b += (sizeof(fe) * P * 10 + 255) / 256 * 256;
+    h_flags = (uint32_t*)b;
+  }
   std::vector<g1_affine> ha;
   // `keep_busy` enqueues work that does not depend on the next challenge: it runs on the GPU while the host turns the
   // commitments into challenges
   auto fetch_comms = [&](uint32_t count, const std::function<int()>& keep_busy = nullptr) -> int {
-    hj.resize(count);
-    CAP_HIP(hipMemcpyAsync(hj.data(), w.comms, sizeof(g1_jac) * count, hipMemcpyDeviceToHost, s));
+    CAP_HIP(hipMemcpyAsync(hj, w.comms, sizeof(g1_jac) * count, hipMemcpyDeviceToHost, s));
     CAP_HIP(hipStreamSynchronize(s));
     if (keep_busy) {
       int brc = keep_busy();
@@ -625,7 +642,7 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
     const uint32_t chunk = 64, nchunks = (count + chunk - 1) / chunk;
     parallel_for(nchunks, [&](uint32_t ci) {
       const uint32_t lo = ci * chunk, hi = std::min(count, lo + chunk);
-      std::vector<g1_jac> in(hj.begin() + lo, hj.begin() + hi);
+      std::vector<g1_jac> in(hj + lo, hj + hi);
       std::vector<g1_affine> out;
       batch_to_affine(in, out);
       std::copy(out.begin(), out.end(), ha.begin() + lo);
@@ -818,8 +835,9 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   if (!inv_on_device) {
     // 1 / prod(den) per proof on the host: P products come back (32 B each), one shared inversion (Montgomery's trick),
     // P inverses go out - a round trip of tens of microseconds against 0.17 ms of a single device thread
-    std::vector<fe> tot(P), pref(P);
-    CAP_HIP(hipMemcpyAsync(tot.data(), w.inv_total, sizeof(fe) * P, hipMemcpyDeviceToHost, s));
+    std::vector<fe> pref(P);
+    fe* tot = h_tot;
+    CAP_HIP(hipMemcpyAsync(tot, w.inv_total, sizeof(fe) * P, hipMemcpyDeviceToHost, s));
     CAP_HIP(hipStreamSynchronize(s));
     // (a proof whose product is zero - one of its denominators vanished, probability ~ 2^-236 - must not poison the
     // shared inversion: it is left out of the chain and gets the inverse 0, as the per-proof device inversion gave it)
@@ -837,7 +855,7 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
       acc = Fr::mul(acc, tot[p]);
       tot[p] = inv_p;
     }
-    CAP_HIP(hipMemcpyAsync(w.inv_total, tot.data(), sizeof(fe) * P, hipMemcpyHostToDevice, s));
+    CAP_HIP(hipMemcpyAsync(w.inv_total, tot, sizeof(fe) * P, hipMemcpyHostToDevice, s));
     if ((rc = seg(7, [&]() -> int {
            int r;
            launch("k_perm_finish", k_perm_finish, dim3(cdiv(ps, kThreads), P), dim3(kThreads), 0, s, (const fe*)w.pre,
@@ -891,8 +909,8 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
          return run_msm(s, *B, w.t, m, NW, n + 2, n + 2, P * NW, w.comms);
        })))
     return rc;
-  std::vector<uint32_t> flags(P);
-  CAP_HIP(hipMemcpyAsync(flags.data(), w.flags, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, s));
+  uint32_t* flags = h_flags;
+  CAP_HIP(hipMemcpyAsync(flags, w.flags, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, s));
   if ((rc = fetch_comms(P * NW))) return rc;
   for (uint32_t p = 0; p < P; p++) {
     if (flags[p]) {
@@ -949,8 +967,8 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
          return CAPGPU_OK;
        })))
     return rc;
-  std::vector<fe> evals((size_t)P * 10);
-  CAP_HIP(hipMemcpyAsync(evals.data(), w.evals, sizeof(fe) * evals.size(), hipMemcpyDeviceToHost, s));
+  fe* evals = h_evals;
+  CAP_HIP(hipMemcpyAsync(evals, w.evals, sizeof(fe) * (size_t)P * 10, hipMemcpyDeviceToHost, s));
   CAP_HIP(hipStreamSynchronize(s));
 
   // ---- round 5: linearisation + opening proofs ---------------------------------------------------------
