@@ -71,3 +71,17 @@ def test_derived_fractions_above_one_are_flagged_not_clamped():
     src = open(os.path.join(ROOT, "bench.py")).read()
     assert "_clamp01" not in src
     assert "cu_busy_frac\"] / u[\"cu_busy_frac\"]" in src      # busy share normalised kernel / microbenchmark
+
+
+def test_leg_percentiles_and_protocol_constants():
+    """SURVEY 8d's timing protocol for the MSM / NTT legs: >= 10 warm-up + >= 50 timed iterations, median and p10 / p90"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod2", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.WARMUP_ITERS >= 10 and bench.TIMED_ITERS >= 50
+    st = bench._pcts([float(x) for x in range(100, 0, -1)])
+    assert st["min"] == 1.0 and st["max"] == 100.0 and st["iterations"] == 100
+    assert st["p10"] == 11.0 and st["median"] == 51.0 and st["p90"] == 91.0
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "cg.timer_begin()" in src and "sched_setaffinity" in src and "model name" in src
