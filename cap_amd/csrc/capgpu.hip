@@ -536,9 +536,9 @@ int find_lagrange(uint64_t h, uint32_t log_n, const MsmBases** out) {
   std::lock_guard<std::mutex> lk(e->lag_mu);
   auto it = e->lagrange.find(log_n);
   if (it == e->lagrange.end()) {
-    if (B->n < ((size_t)1 << log_n) + 2) {
+    if (B->n < ((size_t)1 << log_n) + 3) {
       set_error("capgpu: SRS %llu has %zu points, the Lagrange-form commit key of a 2^%u domain needs %zu",
-                (unsigned long long)h, B->n, log_n, ((size_t)1 << log_n) + 2);
+                (unsigned long long)h, B->n, log_n, ((size_t)1 << log_n) + 3);
       return CAPGPU_ERR_INVALID_ARG;
     }
     if (c.capturing) {
@@ -1615,8 +1615,8 @@ int capgpu_msm_g1_lagrange(uint64_t srs_handle, uint32_t log_n, const uint64_t* 
                            int scalars_montgomery, uint64_t out_xyz[12]) {
   CAP_CHECK_INIT();
   const size_t n = (size_t)1 << (log_n & 31);
-  if (!scalars || !out_xyz || log_n > 26 || count == 0 || count > n + 2) {
-    set_error("capgpu_msm_g1_lagrange: bad argument (1 .. 2^log_n + 2 scalars, log_n <= 26)");
+  if (!scalars || !out_xyz || log_n > 26 || count == 0 || count > n + 3) {
+    set_error("capgpu_msm_g1_lagrange: bad argument (1 .. 2^log_n + 3 scalars, log_n <= 26)");
     return CAPGPU_ERR_INVALID_ARG;
   }
   Context& c = pick_context();

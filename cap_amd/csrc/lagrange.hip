@@ -9,8 +9,9 @@
 // the Lagrange points are the inverse DFT of the SRS points taken in the GROUP: a radix-2 transform whose butterflies are
 // (A + [w] B, A - [w] B) with a 254-bit scalar multiplication per butterfly.  That is ~n/2 (log n + 1) scalar
 // multiplications of ~380 point operations each - 0.25 M of them at n = 2^15 - once per (SRS, domain size); the result is
-// an ordinary window table (msm.hpp) of n + 2 points: L_0 .. L_(n-1), then the two blinding points Z0 = [tau^n - 1] G
-// and Z1 = [tau^(n+1) - tau] G.  Same group elements, same proof bytes (tests/test_gpu_lagrange.py).
+// an ordinary window table (msm.hpp) of n + 3 points: L_0 .. L_(n-1), then the blinding points Z_e = [tau^(n+e) - tau^e] G,
+// e = 0, 1, 2 (two blinders per wire polynomial, three for the permutation product).  Same group elements, same proof
+// bytes (tests/test_gpu_lagrange.py).
 //
 // One thread per butterfly; the launches are one wave per CU (n / 2 threads), every lane a chain of dependent point
 // operations: the row-wise multiplication schedule, like the MSM's one-wavefront finishing kernels.
@@ -27,6 +28,7 @@ namespace cap {
 namespace {
 
 using F = Fq29;
+constexpr uint32_t kLagBlind = 3;  // blinding points behind the n Lagrange points
 
 __device__ __forceinline__ g1x neg_pt(const g1x& p) {
   g1x r = p;
@@ -73,11 +75,11 @@ __global__ __launch_bounds__(64) void lag_stage(g1_xyzz* __restrict__ a, uint32_
   a[i1] = G1L::store(G1L::add(A, neg_pt(B)));
 }
 
-// out[j] = [1/n] a[j] in arkworks' affine form (what msm_precompute takes), j < n; out[n], out[n + 1] = the blinding points
+// out[j] = [1/n] a[j] in arkworks' affine form (what msm_precompute takes), j < n; out[n .. n + 2] = the blinding points
 __global__ __launch_bounds__(64) void lag_finish(const g1_xyzz* __restrict__ a, uint32_t n, fe n_inv,
                                                  const g1_affine* __restrict__ srs, g1_affine* __restrict__ out) {
   const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-  if (j >= n + 2) return;
+  if (j >= n + kLagBlind) return;
   g1x p;
   if (j < n) {
     p = scalar_mul(G1L::load(a[j]), n_inv);
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(64) void lag_finish(const g1_xyzz* __restrict__ a, 
 
 int lagrange_build(const MsmBases& srs, uint32_t log_n, MsmBases* out, hipStream_t stream) {
   const size_t n = (size_t)1 << log_n;
-  if (log_n > 26 || srs.n < n + 2 || !srs.ext) return (int)hipErrorInvalidValue;
+  if (log_n > 26 || srs.n < n + kLagBlind || !srs.ext) return (int)hipErrorInvalidValue;
   // omega_n^-k, k < n / 2, and 1/n as plain integers (the scalars of the butterflies)
   std::vector<fe> tw(n / 2 ? n / 2 : 1);
   const fe w_inv = Fr::inv(ntt_root_of_unity(log_n));
@@ -122,7 +124,7 @@ int lagrange_build(const MsmBases& srs, uint32_t log_n, MsmBases* out, hipStream
   };
   hipError_t e = hipMalloc(&d_a, sizeof(g1_xyzz) * n);
   if (e == hipSuccess) e = hipMalloc(&d_tw, sizeof(fe) * tw.size());
-  if (e == hipSuccess) e = hipMalloc(&d_aff, sizeof(g1_affine) * (n + 2));
+  if (e == hipSuccess) e = hipMalloc(&d_aff, sizeof(g1_affine) * (n + kLagBlind));
   if (e == hipSuccess) e = hipMemcpyAsync(d_tw, tw.data(), sizeof(fe) * tw.size(), hipMemcpyHostToDevice, stream);
   if (e != hipSuccess) {
     cleanup();
@@ -133,9 +135,9 @@ int lagrange_build(const MsmBases& srs, uint32_t log_n, MsmBases* out, hipStream
   for (uint32_t half = 1; half < n; half <<= 1)
     launch("lag_stage", lag_stage, dim3((unsigned)((n / 2 + 63) / 64)), dim3(64), 0, stream, d_a, (uint32_t)n, half,
            (const fe*)d_tw, (uint32_t)(n / (2 * half)));
-  launch("lag_finish", lag_finish, dim3((unsigned)((n + 2 + 63) / 64)), dim3(64), 0, stream, (const g1_xyzz*)d_a, (uint32_t)n,
+  launch("lag_finish", lag_finish, dim3((unsigned)((n + kLagBlind + 63) / 64)), dim3(64), 0, stream, (const g1_xyzz*)d_a, (uint32_t)n,
          n_inv, (const g1_affine*)srs.ext, d_aff);
-  int rc = msm_precompute(out, d_aff, n + 2, msm_choose_window(n + 2), stream);
+  int rc = msm_precompute(out, d_aff, n + kLagBlind, msm_choose_window(n + kLagBlind), stream);
   e = hipStreamSynchronize(stream);  // the table may be used from another context's stream next; the temporaries go
   cleanup();
   if (rc == 0 && e != hipSuccess) rc = (int)e;

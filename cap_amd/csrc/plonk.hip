@@ -663,8 +663,8 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
     if (!Lag) return run_msm(s, *B, w.wpoly + (size_t)p0 * NW * ps, ps, 1, 0, n + 2, cnt * NW, out);
     fe* stage = w.t + (size_t)p0 * NW * (n + 2);
     const fe* ev = (coeffs ? (const fe*)w.wev : d_wires) + (size_t)p0 * NW * n;
-    launch("k_stage_evals", k_stage_evals, dim3(cdiv(n + 2, kThreads), cnt * NW), dim3(kThreads), 0, s, ev, n,
-           (const fe*)(w.d_blind + (size_t)p0 * 13), (uint32_t)NW, stage);
+    launch("k_stage_evals", k_stage_evals, dim3(cdiv(n + 2, kThreads), cnt * NW), dim3(kThreads), 0, s, ev, n, n,
+           (const fe*)(w.d_blind + (size_t)p0 * 13), (uint32_t)NW, 0u, 2u, stage);
     return run_msm(s, *Lag, stage, n + 2, 1, 0, n + 2, cnt * NW, out);
   };
   auto r1_chunk_kernels = [&](uint32_t p0, uint32_t cnt, bool commit) -> int {
@@ -796,19 +796,39 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   auto z_cosets = [&](hipStream_t st) -> int {
     return run_ntt3_fwd(st, K.log_m, w.coset + 5 * m, P, NttIo{w.zpoly, ps, 0, n + 3, 1, 7 * m, 0, 1});
   };
-  auto commit_z = [&]() -> int {
-    if (!overlap) return run_msm(s, *B, w.zpoly, ps, 1, 0, n + 3, P, w.comms);
+  // z's values -> its commitment.  From coefficients (jf-plonk's way): interpolate, blind, MSM on the monomial key.  From
+  // evaluations (the Lagrange-form key): the MSM of the n values and the three blinders needs neither - it starts at
+  // once, and the small batches of `overlap` interpolate, blind and transform z to the cosets beside it.
+  auto finish_and_commit_z = [&]() -> int {
+    int r;
+    launch("k_perm_finish", k_perm_finish, dim3(cdiv(ps, kThreads), P), dim3(kThreads), 0, s, (const fe*)w.pre,
+           (const fe*)w.sfx, (const fe*)w.den, (const fe*)w.inv_total, n, w.zpoly, ps);
+    auto interpolate_and_blind = [&](hipStream_t st) -> int {
+      int q = run_ntt(st, K.log_n, w.zpoly, ps, P, 1, 0);
+      if (q) return q;
+      launch("k_blind", k_blind<0>, dim3(P), dim3(64), 0, st, w.zpoly, ps, n, (const fe*)w.d_blind, 1u, 10u, 3u, P);
+      return CAPGPU_OK;
+    };
+    if (Lag) {  // (the values are staged before the in-place interpolation overwrites them)
+      launch("k_stage_evals", k_stage_evals, dim3(cdiv(n + 3, kThreads), P), dim3(kThreads), 0, s, (const fe*)w.zpoly, ps, n,
+             (const fe*)w.d_blind, 1u, 10u, 3u, w.t);
+    }
+    if (!overlap) {
+      if ((r = interpolate_and_blind(s))) return r;
+      return Lag ? run_msm(s, *Lag, w.t, n + 3, 1, 0, n + 3, P, w.comms) : run_msm(s, *B, w.zpoly, ps, 1, 0, n + 3, P, w.comms);
+    }
+    if (!Lag && (r = interpolate_and_blind(s))) return r;  // the monomial MSM reads the blinded coefficients
     CAP_HIP(hipEventRecord(c.ev_fork, s));
     CAP_HIP(hipStreamWaitEvent(s2, c.ev_fork, 0));
-    int r = z_cosets(s2);
-    if (r == CAPGPU_OK) r = run_msm(s, *B, w.zpoly, ps, 1, 0, n + 3, P, w.comms);
+    if (Lag && (r = interpolate_and_blind(s2))) return r;
+    if ((r = z_cosets(s2))) return r;
+    r = Lag ? run_msm(s, *Lag, w.t, n + 3, 1, 0, n + 3, P, w.comms) : run_msm(s, *B, w.zpoly, ps, 1, 0, n + 3, P, w.comms);
     CAP_HIP(hipEventRecord(c.ev_join, s2));
     CAP_HIP(hipStreamWaitEvent(s, c.ev_join, 0));
     return r;
   };
   // ---- round 2: permutation grand product --------------------------------------------------------------
   if ((rc = seg(2, [&]() -> int {
-         int r;
          launch("k_perm_numden", k_perm_numden, dim3(cdiv(n, kThreads), P), dim3(kThreads), 0, s,
                 coeffs ? (const fe*)w.wev : d_wires, (const fe*)K.sig_eval, sig_of, (const fe*)dom_n->tw_fwd,
                 (const Chal*)w.chal, K.qc29, n, w.num, w.den);
@@ -825,11 +845,7 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
                   w.inv_total, P);
            return CAPGPU_OK;  // the segment ends here: the host inverts the totals (below)
          }
-         launch("k_perm_finish", k_perm_finish, dim3(cdiv(ps, kThreads), P), dim3(kThreads), 0, s, (const fe*)w.pre,
-                (const fe*)w.sfx, (const fe*)w.den, (const fe*)w.inv_total, n, w.zpoly, ps);
-         if ((r = run_ntt(s, K.log_n, w.zpoly, ps, P, 1, 0))) return r;
-         launch("k_blind", k_blind<0>, dim3(P), dim3(64), 0, s, w.zpoly, ps, n, (const fe*)w.d_blind, 1u, 10u, 3u, P);
-         return commit_z();
+         return finish_and_commit_z();
        })))
     return rc;
   if (!inv_on_device) {
@@ -857,12 +873,7 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
     }
     CAP_HIP(hipMemcpyAsync(w.inv_total, tot, sizeof(fe) * P, hipMemcpyHostToDevice, s));
     if ((rc = seg(7, [&]() -> int {
-           int r;
-           launch("k_perm_finish", k_perm_finish, dim3(cdiv(ps, kThreads), P), dim3(kThreads), 0, s, (const fe*)w.pre,
-                  (const fe*)w.sfx, (const fe*)w.den, (const fe*)w.inv_total, n, w.zpoly, ps);
-           if ((r = run_ntt(s, K.log_n, w.zpoly, ps, P, 1, 0))) return r;
-           launch("k_blind", k_blind<0>, dim3(P), dim3(64), 0, s, w.zpoly, ps, n, (const fe*)w.d_blind, 1u, 10u, 3u, P);
-           return commit_z();
+           return finish_and_commit_z();
          })))
       return rc;
   }

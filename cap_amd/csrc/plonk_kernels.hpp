@@ -63,16 +63,19 @@ __global__ void k_blind(fe* __restrict__ polys, size_t stride, size_t n, const f
   p[n + t] = SET_TAIL ? b : Fr::add(p[n + t], b);
 }
 
-// round 1, commitments from evaluations (lagrange.hip): the MSM scalars of wire column q are its n values followed by
-// its two blinders - commit(w + (b0 + b1 X)(X^n - 1)) = sum_j w_j [L_j] + b0 [tau^n - 1] + b1 [tau^(n+1) - tau]
-__global__ __launch_bounds__(kThreads) void k_stage_evals(const fe* __restrict__ evals /*[count][n]*/, size_t n,
+// commitments from evaluations (lagrange.hip): the MSM scalars of column q are its n values followed by its nb blinders -
+// commit(w + (b0 + b1 X [+ b2 X^2])(X^n - 1)) = sum_j w_j [L_j] + sum_e b_e [tau^(n+e) - tau^e].  Column q's values start at
+// evals + q * src_stride; its blinders at blinders[(q / inner) * 13 + bl_off + (q % inner) * nb ..] (k_blind's layout).
+__global__ __launch_bounds__(kThreads) void k_stage_evals(const fe* __restrict__ evals, size_t src_stride, size_t n,
                                                           const fe* __restrict__ blinders, uint32_t inner,
-                                                          fe* __restrict__ dst /*[count][n + 2]*/) {
+                                                          uint32_t bl_off, uint32_t nb,
+                                                          fe* __restrict__ dst /*[count][n + nb]*/) {
   const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t q = blockIdx.y;
-  if (j >= n + 2) return;
-  dst[(size_t)q * (n + 2) + j] =
-      j < n ? evals[(size_t)q * n + j] : blinders[(size_t)(q / inner) * 13 + (size_t)(q % inner) * 2 + (j - n)];
+  if (j >= n + nb) return;
+  dst[(size_t)q * (n + nb) + j] =
+      j < n ? evals[(size_t)q * src_stride + j]
+            : blinders[(size_t)(q / inner) * 13 + bl_off + (size_t)(q % inner) * nb + (j - n)];
 }
 
 // round 2: per-row numerator / denominator of the permutation grand product

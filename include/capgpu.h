@@ -176,12 +176,12 @@ int capgpu_srs_free(uint64_t handle);
  * additions were made in, which on the device varies from run to run (bucket lists are filled with atomics): compare
  * results in affine form (X / Z^2, Y / Z^3), as every caller of the reference does through into_affine(). */
 int capgpu_msm_g1(uint64_t srs_handle, size_t offset, const uint64_t* scalars, size_t n, uint64_t out_xyz[12]);
-/* The same commitment from a polynomial's VALUES: out = sum_{j < n} s_j [L_j(tau)] G + s_n [tau^n - 1] G +
- * s_(n+1) [tau^(n+1) - tau] G, n = 2^log_n, L_j the Lagrange basis of the n-th roots of unity; `count` <= n + 2 scalars
- * (the last two slots are the blinders of a jf-plonk wire polynomial (b0 + b1 X)(X^n - 1)); scalars_montgomery != 0:
- * arkworks' Fr memory form.  Equals capgpu_msm_g1 on the coefficients ark-poly's ifft makes of the values - the form
- * round 1 of the prover commits in (capgpu_plonk_set_wire_commit).  The Lagrange-form commit key is derived from the
- * SRS on first use (the SRS must hold n + 2 points) and kept with it. */
+/* The same commitment from a polynomial's VALUES: out = sum_{j < n} s_j [L_j(tau)] G + sum_{e < 3} s_(n+e) [tau^(n+e) -
+ * tau^e] G, n = 2^log_n, L_j the Lagrange basis of the n-th roots of unity; `count` <= n + 3 scalars (the last three
+ * slots are the blinders of jf-plonk's polynomials: (b0 + b1 X)(X^n - 1) for a wire, (b0 + b1 X + b2 X^2)(X^n - 1) for the
+ * permutation product); scalars_montgomery != 0: arkworks' Fr memory form.  Equals capgpu_msm_g1 on the coefficients
+ * ark-poly's ifft makes of the values - the form rounds 1 and 2 of the prover commit in (capgpu_plonk_set_wire_commit).
+ * The Lagrange-form commit key is derived from the SRS on first use (the SRS must hold n + 3 points) and kept with it. */
 int capgpu_msm_g1_lagrange(uint64_t srs_handle, uint32_t log_n, const uint64_t* scalars, size_t count,
                            int scalars_montgomery, uint64_t out_xyz[12]);
 int capgpu_msm_g1_batch(uint64_t srs_handle, const size_t* offsets, const uint64_t* const* scalars,
@@ -330,7 +330,8 @@ int capgpu_plonk_set_coalescing(uint32_t window_us, uint32_t max_batch);
  *     sum_j w_j [L_j(tau)] G + b0 [tau^n - 1] G + b1 [tau^(n+1) - tau] G
  * - an MSM of the column's n VALUES and its two blinders on the Lagrange-form commit key of the domain, which the
  * library derives from the SRS once per (SRS, domain size) by a group inverse transform (cap_amd/csrc/lagrange.hip;
- * 2 x 64 B x (n + 2) x 18-20 window rows of device memory, built by capgpu_plonk_preprocess or by the first proof).  The
+ * 2 x 64 B x (n + 3) x 18-20 window rows of device memory, built by capgpu_plonk_preprocess or by the first proof; the
+ * permutation product's commitment is taken the same way, with its three blinders).  The
  * witness values of a CAP circuit are mostly zeros, booleans and range-check limbs (src/circuit/transfer.rs:53-193): as
  * MSM scalars they have at most one non-zero digit where a coefficient has seventeen.  Proof bytes are identical.
  * mode: 1 = from evaluations (the default), 0 = from coefficients, -1 = back to the default (CAPGPU_WIRE_COMMIT=coeffs
