@@ -438,6 +438,16 @@ pub mod arkworks {
     ///   let wires     = poly_columns(&circuit.compute_wire_polynomials()?, n);                  // 5 x n (per proof)
     /// A memcpy of 5 n field elements per proof - against the 10 n-point FFTs per proof the evaluation form used to
     /// cost this shim (5 here to undo jf-relation's interpolation, 5 on the device to redo it).
+    pub fn poly_columns(polys: &[DensePolynomial<Fr>], n: usize) -> Vec<[u64; 4]> {
+        let mut out = vec![[0u64; 4]; polys.len() * n];
+        for (i, p) in polys.iter().enumerate() {
+            assert!(p.coeffs.len() <= n, "polynomial longer than the evaluation domain");
+            for (j, c) in p.coeffs.iter().enumerate() {
+                out[i * n + j] = fr_words(c);
+            }
+        }
+        out
+    }
     /// The evaluation-form columns (`CAPGPU_INPUT_EVALS`) of a family of polynomials: one n-point FFT each on the CPU.
     /// Kept for callers written against rounds 1-3 of this crate; new code passes `poly_columns` to the `_coeffs` entry
     /// points and lets the device do the transform.
@@ -449,16 +459,6 @@ pub mod arkworks {
         for (i, p) in polys.iter().enumerate() {
             for (j, v) in domain.fft(&p.coeffs).iter().enumerate() {
                 out[i * n + j] = fr_words(v);
-            }
-        }
-        out
-    }
-    pub fn poly_columns(polys: &[DensePolynomial<Fr>], n: usize) -> Vec<[u64; 4]> {
-        let mut out = vec![[0u64; 4]; polys.len() * n];
-        for (i, p) in polys.iter().enumerate() {
-            assert!(p.coeffs.len() <= n, "polynomial longer than the evaluation domain");
-            for (j, c) in p.coeffs.iter().enumerate() {
-                out[i * n + j] = fr_words(c);
             }
         }
         out
