@@ -71,6 +71,12 @@ extern "C" {
     pub fn capgpu_device_info(name_out: *mut c_char, cu_count_out: *mut c_int, hbm_bytes_out: *mut u64) -> c_int;
     pub fn capgpu_device_peer_info(slot_a: c_int, slot_b: c_int, access_out: *mut c_int) -> c_int;
     pub fn capgpu_mem_info(free_bytes_out: *mut u64, total_bytes_out: *mut u64) -> c_int;
+    // ---- footprint control and diagnostics
+    pub fn capgpu_trim(bytes_released_out: *mut u64, contexts_busy_out: *mut c_int) -> c_int;
+    pub fn capgpu_set_memory_limit(scratch_bytes_per_device: u64) -> c_int;
+    pub fn capgpu_scratch_info(scratch_bytes_out: *mut u64, limit_out: *mut u64) -> c_int;
+    pub fn capgpu_trace_enable(on: c_int) -> c_int;
+    pub fn capgpu_trace_dump(path: *const c_char, events_out: *mut u64) -> c_int;
     // ---- device memory / stream
     pub fn capgpu_malloc(dev_ptr_out: *mut *mut c_void, bytes: usize) -> c_int;
     pub fn capgpu_free(dev_ptr: *mut c_void) -> c_int;

@@ -581,6 +581,29 @@ def note_circuit(kind: str, seed: int = 2) -> SyntheticCircuit:
     return synthetic_circuit(log_n, num_inputs, seed)
 
 
+def closed_loop_callers(prove_fn, pk: int, wires, pubs, num_inputs: int, msg: bytes, blinders, proofs, threads: int,
+                        calls: int):
+    """`threads` NATIVE threads (cap_amd/csrc/witgen.c: capwit_closed_loop_callers), each calling `prove_fn` - the ctypes
+    function object of capgpu_plonk_prove_ex - `calls` times, one proof per call, straight after one another: the
+    reference's rayon workers (src/utils/params_builder.rs:194-226).  Call k of thread t proves entry t * calls + k of
+    wires / pubs / blinders (lists of C-contiguous uint64 arrays) into proofs[t * calls + k] (ctypes structures).
+    Returns (failed calls, seconds from the common start to the last return)."""
+    import ctypes
+    total = threads * calls
+    assert len(wires) == len(pubs) == len(blinders) == len(proofs) == total
+    vp = ctypes.c_void_p
+    arr = lambda xs: (vp * total)(*[x.ctypes.data for x in xs])      # noqa: E731
+    pr = (vp * total)(*[ctypes.addressof(p) for p in proofs])
+    mbuf = (ctypes.c_uint8 * max(len(msg), 1)).from_buffer_copy(msg or b"\0")
+    secs = ctypes.c_double(0)
+    fn = _witgen().capwit_closed_loop_callers
+    fn.restype = ctypes.c_int
+    failed = fn(ctypes.cast(prove_fn, vp), ctypes.c_uint64(pk), ctypes.c_int(threads), ctypes.c_int(calls), arr(wires),
+                arr(pubs), ctypes.c_size_t(num_inputs), mbuf, ctypes.c_size_t(len(msg)), arr(blinders), pr,
+                ctypes.byref(secs))
+    return failed, secs.value
+
+
 def weighted_scalar_sums(sc: np.ndarray, lo: int = 0):
     """(sum k_i, sum (lo + i) k_i) for canonical scalars (n, 4) uint64 - exact, numpy on 16-bit pieces.  With bases
     P_i = [a + i b] G (capgpu_srs_generate_affine_seq) the MSM must equal [a * s0 + b * s1] G: the full-size known

@@ -106,6 +106,74 @@ int take_launch_error() {
   return CAPGPU_ERR_HIP;
 }
 
+// bytes of scratch (the Scratch buffers of every context) the library holds per HIP device, and the cap on it
+// (capgpu_set_memory_limit; 0 = none).  Tables the caller created - SRS, keys, domains - are not scratch.
+static std::atomic<size_t> g_scratch_bytes[64];
+static std::atomic<size_t> g_scratch_limit{0};
+static void scratch_count(int device, size_t add, size_t sub) {
+  std::atomic<size_t>& a = g_scratch_bytes[(size_t)device & 63];
+  if (add) a.fetch_add(add);
+  if (sub) a.fetch_sub(sub);
+}
+void scratch_account(int device, size_t add, size_t sub) { scratch_count(device, add, sub); }
+bool scratch_room_for(int device, size_t bytes) {
+  const size_t limit = g_scratch_limit.load();
+  return !limit || g_scratch_bytes[(size_t)device & 63].load() + bytes <= limit;
+}
+
+// every stream of the context that may still be running kernels on its scratch (the side stream of the
+// small-batch overlap and the copy stream were not drained before a buffer was freed)
+static hipError_t drain_context_streams(Context& c) {
+  hipError_t e = hipStreamSynchronize(c.stream);
+  if (c.own_stream && c.own_stream != c.stream && e == hipSuccess) e = hipStreamSynchronize(c.own_stream);
+  if (c.side_stream && e == hipSuccess) e = hipStreamSynchronize(c.side_stream);
+  if (c.copy_stream && e == hipSuccess) e = hipStreamSynchronize(c.copy_stream);
+  return e;
+}
+
+// Releases what context c holds beyond its tables: scratch buffers, the pinned result area, captured prover graphs (they
+// name scratch addresses).  The caller holds c.mu.  Returns the device bytes released.
+static size_t trim_context(Context& c) {
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  (void)hipSetDevice(c.device);
+  (void)drain_context_streams(c);
+  size_t released = 0;
+  c.prove_graphs.reset();
+  for (Scratch* s : {&c.ntt_scratch, &c.msm_ws, &c.stage_a, &c.stage_b, &c.prove_ws, &c.gather}) {
+    if (!s->p) continue;
+    (void)hipFree(s->p);
+    released += s->cap;
+    scratch_count(c.device, 0, s->cap);
+    s->p = nullptr;
+    s->cap = 0;
+  }
+  if (c.pin_host) {
+    (void)hipHostFree(c.pin_host);
+    c.pin_host = nullptr;
+    c.pin_cap = 0;
+  }
+  (void)hipGetLastError();
+  if (prev >= 0) (void)hipSetDevice(prev);
+  return released;
+}
+// every context of `device` (all devices: -1) nobody is using right now, except `keep`; *busy_out counts the others
+static size_t trim_idle_contexts(int device, Context* keep, int* busy_out) {
+  size_t released = 0;
+  for (auto& cp : rt().ctxs) {
+    Context& o = *cp;
+    if (&o == keep || (device >= 0 && o.device != device)) continue;
+    if (!o.mu.try_lock()) {
+      if (busy_out) (*busy_out)++;
+      continue;
+    }
+    if (o.depth == 0) released += trim_context(o);  // (depth > 0: an entry point of THIS thread is running on it)
+    else if (busy_out) (*busy_out)++;
+    o.mu.unlock();
+  }
+  return released;
+}
+
 int scratch_reserve(Scratch& s, size_t bytes) {
   if (bytes <= s.cap) return CAPGPU_OK;
   Context& c = ctx();
@@ -114,21 +182,44 @@ int scratch_reserve(Scratch& s, size_t bytes) {
     return CAPGPU_ERR_HIP;
   }
   if (s.p) {
-    CAP_HIP(hipStreamSynchronize(c.stream));
+    CAP_HIP(drain_context_streams(c));
     CAP_HIP(hipFree(s.p));
+    scratch_count(c.device, 0, s.cap);
     s.p = nullptr;
     s.cap = 0;
   }
   size_t want = bytes + bytes / 4;
-  CAP_HIP(hipMalloc(&s.p, want));
+  if (const size_t limit = g_scratch_limit.load()) {
+    // capgpu_set_memory_limit: first without the growth slack, then with what the device's idle contexts give back
+    auto over = [&](size_t w) { return g_scratch_bytes[(size_t)c.device & 63].load() + w > limit; };
+    if (over(want)) want = bytes;
+    if (over(want)) (void)trim_idle_contexts(c.device, &c, nullptr);
+    if (over(want)) {
+      set_error("capgpu: this call needs %zu more bytes of device scratch; %zu are in use on device %d and "
+                "capgpu_set_memory_limit allows %zu (prove in smaller batches, or raise the limit)",
+                want, g_scratch_bytes[(size_t)c.device & 63].load(), c.device, limit);
+      return CAPGPU_ERR_OOM;
+    }
+  }
+  hipError_t e = hipMalloc(&s.p, want);
+  if (e == hipErrorOutOfMemory) {  // the device is full: what idle contexts hold may be all that is missing
+    (void)hipGetLastError();
+    s.p = nullptr;
+    if (trim_idle_contexts(c.device, &c, nullptr)) e = hipMalloc(&s.p, want);
+  }
+  if (e != hipSuccess) {
+    s.p = nullptr;
+    return hip_fail(e, "hipMalloc (scratch)");
+  }
   s.cap = want;
+  scratch_count(c.device, want, 0);
   return CAPGPU_OK;
 }
 
 int pinned_reserve(Context& c, size_t bytes) {
   if (bytes <= c.pin_cap) return CAPGPU_OK;
   if (c.pin_host) {
-    CAP_HIP(hipStreamSynchronize(c.stream));
+    CAP_HIP(drain_context_streams(c));
     CAP_HIP(hipHostFree(c.pin_host));
     c.pin_host = nullptr;
     c.pin_cap = 0;
@@ -844,6 +935,7 @@ void capgpu_shutdown(void) {
   Runtime& R = rt();
   if (!R.initialised.load()) return;
   (void)capgpu_comm_destroy();
+  plonk_reset_staging();
   {
     AllEntries all;
     for (auto& cp : R.ctxs) {
@@ -875,6 +967,7 @@ void capgpu_shutdown(void) {
       ntt_free_small_tables(&c.small);
       for (Scratch* s : {&c.ntt_scratch, &c.msm_ws, &c.stage_a, &c.stage_b, &c.prove_ws, &c.gather}) {
         if (s->p) hipFree(s->p);
+        scratch_count(c.device, 0, s->cap);
         s->p = nullptr;
         s->cap = 0;
       }
@@ -957,6 +1050,49 @@ int capgpu_mem_info(uint64_t* free_bytes_out, uint64_t* total_bytes_out) {
   return CAPGPU_OK;
 }
 
+int capgpu_trim(uint64_t* bytes_released_out, int* contexts_busy_out) {
+  CAP_CHECK_INIT();
+  int busy = 0;
+  const size_t released = trim_idle_contexts(-1, nullptr, &busy) + plonk_trim_staging();
+  if (bytes_released_out) *bytes_released_out = (uint64_t)released;
+  if (contexts_busy_out) *contexts_busy_out = busy;
+  return CAPGPU_OK;
+}
+int capgpu_set_memory_limit(uint64_t scratch_bytes_per_device) {
+  CAP_CHECK_INIT();
+  g_scratch_limit.store((size_t)scratch_bytes_per_device);
+  if (scratch_bytes_per_device) {  // already above it: give back what idle contexts hold (a running call keeps what it has)
+    std::vector<int> seen;
+    for (auto& cp : rt().ctxs) {
+      const int d = cp->device;
+      if (std::find(seen.begin(), seen.end(), d) != seen.end()) continue;
+      seen.push_back(d);
+      if (g_scratch_bytes[(size_t)d & 63].load() > scratch_bytes_per_device) (void)trim_idle_contexts(d, nullptr, nullptr);
+    }
+  }
+  return CAPGPU_OK;
+}
+int capgpu_scratch_info(uint64_t* scratch_bytes_out, uint64_t* limit_out) {
+  CAP_CHECK_INIT();
+  if (scratch_bytes_out) *scratch_bytes_out = (uint64_t)g_scratch_bytes[(size_t)ctx().device & 63].load();
+  if (limit_out) *limit_out = (uint64_t)g_scratch_limit.load();
+  return CAPGPU_OK;
+}
+int capgpu_trace_enable(int on) {
+  trace_enable(on != 0);
+  return CAPGPU_OK;
+}
+int capgpu_trace_dump(const char* path, uint64_t* events_out) {
+  if (!path) return CAPGPU_ERR_INVALID_ARG;
+  const long n = trace_dump(path);
+  if (n < 0) {
+    set_error("capgpu_trace_dump: cannot write %s", path);
+    return CAPGPU_ERR_INVALID_ARG;
+  }
+  if (events_out) *events_out = (uint64_t)n;
+  return CAPGPU_OK;
+}
+
 int capgpu_malloc(void** dev_ptr_out, size_t bytes) {
   CAP_CHECK_INIT();
   if (!dev_ptr_out) return CAPGPU_ERR_INVALID_ARG;
@@ -1001,7 +1137,17 @@ int capgpu_timer_begin(void) {
     CAP_HIP(hipEventCreate(&c.tm0));
     CAP_HIP(hipEventCreate(&c.tm1));
   }
+  // ONE measurement per context at a time: the event pair is shared, and _end waits outside the context lock.  The thread
+  // that opened a measurement may restart it; another thread is refused until the owner's _end.
+  const std::thread::id me = std::this_thread::get_id();
+  if (c.tm_open && c.tm_owner != me) {
+    set_error("capgpu_timer_begin: another thread has a measurement open on context %d (one per context at a time; "
+              "bind the threads to different contexts with capgpu_set_device)", c.slot);
+    return CAPGPU_ERR_INVALID_ARG;
+  }
   CAP_HIP(hipEventRecord(c.tm0, c.stream));
+  c.tm_open = true;
+  c.tm_owner = me;
   return CAPGPU_OK;
 }
 int capgpu_timer_end(double* ms_out) {
@@ -1010,17 +1156,23 @@ int capgpu_timer_end(double* ms_out) {
   hipEvent_t e0, e1;
   {
     Entry lk(c);
-    if (!c.tm0 || !ms_out) {
-      set_error("capgpu_timer_end: no capgpu_timer_begin on this context (or null output)");
+    if (!c.tm0 || !ms_out || !c.tm_open || c.tm_owner != std::this_thread::get_id()) {
+      set_error("capgpu_timer_end: no measurement of this thread is open on this context (or null output)");
       return CAPGPU_ERR_INVALID_ARG;
     }
     CAP_HIP(hipEventRecord(c.tm1, c.stream));
     e0 = c.tm0;
     e1 = c.tm1;
   }
-  CAP_HIP(hipEventSynchronize(e1));  // not under the context lock: other threads may enqueue meanwhile
+  // not under the context lock: other threads may enqueue meanwhile (they cannot re-record the events: tm_open)
+  hipError_t e = hipEventSynchronize(e1);
   float ms = 0;
-  CAP_HIP(hipEventElapsedTime(&ms, e0, e1));
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  {
+    Entry lk(c);
+    c.tm_open = false;
+  }
+  CAP_HIP(e);
   *ms_out = (double)ms;
   return CAPGPU_OK;
 }

@@ -11,8 +11,14 @@
 //   * when the group has no leader, a queued caller becomes the leader: it waits one window (restarted while requests
 //     keep arriving, 16 windows at most), takes a free context (Hooks::acquire: a context nobody holds, LOCKED), takes
 //     up to max_batch requests off the queue, gives up the leadership and runs the batch outside `mu`;
-//   * a batch large enough is cut in two UNEVEN parts when a second context is free (Hooks::acquire_second): the
-//     second part runs on a helper thread; each part's callers are released when THEIR part is done (`early`);
+//   * while max_in_flight batch parts are already running (round 6: two by default) the leader keeps COLLECTING instead
+//     of taking a third free context: closed-loop callers (a rayon loop over notes) otherwise fragment into a dozen
+//     small batches on every context of the device - 64 callers ran as 48 batches of 11 proofs on four contexts, each
+//     paying its own latency-bound launches (profiles/phase_trace_r06.md) - where two or three large ones fill the chip;
+//     a part that ends wakes the leader, a full queue or 16 windows without progress end the wait as well;
+//   * a batch large enough is cut in two UNEVEN parts when a second context is free (Hooks::acquire_second) and nothing
+//     else is in flight: the second part runs on a helper thread; each part's callers are released when THEIR part is
+//     done (`early`);
 //   * a request is never touched again once `done` is set: its caller returns and the request - a stack object - dies.
 #pragma once
 #include <algorithm>
@@ -26,6 +32,8 @@
 #include <thread>
 #include <vector>
 
+#include "trace.hpp"
+
 namespace cap {
 
 // Req: any type with a `bool done` member.
@@ -38,6 +46,7 @@ namespace cap {
 //   size_t deal_min();                    fewest requests a part of a cut batch holds
 //   size_t split_eighths();               size of the first part of a cut batch, in eighths (3: 3/8 : 5/8)
 //   bool early_release();                 release a part's callers when that part is done (else when both are)
+//   size_t max_in_flight();               batch parts running at once before a leader keeps collecting instead (>= 1)
 template <class Req>
 struct CoalescerCore {
   std::mutex mu;
@@ -47,6 +56,10 @@ struct CoalescerCore {
   uint32_t window_us = 0;  // 0 = off
   uint32_t max_batch = 256;
   std::atomic<uint64_t> batches{0}, proofs{0};
+  uint32_t in_flight = 0;  // batch parts running right now (under mu)
+  // callers that have entered the library but are not queued yet (they are copying their witness to the device,
+  // plonk.hip: StagePool): a leader's window does not close while some are on their way
+  std::atomic<uint32_t> arriving{0};
 
   // cv.wait_for, except under ThreadSanitizer: libstdc++ waits on the steady clock through pthread_cond_clockwait, which
   // gcc's libtsan (<= 11) does not intercept - it misses the unlock inside the wait and reports a "double lock" at the
@@ -75,6 +88,7 @@ struct CoalescerCore {
   void submit(std::unique_lock<std::mutex>& lk, Req& req, uint64_t group, Hooks& h) {
     std::vector<Req*>& q = pending[group];
     q.push_back(&req);
+    trace("co_submit", (int64_t)q.size());
     if (q.size() >= max_batch) cv.notify_all();
     bool waited_window = false;
     while (!req.done) {
@@ -85,15 +99,25 @@ struct CoalescerCore {
       }
       // this thread leads the group's next batch: collect for the window, and for as long as every context is busy
       leader[group] = true;
+      trace("co_lead", (int64_t)q.size());
       if (!waited_window) {
         // the window restarts while calls keep arriving (threads released by the previous batch come back one by one),
         // up to 16 windows in all
         const auto cap = std::chrono::steady_clock::now() + std::chrono::microseconds(16ull * window_us);
         for (size_t seen = q.size();; seen = q.size()) {
           const bool full = timed_wait(lk, std::chrono::microseconds(window_us), [&] { return q.size() >= max_batch; });
-          if (full || q.size() == seen || std::chrono::steady_clock::now() >= cap) break;
+          if (full || (q.size() == seen && arriving.load() == 0) || std::chrono::steady_clock::now() >= cap) break;
         }
         waited_window = true;
+        trace("co_window_end", (int64_t)q.size());
+      }
+      // enough parts in flight to keep the device busy: keep collecting until one of them ends (its release notifies
+      // cv), the queue is full, or 64 windows have passed (a part that never ends must not hold the queue for ever)
+      {
+        const size_t limit = std::max<size_t>(h.max_in_flight(), 1);
+        const auto cap = std::chrono::steady_clock::now() + std::chrono::microseconds(64ull * std::max(window_us, 100u));
+        while (in_flight >= limit && q.size() < max_batch && std::chrono::steady_clock::now() < cap)
+          timed_wait(lk, std::chrono::microseconds(std::max(window_us, 100u)));
       }
       // a free context (several batches are then in flight, one per context); later arrivals join the queue meanwhile
       void* c = nullptr;
@@ -102,10 +126,13 @@ struct CoalescerCore {
         if (c) break;
         timed_wait(lk, std::chrono::microseconds(100));
       }
+      trace("co_acquired", (int64_t)q.size(), (int64_t)in_flight);
       const size_t take = std::min<size_t>(q.size(), max_batch);
       std::vector<Req*> reqs(q.begin(), q.begin() + take);
       q.erase(q.begin(), q.begin() + take);
       leader[group] = false;
+      const bool alone = in_flight == 0;  // nothing else is running: a large batch may be cut over two contexts
+      in_flight++;
       lk.unlock();
       // a second free context takes part of a batch large enough to cut: the parts overlap on the device, or run on two
       // devices.  The cut is UNEVEN (3/8 : 5/8 by default): callers that come straight back for their next proof (a rayon
@@ -114,30 +141,38 @@ struct CoalescerCore {
       // while the other is being gathered.
       std::vector<Req*> second;
       void* c2 = nullptr;
-      if (reqs.size() >= 2 * h.deal_min() && (c2 = h.acquire_second()) != nullptr) {
+      if (alone && reqs.size() >= 2 * h.deal_min() && (c2 = h.acquire_second()) != nullptr) {
         const size_t first = std::max<size_t>(h.deal_min(), reqs.size() * h.split_eighths() / 8);
         second.assign(reqs.begin() + first, reqs.end());
         reqs.resize(first);
       }
       const bool early = h.early_release();
+      trace("co_run", (int64_t)reqs.size(), (int64_t)second.size());
       std::thread helper;
-      if (c2)
+      if (c2) {
+        {
+          std::lock_guard<std::mutex> g(mu);
+          in_flight++;
+        }
         helper = std::thread([this, &second, c2, &h, early] {
           h.run(c2, second, true);
-          if (early) {
-            std::lock_guard<std::mutex> g(mu);
+          trace("co_run2_end", (int64_t)second.size());
+          std::lock_guard<std::mutex> g(mu);
+          in_flight--;
+          if (early)
             for (Req* r : second) r->done = true;  // (a request is not touched again once it is marked: its caller returns)
-            cv.notify_all();
-          }
+          cv.notify_all();
         });
+      }
       h.run(c, reqs, false);  // (run counts what it proved in `batches` / `proofs`)
       h.release(c);
-      if (early) {
-        lk.lock();
+      trace("co_run_end", (int64_t)reqs.size());
+      lk.lock();
+      in_flight--;
+      if (early)
         for (Req* r : reqs) r->done = true;
-        cv.notify_all();
-        lk.unlock();
-      }
+      cv.notify_all();
+      lk.unlock();
       if (helper.joinable()) helper.join();
       lk.lock();
       if (!early) {
@@ -146,6 +181,7 @@ struct CoalescerCore {
         cv.notify_all();
       }
     }
+    trace("co_return");
   }
 };
 

@@ -19,6 +19,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/capgpu.h"
@@ -26,6 +27,7 @@
 #include "launch.hpp"
 #include "msm.hpp"
 #include "ntt.hpp"
+#include "trace.hpp"
 
 namespace cap {
 
@@ -105,6 +107,8 @@ struct Context {
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   hipStream_t stream = nullptr;  // the stream work is enqueued on (own_stream unless capgpu_set_stream)
   hipEvent_t tm0 = nullptr, tm1 = nullptr;  // capgpu_timer_begin / _end
+  bool tm_open = false;                      // a measurement is open (one per context at a time) ...
+  std::thread::id tm_owner;                  // ... by this thread
   NttSmallTables small;
   std::map<uint32_t, NttDomain> domains;
   std::map<uint32_t, Ntt3Domain> domains3;  // N = 3 * 2^log_m (the prover's quotient domain)
@@ -192,8 +196,14 @@ const char* last_error();
 int hip_fail(hipError_t e, const char* what);  // records message, returns CAPGPU_ERR_HIP / _OOM
 int take_launch_error();                       // CAPGPU_OK, or CAPGPU_ERR_HIP naming the first kernel whose launch failed
 
-// grows (never shrinks) a scratch buffer of the current context; synchronises its stream before freeing the old one
+// grows (never shrinks) a scratch buffer of the current context; drains its streams before freeing the old one.  Scratch is
+// what capgpu_trim releases and capgpu_set_memory_limit caps (per device); device memory held outside a Scratch that is
+// scratch by nature (plonk.hip's staging slots) is entered with scratch_account and asks scratch_room_for first.
 int scratch_reserve(Scratch& s, size_t bytes);
+void scratch_account(int device, size_t add, size_t sub);
+bool scratch_room_for(int device, size_t bytes);
+size_t plonk_trim_staging();  // plonk.hip: frees the unused staging slots of coalesced callers; returns the bytes
+void plonk_reset_staging();   // ... and the pool's streams (capgpu_shutdown)
 // grows (never shrinks) context c's pinned host buffer; synchronises its stream before freeing the old one
 int pinned_reserve(Context& c, size_t bytes);
 // cached domain tables for 2^log_n

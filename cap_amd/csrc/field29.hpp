@@ -45,6 +45,14 @@ struct FqP29 {
   // 4p, same inflation
   static constexpr uint32_t SUB4P[9] = {0x21f3f51cu, 0x241182dau, 0x31ca8d3bu, 0x2b548b42u, 0x361765dfu,
                                         0x2b6d0301u, 0x229b8503u, 0x397098cfu, 0x00c19138u};
+  // 8p with limbs 0..7 inflated into [2^30, 2^31)
+  static constexpr uint32_t SUB8P[9] = {0x43e7ea38u, 0x482305b4u, 0x43951a76u, 0x56a91685u, 0x4c2ecbbeu,
+                                        0x56da0603u, 0x45370a06u, 0x52e1319eu, 0x01832271u};
+  // constant-multiplicand product (mul_shoup): 2^261 - p, and -p^-1 mod 2^261
+  static constexpr uint32_t NEGP[9] = {0x078302b9u, 0x1efb9f49u, 0x038d5cb0u, 0x1d2add2fu, 0x0a7a2687u,
+                                       0x1d24bf3fu, 0x1f591ebeu, 0x11a3d9cbu, 0x1fcf9bb1u};
+  static constexpr uint32_t NPINV[9] = {0x04866389u, 0x1e903c17u, 0x129ab261u, 0x1cfaca3du, 0x1da809edu,
+                                        0x05e80c19u, 0x11af62bfu, 0x16f23111u, 0x0ff57a22u};
 };
 struct FrP29 {
   using Base = FrP;
@@ -65,6 +73,12 @@ struct FrP29 {
                                         0x25b68180u, 0x214dc281u, 0x3cb84c67u, 0x0060c89bu};
   static constexpr uint32_t SUB4P[9] = {0x20000004u, 0x3c3eb27du, 0x39709142u, 0x3f4243ccu, 0x36174a0bu,
                                         0x2b6d0301u, 0x229b8503u, 0x397098cfu, 0x00c19138u};
+  static constexpr uint32_t SUB8P[9] = {0x40000008u, 0x587d64fau, 0x52e12285u, 0x5e848799u, 0x4c2e9417u,
+                                        0x56da0603u, 0x45370a06u, 0x52e1319eu, 0x01832271u};
+  static constexpr uint32_t NEGP[9] = {0x0fffffffu, 0x00f05360u, 0x11a3dbafu, 0x182f6f0cu, 0x0a7a2d7cu,
+                                       0x1d24bf3fu, 0x1f591ebeu, 0x11a3d9cbu, 0x1fcf9bb1u};
+  static constexpr uint32_t NPINV[9] = {0x0fffffffu, 0x170fac9fu, 0x1a446cf0u, 0x0d0c9698u, 0x02391658u,
+                                        0x0c144c83u, 0x06cb8e6au, 0x03a1b068u, 0x1273f82fu};
 };
 
 #ifdef CAP_FL_CHECK
@@ -449,6 +463,84 @@ struct Fl {
 #pragma unroll
       for (int j = 0; j < 9; j++) c[i + j] += (uint64_t)a.v[i] * b.v[j] + (uint64_t)c2.v[i] * d.v[j];
     return reduce_cols(c);
+  }
+
+  // ---- constant-multiplicand product (round-5 VERDICT item 4) --------------------------------------------------
+  // a * w mod p for a table constant w given as the pair (w, wq): w the PLAIN canonical value (< p), wq =
+  // floor(w * 2^261 / p) (shoup_quotient).  No Montgomery factor: data in the internal form stays in it.
+  //   q  = floor(a * wq / 2^261), from columns 7 .. 16 of the product (53 multiply-adds; what lies below column 7
+  //        changes q by at most one),
+  //   r  = low 261 bits of a * w + q * (2^261 - p)   (45 + 45 multiply-adds)  =  a * w - q * p  exactly,
+  // 143 multiply-adds and no serial digit chain against the 171 of the Montgomery product.
+  // Bounds: limbs(a) < 2^30 (a normalized value or one lazy sum of two), w and wq normalized.  With Q = floor(a w / p):
+  // Q - q <= a / 2^261 + 2, so the normalized result is < 4p for a < 2^261 and < 5p for a lazy sum of two (< 2^262).
+  static CAP_HD fl mul_shoup(const fl& a, const fl& w, const fl& wq) {
+    uint32_t q[9];
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 7; k < 17; k++) {
+#pragma unroll
+      for (int i = 0; i < 9; i++) {
+        const int j = k - i;
+        if (j >= 0 && j < 9) {
+          acc += (uint64_t)a.v[i] * wq.v[j];
+          CAP_FL_KEEP(acc);
+        }
+      }
+      if (k >= 9) q[k - 9] = (uint32_t)acc & M29;
+      acc >>= 29;
+    }
+    CAP_FL_ASSERT(acc < (1ull << 31));
+    q[8] = (uint32_t)acc;
+    fl r;
+    acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) {
+        acc += (uint64_t)a.v[i] * w.v[k - i];
+        CAP_FL_KEEP(acc);
+        acc += (uint64_t)q[i] * PR::NEGP[k - i];
+        CAP_FL_KEEP(acc);
+      }
+      r.v[k] = (uint32_t)acc & M29;
+      acc >>= 29;
+    }
+    return r;  // (what is left in acc are bits 261.. of a w + q (2^261 - p): multiples of 2^261, dropped)
+  }
+  // wq = floor(w * 2^261 / p) from t = w * 2^261 mod p, CANONICAL (the internal Montgomery form of w): the division
+  // (w 2^261 - t) / p is exact and its quotient is below 2^261, so it is (-t) * p^-1 mod 2^261 - one low-half product.
+  static CAP_HD fl shoup_quotient(const fl& t_canonical) {
+    fl r;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+#pragma unroll
+      for (int i = 0; i <= k; i++) acc += (uint64_t)t_canonical.v[i] * PR::NPINV[k - i];
+      r.v[k] = (uint32_t)acc & M29;
+      acc >>= 29;
+    }
+    return r;
+  }
+  // a - b + 8p, normalized, for a normalized b < 7.9 p (a mul_shoup result); limbs(a) < 2^30
+  static CAP_HD fl sub8p(const fl& a, const fl& b) {
+    fl r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      CAP_FL_ASSERT(i == 8 ? b.v[i] <= PR::SUB8P[i] : (b.v[i] < (1u << 29) && a.v[i] < (1u << 30)));
+      r.v[i] = a.v[i] + (PR::SUB8P[i] - b.v[i]);
+    }
+    return normalize(r);
+  }
+  // a - b + 8p WITHOUT carrying (see sub2p_lazy): limbs(a) + 2^31 at most, for limbs(a) < 2^30
+  static CAP_HD fl sub8p_lazy(const fl& a, const fl& b) {
+    fl r;
+#pragma unroll
+    for (int i = 0; i < 9; i++) {
+      CAP_FL_ASSERT(i == 8 ? b.v[i] <= PR::SUB8P[i] : (b.v[i] < (1u << 29) && a.v[i] < (1u << 30)));
+      r.v[i] = a.v[i] + (PR::SUB8P[i] - b.v[i]);
+    }
+    return r;
   }
 
   // 1 / a = a^(p-2) in the internal Montgomery form (0 for a = 0): 4-bit fixed windows, 252 squarings and at most

@@ -460,6 +460,36 @@ hipStream_t side_stream(Context& c) {
   }
   return c.side_stream;
 }
+// The parts of ONE dealt host batch (capgpu_plonk_prove_batch cuts it over two contexts of a device) copy their witnesses
+// in PART ORDER, not side by side: two copies at once share the link, both parts' first chunks land late and the GPU idles
+// for both; in part order the first part's first chunk lands after half that time and its kernels run while the second
+// part's witnesses arrive (round-5 VERDICT item 2: pcie_inclusive 0.92 of the resident rate).  A part takes its turn
+// before its first copy and passes it on when its last copy has landed; the dealer passes a part's turn on when the part
+// returns, whatever happened inside (an error path never holds the others up).
+struct H2dTurn {
+  std::mutex mu;
+  std::condition_variable cv;
+  uint32_t next = 0;
+  void wait_for(uint32_t idx) {
+    std::unique_lock<std::mutex> lk(mu);
+    cv.wait(lk, [&] { return next >= idx; });
+  }
+  void pass(uint32_t idx) {  // part idx is done copying (idempotent)
+    std::lock_guard<std::mutex> lk(mu);
+    if (next < idx + 1) next = idx + 1;
+    cv.notify_all();
+  }
+};
+thread_local H2dTurn* tl_h2d_turn = nullptr;
+thread_local uint32_t tl_h2d_index = 0;
+static bool h2d_in_part_order() {
+  static const bool on = [] {
+    const char* e = getenv("CAPGPU_H2D_PART_ORDER");
+    return !e || atoi(e) != 0;
+  }();
+  return on;
+}
+
 // chunks of proofs the host-resident wire columns of a batch are copied and committed in (round 1 of prove_batch)
 uint32_t h2d_chunks(uint32_t P) {
   static const int forced = [] {
@@ -469,6 +499,20 @@ uint32_t h2d_chunks(uint32_t P) {
   }();
   if (forced) return std::min<uint32_t>((uint32_t)forced, P);
   return P >= 64 ? 4u : (P >= 32 ? 2u : 1u);  // a chunk's commitments should still fill the chip (>= 80 MSMs)
+}
+// first proof of chunk ck (ck = chunks: P).  Equal chunks - except that the FIRST chunk of a batch of >= 64 proofs that
+// starts on an idle device is kept short (CAPGPU_PROVE_FIRST_CHUNK proofs, default 16; 0 = equal chunks): nothing runs
+// until it has landed.
+uint32_t h2d_chunk_start(uint32_t P, uint32_t chunks, uint32_t ck, bool short_first) {
+  static const uint32_t first = [] {
+    const char* e = getenv("CAPGPU_PROVE_FIRST_CHUNK");
+    const int x = e ? atoi(e) : 16;
+    return (uint32_t)(x >= 0 && x <= 4096 ? x : 16);
+  }();
+  if (ck == 0) return 0;
+  if (ck >= chunks) return P;
+  if (!short_first || first == 0 || chunks < 3 || first * chunks >= P) return (uint32_t)((uint64_t)P * ck / chunks);
+  return first + (uint32_t)((uint64_t)(P - first) * (ck - 1) / (chunks - 1));
 }
 
 // msgs / msg_lens (optional): one transcript init message per proof; otherwise ext_msg is shared by the batch.
@@ -492,6 +536,11 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   // memory: the call blocks the host, not the device) overlaps the commitments of the one before.
   Context& c = ctx();
   hipStream_t s = c.stream;
+  trace("pb_begin", c.slot, P);
+  struct TraceEnd {
+    int slot;
+    ~TraceEnd() { trace("pb_end", slot); }
+  } trace_end{c.slot};
   // host-resident witnesses are copied on the context's copy stream straight from the callers' buffers: no exit path -
   // an error return in particular - may leave such a copy in flight (the caller frees or reuses its buffer, and the
   // next call writes the same staging area)
@@ -692,8 +741,15 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
     if (chunks == 1 && (r = commit_wires(0, P))) return r;
     return CAPGPU_OK;
   };
+  H2dTurn* const turn = h_wires ? tl_h2d_turn : nullptr;
+  const uint32_t turn_idx = tl_h2d_index;
+  if (turn) {
+    turn->wait_for(turn_idx);
+    trace("pb_h2d_turn", c.slot, turn_idx);
+  }
+  const bool short_first = h_wires && (!turn || turn_idx == 0);  // (a later part's copies run under the first part's kernels)
   for (uint32_t ck = 0; ck < chunks; ck++) {
-    const uint32_t p0 = (uint32_t)((uint64_t)P * ck / chunks), p1 = (uint32_t)((uint64_t)P * (ck + 1) / chunks);
+    const uint32_t p0 = h2d_chunk_start(P, chunks, ck, short_first), p1 = h2d_chunk_start(P, chunks, ck + 1, short_first);
     if (h_wires) {
       hipStream_t cs = chunks > 1 ? h2d_stream() : nullptr;
       if (!cs) cs = s;
@@ -705,6 +761,7 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
         CAP_HIP(e2);
       }
       // one copy per run of proofs that are contiguous in host memory (a plain batch: one per chunk)
+      trace("pb_h2d_issue", c.slot, ck);
       for (uint32_t p = p0; p < p1;) {
         uint32_t q = p + 1;
         while (q < p1 && h_wires[q] == h_wires[q - 1] + (size_t)4 * NW * n) q++;
@@ -712,6 +769,7 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
                                sizeof(fe) * (size_t)(q - p) * NW * n, hipMemcpyHostToDevice, cs));
         p = q;
       }
+      trace("pb_h2d_issued", c.slot, ck);
       if (cs != s) {  // the chunk's kernels wait for its copy, not for the copies after it
         hipEvent_t ev;
         CAP_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
@@ -721,6 +779,12 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
       }
     }
     if (chunks > 1 && (rc = r1_chunk_kernels(p0, p1 - p0, true))) return rc;
+  }
+  if (turn) {
+    // (a pageable source has landed when hipMemcpyAsync returns; a pinned one when its stream has drained: the next part
+    // gets the link to itself either way.  This part's kernels are already enqueued behind their chunks.)
+    if (chunks > 1 && c.copy_stream) CAP_HIP(hipStreamSynchronize(c.copy_stream));
+    turn->pass(turn_idx);
   }
   hipStream_t s2 = nullptr;
   const bool overlap = chunks == 1 && P <= r1_overlap_max() && !c.prof.on && !comm_shard_prover() && s == c.own_stream &&
@@ -777,6 +841,7 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
          return seg(1, [&]() -> int { return r3_wire_cosets(s); });
        })))
     return rc;
+  trace("pb_r1_done", c.slot);
   std::vector<Chal> chal(P);
   parallel_for(P, [&](uint32_t p) {
     for (int i = 0; i < NW; i++) {
@@ -882,6 +947,7 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
          return seg(3, [&]() -> int { return z_cosets(s); });
        })))
     return rc;
+  trace("pb_r2_done", c.slot);
   parallel_for(P, [&](uint32_t p) {
     append_g1(tr[p], ha[p]);
     affine_to_words(ha[p], proofs[p].prod_perm_poly_comm);
@@ -923,6 +989,7 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   uint32_t* flags = h_flags;
   CAP_HIP(hipMemcpyAsync(flags, w.flags, sizeof(uint32_t) * P, hipMemcpyDeviceToHost, s));
   if ((rc = fetch_comms(P * NW))) return rc;
+  trace("pb_r3_done", c.slot);
   for (uint32_t p = 0; p < P; p++) {
     if (flags[p]) {
       set_error("capgpu_plonk_prove: proof %u: quotient polynomial has the wrong degree (flags %u): "
@@ -981,6 +1048,7 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   fe* evals = h_evals;
   CAP_HIP(hipMemcpyAsync(evals, w.evals, sizeof(fe) * (size_t)P * 10, hipMemcpyDeviceToHost, s));
   CAP_HIP(hipStreamSynchronize(s));
+  trace("pb_r4_done", c.slot);
 
   // ---- round 5: linearisation + opening proofs ---------------------------------------------------------
   std::vector<LinTerm> terms((size_t)P * kLinTerms);
@@ -1073,6 +1141,7 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
        })))
     return rc;
   if ((rc = fetch_comms(P * 2))) return rc;
+  trace("pb_r5_done", c.slot);
   for (uint32_t p = 0; p < P; p++) {
     affine_to_words(ha[p * 2], proofs[p].opening_proof);
     affine_to_words(ha[p * 2 + 1], proofs[p].shifted_opening_proof);
@@ -1178,11 +1247,112 @@ struct ProveReq {
   int rc = CAPGPU_OK;
   std::string err;
   bool done = false;
+  // the caller's own copy of its witness on the device, started when the call arrived (StagePool); null: not staged
+  const void* d_wires = nullptr;
+  hipEvent_t staged = nullptr;  // recorded behind that copy
 };
+
+// OPTIONAL (CAPGPU_COALESCE_PRESTAGE=1; off by default): witnesses of coalesced single-proof calls copied to the device BY
+// THEIR CALLERS, when the call arrives - into a slot of this pool, on the pool's streams - instead of by the leader once
+// the batch has been gathered.  The copy of a 24 .. 40 proof batch (3 - 4.5 ms at 5.2 MB per proof) sits at the head of
+// every batch with nothing of that batch running, a tenth of its lifetime; staged, the batch starts from device memory
+// (one device-to-device copy per request into its contiguous input array) and a caller's latency drops by those
+// milliseconds (50 -> 45 ms with 64 closed-loop callers).  THROUGHPUT does not move (profiles/phase_trace_r06.md: 0.875 of
+// the resident rate either way): the link needs the same 4 ms for the batch's 200 MB wherever the copy is issued, the
+// callers now come back spread over those milliseconds, and the batches that form are smaller.  One physical device only
+// (the slot must live where the batch will run); slots are scratch for capgpu_trim / capgpu_set_memory_limit.
+struct StageSlot {
+  void* d = nullptr;
+  hipEvent_t ev = nullptr;
+  size_t bytes = 0;
+  hipStream_t stream = nullptr;  // one of the pool's copy streams (callers copy concurrently: several, round-robin)
+};
+struct StagePool {
+  std::mutex mu;
+  static constexpr int kStreams = 4;
+  hipStream_t streams[kStreams] = {};
+  int device = -1;
+  std::vector<StageSlot> idle;
+  size_t live = 0, made = 0;
+  static constexpr size_t kMaxSlots = 320;
+  static bool enabled() {  // (read per call: a process may switch it)
+    const char* e = getenv("CAPGPU_COALESCE_PRESTAGE");
+    return e && atoi(e) != 0;
+  }
+  // a slot of `bytes` on `dev`, or an empty one (the caller's witness then travels with the batch, as before)
+  StageSlot acquire(int dev, size_t bytes) {
+    std::lock_guard<std::mutex> lk(mu);
+    if (device >= 0 && device != dev) return {};
+    if (!streams[0]) {
+      for (int i = 0; i < kStreams; i++)
+        if (hipStreamCreateWithFlags(&streams[i], hipStreamNonBlocking) != hipSuccess) {
+          (void)hipGetLastError();
+          for (int j = 0; j < i; j++) (void)hipStreamDestroy(streams[j]);
+          for (int j = 0; j < kStreams; j++) streams[j] = nullptr;
+          return {};
+        }
+      device = dev;
+    }
+    for (size_t i = 0; i < idle.size(); i++)
+      if (idle[i].bytes == bytes) {
+        StageSlot s = idle[i];
+        idle.erase(idle.begin() + (long)i);
+        return s;
+      }
+    if (live >= kMaxSlots || !scratch_room_for(dev, bytes)) return {};
+    StageSlot s;
+    if (hipMalloc(&s.d, bytes) != hipSuccess || hipEventCreateWithFlags(&s.ev, hipEventDisableTiming) != hipSuccess) {
+      if (s.d) (void)hipFree(s.d);
+      (void)hipGetLastError();
+      return {};
+    }
+    s.bytes = bytes;
+    s.stream = streams[made++ % kStreams];
+    live++;
+    scratch_account(dev, bytes, 0);
+    return s;
+  }
+  void release(const StageSlot& s) {
+    if (!s.d) return;
+    std::lock_guard<std::mutex> lk(mu);
+    idle.push_back(s);
+  }
+  size_t trim() {  // frees the idle slots (the ones in use stay with their callers)
+    std::lock_guard<std::mutex> lk(mu);
+    size_t freed = 0;
+    for (int i = 0; i < kStreams; i++)
+      if (streams[i]) (void)hipStreamSynchronize(streams[i]);
+    for (StageSlot& s : idle) {
+      (void)hipFree(s.d);
+      (void)hipEventDestroy(s.ev);
+      freed += s.bytes;
+      scratch_account(device, 0, s.bytes);
+      live--;
+    }
+    idle.clear();
+    (void)hipGetLastError();
+    return freed;
+  }
+  void reset() {  // capgpu_shutdown: nothing is in flight any more
+    (void)trim();
+    std::lock_guard<std::mutex> lk(mu);
+    for (int i = 0; i < kStreams; i++) {
+      if (streams[i]) (void)hipStreamDestroy(streams[i]);
+      streams[i] = nullptr;
+    }
+    device = -1;
+    (void)hipGetLastError();
+  }
+};
+StagePool& stage_pool() {
+  static StagePool p;
+  return p;
+}
 // (the gathering protocol - queues, leaders, windows, the cut over two contexts - is coalescer.hpp, which also builds for
 // the host alone and runs under ThreadSanitizer there: tests/cpp/coalescer_tsan.cpp)
 struct Coalescer : CoalescerCore<ProveReq> {
-  std::map<uint64_t, uint64_t> group_of;  // (proving-key handle, input form) -> group id (handles are never reused)
+  // (proving-key handle, input form) -> (group id, domain size of the key); handles are never reused
+  std::map<uint64_t, std::pair<uint64_t, size_t>> group_of;
 };
 Coalescer& coalescer() {
   static Coalescer c;
@@ -1190,6 +1360,9 @@ Coalescer& coalescer() {
 }
 
 }  // namespace
+
+size_t plonk_trim_staging() { return stage_pool().trim(); }
+void plonk_reset_staging() { stage_pool().reset(); }
 
 // the registry's (home) copy of a key, without replicating it
 static int home_key(uint64_t h, std::shared_ptr<ProvingKey>* out) {
@@ -1665,11 +1838,37 @@ static int deal(int count, const std::function<int(int first, int cnt)>& part) {
     const size_t i = (start + k) % S;
     if (std::find(pick.begin(), pick.end(), i) == pick.end()) pick.push_back(i);
   }
+  H2dTurn turn;
+  // (parts on different devices have a link each: only the parts of ONE device take turns)
+  bool one_device = true;
+  for (size_t i = 1; i < parts; i++) one_device = one_device && rt().ctxs[pick[i]]->device == rt().ctxs[pick[0]]->device;
+  const bool ordered = h2d_in_part_order() && one_device;
+  // Two parts whose copies go in part order do not start together: the first has the device to itself while the second's
+  // witnesses arrive, stays ahead through every round and would end well before it, leaving the second part's last rounds
+  // alone on the device (its host steps uncovered).  The first part is therefore the larger: CAPGPU_DEAL_FIRST_SIXTEENTHS
+  // (default 9: 144 + 112 of 256; 8 = equal halves).
+  static const uint64_t first16 = [] {
+    const char* e = getenv("CAPGPU_DEAL_FIRST_SIXTEENTHS");
+    const int x = e ? atoi(e) : 9;
+    return (uint64_t)(x >= 4 && x <= 12 ? x : 9);
+  }();
+  auto cut = [&](size_t i) -> int {  // first proof of part i
+    if (i == 0) return 0;
+    if (i >= parts) return count;
+    if (ordered && parts == 2 && count >= 64) return (int)((uint64_t)count * first16 / 16);
+    return (int)((uint64_t)count * i / parts);
+  };
   auto body = [&](size_t i) {
-    const int first = (int)((uint64_t)count * i / parts), last = (int)((uint64_t)count * (i + 1) / parts);
+    const int first = cut(i), last = cut(i + 1);
     ScopedCtx sc(*rt().ctxs[pick[i]]);
+    if (ordered) {
+      tl_h2d_turn = &turn;
+      tl_h2d_index = (uint32_t)i;
+    }
     rcs[i] = part(first, last - first);
     if (rcs[i]) errs[i] = last_error();
+    tl_h2d_turn = nullptr;
+    turn.pass((uint32_t)i);  // (whatever happened inside: a part that failed before its copies must not hold the others up)
   };
   std::vector<std::thread> th;
   for (size_t i = 1; i < parts; i++) th.emplace_back(body, i);
@@ -1884,6 +2083,8 @@ static void run_coalesced(std::vector<ProveReq*>& reqs) {
   std::vector<capgpu_proof> out(g);
   std::vector<const ProvingKey*> keys(g);
   std::vector<const uint64_t*> rows(g);  // every caller's own buffer: copied inside round 1, chunk by chunk
+  size_t staged = 0;
+  for (size_t i = 0; i < g; i++) staged += good[i]->d_wires != nullptr;
   for (size_t i = 0; i < g; i++) {
     rows[i] = good[i]->wires;
     if (good[i]->num_inputs) memcpy(&pubs[4 * ni * i], good[i]->pubs, 32 * good[i]->num_inputs);
@@ -1892,8 +2093,26 @@ static void run_coalesced(std::vector<ProveReq*>& reqs) {
     lens[i] = good[i]->msg_len;
     keys[i] = hold[i].get();
   }
+  bool resident = false;
+  if (staged) {
+    // the callers copied their witnesses when they arrived (StagePool): gather them into the batch's input array behind
+    // their copies; a request that got no slot goes host -> device here, on the batch's stream
+    trace("co_gather_staged", (int64_t)staged, (int64_t)g);
+    hipError_t e = hipSuccess;
+    for (size_t i = 0; i < g && e == hipSuccess; i++) {
+      char* dst = (char*)c.stage_b.p + per * i;
+      if (good[i]->d_wires) {
+        e = hipStreamWaitEvent(c.stream, good[i]->staged, 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(dst, good[i]->d_wires, per, hipMemcpyDeviceToDevice, c.stream);
+      } else {
+        e = hipMemcpyAsync(dst, good[i]->wires, per, hipMemcpyHostToDevice, c.stream);
+      }
+    }
+    if (e != hipSuccess) return fail_all(hip_fail(e, "gathering the staged witnesses"));
+    resident = true;
+  }
   rc = prove_batch(*keys[0], (uint32_t)g, (const fe*)c.stage_b.p, pubs.data(), ni, nullptr, 0, blind.data(), out.data(),
-                   msgs.data(), lens.data(), mixed ? &keys : nullptr, rows.data(), good[0]->form);
+                   msgs.data(), lens.data(), mixed ? &keys : nullptr, resident ? nullptr : rows.data(), good[0]->form);
   if (rc == CAPGPU_OK) rc = take_launch_error();
   if (rc == CAPGPU_OK) {
     for (size_t i = 0; i < g; i++) *good[i]->out = out[i];
@@ -1925,6 +2144,7 @@ int capgpu_plonk_prove_ex(uint64_t pk_handle, const uint64_t* wires, const uint6
   ProveReq req{pk_handle, wires, pub_inputs, num_inputs, ext_msg, ext_msg_len, blinders, proof_out, input_form};
   std::unique_lock<std::mutex> lk(co.mu);
   uint64_t group = 0;
+  size_t key_n = 0;
   {
     // (key, form) -> group: bit 7 of the group id is the input form, the bits below it the domain size
     const uint64_t gkey = (pk_handle << 1) | (uint64_t)(input_form == CAPGPU_INPUT_COEFFS);
@@ -1939,11 +2159,46 @@ int capgpu_plonk_prove_ex(uint64_t pk_handle, const uint64_t* wires, const uint6
       lk.lock();
       group = (ksrs << 8) ^ (uint64_t)__builtin_ctzll(kn | (1ull << 63)) ^
               ((uint64_t)(input_form == CAPGPU_INPUT_COEFFS) << 7);
-      co.group_of[gkey] = group;
+      co.group_of[gkey] = {group, kn};
+      key_n = kn;
     } else {
-      group = it->second;
+      group = it->second.first;
+      key_n = it->second.second;
     }
   }
+  // this caller's witness starts its way to the device now, on the staging pool's stream, while the batch it will be
+  // part of is still being gathered (one bound device only: the slot must live where the batch runs)
+  StageSlot slot;
+  {
+    int devices = 0;
+    if (StagePool::enabled() && key_n && capgpu_physical_device_count(&devices) == CAPGPU_OK && devices == 1 &&
+        comm_shard_slot() < 0) {
+      co.arriving++;  // (a leader's window stays open for callers that are on their way)
+      lk.unlock();
+      const int dev = ctx().device;
+      const size_t per = sizeof(fe) * NW * key_n;
+      slot = stage_pool().acquire(dev, per);
+      if (slot.d) {
+        hipError_t e = hipMemcpyAsync(slot.d, wires, per, hipMemcpyHostToDevice, slot.stream);
+        if (e == hipSuccess) e = hipEventRecord(slot.ev, slot.stream);
+        if (e != hipSuccess) {  // not fatal: the witness travels with the batch instead
+          (void)hipGetLastError();
+          (void)hipStreamSynchronize(slot.stream);
+          stage_pool().release(slot);
+          slot = StageSlot{};
+        }
+      }
+      req.d_wires = slot.d;
+      req.staged = slot.ev;
+      trace("co_prestaged", slot.d != nullptr);
+      lk.lock();
+      co.arriving--;
+    }
+  }
+  struct SlotReturn {  // (the batch that read the slot is done when submit returns; error paths included)
+    StageSlot& s;
+    ~SlotReturn() { stage_pool().release(s); }
+  } slot_return{slot};
   // what the protocol needs from the runtime: free device contexts and the prover
   struct Hooks {
     // a free device context: any of the process's (several batches are then in flight, one per context), or the one
@@ -1982,6 +2237,18 @@ int capgpu_plonk_prove_ex(uint64_t pk_handle, const uint64_t* wires, const uint6
         return (size_t)(x >= 1 && x <= 4 ? x : 3);
       }();
       return eighths;
+    }
+    // batch parts running at once before a leader keeps collecting instead of taking another free context:
+    // CAPGPU_COALESCE_INFLIGHT (default 2) per bound DEVICE - two large batches fill a GPU, a third only fragments them
+    size_t max_in_flight() {
+      static const size_t per_device = [] {
+        const char* e = getenv("CAPGPU_COALESCE_INFLIGHT");
+        const int x = e ? atoi(e) : 2;
+        return (size_t)(x >= 1 && x <= 64 ? x : 2);
+      }();
+      int devices = 1;
+      (void)capgpu_physical_device_count(&devices);
+      return per_device * (size_t)std::max(devices, 1);
     }
     bool early_release() {  // CAPGPU_COALESCE_EARLY=0: a cut batch's callers return when both parts are done, as before
       static const bool early = [] {

@@ -15,6 +15,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 typedef unsigned __int128 u128;
 typedef struct { uint64_t v[4]; } fr;
@@ -310,4 +311,69 @@ void capwit_msm_work(const uint64_t* vals, uint64_t count, uint32_t c, uint64_t*
   free(hit);
   *entries_out = entries;
   *buckets_out = buckets;
+}
+
+/* ---- closed-loop callers (bench harness) ---------------------------------------------------------------------------
+ * The reference's callers are rayon workers: compiled threads that call prove() for one note and come straight back for
+ * the next (src/utils/params_builder.rs:194-226).  Python threads cannot play them - forty threads released by one batch
+ * queue for the interpreter lock before they can call again, and the stragglers miss the next batch (round 6,
+ * profiles/phase_trace_r06.md) - so the bench starts `threads` native threads here, each making `calls` calls of `fn`
+ * (capgpu_plonk_prove_ex, passed as a pointer: this helper does not link the product library).  Call k of thread t uses
+ * entry t * calls + k of the argument arrays.  Returns the number of failed calls; *seconds_out = first call to last
+ * return. */
+typedef int (*capwit_prove_fn)(uint64_t pk, const uint64_t* wires, const uint64_t* pubs, size_t num_inputs,
+                               const uint8_t* msg, size_t msg_len, const uint64_t* blinders, int form, void* proof_out);
+struct loop_ctx {
+  capwit_prove_fn fn;
+  uint64_t pk;
+  int calls;
+  const uint64_t* const* wires;
+  const uint64_t* const* pubs;
+  size_t num_inputs;
+  const uint8_t* msg;
+  size_t msg_len;
+  const uint64_t* const* blinders;
+  void* const* proofs;
+  pthread_barrier_t* bar;
+  int t, failed;
+};
+static void* loop_worker(void* p) {
+  struct loop_ctx* c = (struct loop_ctx*)p;
+  pthread_barrier_wait(c->bar);
+  for (int k = 0; k < c->calls; k++) {
+    const size_t i = (size_t)c->t * (size_t)c->calls + (size_t)k;
+    if (c->fn(c->pk, c->wires[i], c->pubs[i], c->num_inputs, c->msg, c->msg_len, c->blinders[i], 0, c->proofs[i])) c->failed++;
+  }
+  return 0;
+}
+int capwit_closed_loop_callers(capwit_prove_fn fn, uint64_t pk, int threads, int calls, const uint64_t* const* wires,
+                               const uint64_t* const* pubs, size_t num_inputs, const uint8_t* msg, size_t msg_len,
+                               const uint64_t* const* blinders, void* const* proofs, double* seconds_out) {
+  if (threads < 1 || calls < 1 || threads > 4096) return -1;
+  pthread_t* th = (pthread_t*)malloc(sizeof(pthread_t) * (size_t)threads);
+  struct loop_ctx* cx = (struct loop_ctx*)malloc(sizeof(struct loop_ctx) * (size_t)threads);
+  pthread_barrier_t bar;
+  if (!th || !cx || pthread_barrier_init(&bar, 0, (unsigned)threads + 1)) return -1;
+  int started = 0;
+  for (int t = 0; t < threads; t++) {
+    struct loop_ctx c = {fn, pk, calls, wires, pubs, num_inputs, msg, msg_len, blinders, proofs, &bar, t, 0};
+    cx[t] = c;
+    if (pthread_create(&th[t], 0, loop_worker, &cx[t])) break;
+    started++;
+  }
+  if (started != threads) return -1; /* (a box that cannot start the threads: the leg reports the failure) */
+  struct timespec t0, t1;
+  pthread_barrier_wait(&bar);
+  clock_gettime(CLOCK_MONOTONIC, &t0);
+  int failed = 0;
+  for (int t = 0; t < threads; t++) {
+    pthread_join(th[t], 0);
+    failed += cx[t].failed;
+  }
+  clock_gettime(CLOCK_MONOTONIC, &t1);
+  if (seconds_out) *seconds_out = (double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec);
+  pthread_barrier_destroy(&bar);
+  free(th);
+  free(cx);
+  return failed;
 }

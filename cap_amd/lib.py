@@ -136,6 +136,37 @@ def mem_info():
     return f.value, t.value
 
 
+def trim():
+    """capgpu_trim: release the scratch, pinned result areas and captured graphs of every idle context.
+    Returns (device bytes released, contexts skipped because a call was running on them)."""
+    b, busy = ctypes.c_uint64(0), ctypes.c_int(0)
+    check(load().capgpu_trim(ctypes.byref(b), ctypes.byref(busy)))
+    return b.value, busy.value
+
+
+def set_memory_limit(scratch_bytes_per_device: int):
+    """capgpu_set_memory_limit: cap on the scratch the library holds per device (0 = none); a call that would grow past it
+    fails with CAPGPU_ERR_OOM (CapGpuError code -5) after trimming the device's idle contexts."""
+    check(load().capgpu_set_memory_limit(ctypes.c_uint64(scratch_bytes_per_device)))
+
+
+def scratch_info():
+    """(scratch bytes held on the calling thread's device, the cap - 0 = none)"""
+    b, lim = ctypes.c_uint64(0), ctypes.c_uint64(0)
+    check(load().capgpu_scratch_info(ctypes.byref(b), ctypes.byref(lim)))
+    return b.value, lim.value
+
+
+def trace_enable(on: bool):
+    check(load().capgpu_trace_enable(int(bool(on))))
+
+
+def trace_dump(path: str) -> int:
+    n = ctypes.c_uint64(0)
+    check(load().capgpu_trace_dump(path.encode(), ctypes.byref(n)))
+    return n.value
+
+
 def _p(a: np.ndarray):
     assert a.dtype == np.uint64 and a.flags["C_CONTIGUOUS"]
     return a.ctypes.data_as(u64p)
@@ -263,7 +294,7 @@ def msm_g1(handle: int, scalars: np.ndarray, offset: int = 0) -> np.ndarray:
 
 
 def lagrange_commit(handle: int, log_n: int, scalars_mont: np.ndarray) -> np.ndarray:
-    """KZG commitment from VALUES on the 2^log_n domain (+ up to two blinders): MSM on the Lagrange-form commit key"""
+    """KZG commitment from VALUES on the 2^log_n domain (+ up to three blinders): MSM on the Lagrange-form commit key"""
     sc = np.ascontiguousarray(scalars_mont, dtype=np.uint64).reshape(-1, 4)
     out = np.zeros(12, np.uint64)
     check(load().capgpu_msm_g1_lagrange(ctypes.c_uint64(handle), ctypes.c_uint32(log_n), _p(sc), ctypes.c_size_t(sc.shape[0]),

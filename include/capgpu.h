@@ -130,6 +130,29 @@ int capgpu_device_info(char* name_out, int* cu_count_out, uint64_t* hbm_bytes_ou
 int capgpu_device_peer_info(int slot_a, int slot_b, int* access_out);
 /* free / total device memory of the calling thread's device, in bytes (hipMemGetInfo) */
 int capgpu_mem_info(uint64_t* free_bytes_out, uint64_t* total_bytes_out);
+/* Footprint control (SURVEY 8b ownership rules: the library owns its workspace, the caller decides how much of the GPU
+ * that may be).  A context's scratch - prover workspace, MSM workspace, NTT scratch, staging - grows to the largest call
+ * it has served and stays (~25 GB per context after a 256-proof batch at n = 2^15; four contexts per bound device):
+ *  - capgpu_trim releases the scratch, the pinned result area and the captured launch graphs of every context no call is
+ *    running on; tables the caller created (SRS, proving keys, NTT domains) stay.  *bytes_released_out: device bytes
+ *    given back; *contexts_busy_out: contexts skipped because a call was running on them.  The next call on a trimmed
+ *    context allocates again (a hipMalloc per buffer, ~ms).
+ *  - capgpu_set_memory_limit caps the scratch the library holds PER DEVICE (sum over that device's contexts; 0 = no
+ *    cap, the default).  A call that would grow past it first takes the growth slack off, then trims the device's idle
+ *    contexts, and then fails with CAPGPU_ERR_OOM naming the bytes it needed - the caller proves in smaller batches
+ *    (scratch is proportional to the batch) or raises the cap.  Scratch already held above a new cap is trimmed from
+ *    idle contexts at once.  Tables are not counted.
+ *  - capgpu_scratch_info: scratch bytes currently held on the calling thread's device, and the cap. */
+int capgpu_trim(uint64_t* bytes_released_out, int* contexts_busy_out);
+int capgpu_set_memory_limit(uint64_t scratch_bytes_per_device);
+int capgpu_scratch_info(uint64_t* scratch_bytes_out, uint64_t* limit_out);
+/* Host-side phase trace (diagnostics; no reference counterpart): while on, the library timestamps the phases the kernel
+ * profiler cannot see - a coalesced call's queueing, window and context wait, the host-to-device copies of a batch's
+ * witnesses, the host steps between the prover's rounds, the release of the callers - into a ring of 2^20 events.
+ * capgpu_trace_enable(1) starts a fresh trace, (0) stops it; capgpu_trace_dump writes one line per event
+ * ("t_us thread tag a b"; tools/gpu_phase_trace.py reads it) and returns the count.  Off: one relaxed load per site. */
+int capgpu_trace_enable(int on);
+int capgpu_trace_dump(const char* path, uint64_t* events_out);
 
 /* ---- device memory / stream (plumbing for callers that keep data resident) -------------- */
 int capgpu_malloc(void** dev_ptr_out, size_t bytes);
@@ -139,7 +162,10 @@ int capgpu_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);
 int capgpu_sync(void);
 /* Device time, in milliseconds, of the work the calling thread's context executes between the two calls (HIP events on
  * its stream; _end waits for that work).  SURVEY 8d's "hipEvent around device section": bench.py times its MSM / NTT
- * legs with it.  One pair per context: a second _begin restarts the measurement. */
+ * legs with it.  ONE measurement per context at a time, owned by the thread that opened it: that thread may restart it
+ * with a second _begin; _begin from another thread while it is open, and _end without an open measurement of the
+ * calling thread, return CAPGPU_ERR_INVALID_ARG (threads that time concurrently bind different contexts:
+ * capgpu_set_device). */
 int capgpu_timer_begin(void);
 int capgpu_timer_end(double* ms_out);
 /* Run all subsequent work on the caller's hipStream_t (e.g. torch's current stream); NULL

@@ -54,6 +54,8 @@ struct Hooks {
     }
     return nullptr;
   }
+  size_t in_flight_limit = 2;
+  size_t max_in_flight() { return in_flight_limit; }
   void* acquire() { return try_acquire(); }
   void* acquire_second() {
     if (ctxs.size() <= 1) return nullptr;

@@ -43,6 +43,10 @@ template<class F> void run(char op, fl a, fl b){
     case 'M': r=F::mul_add_mul(a,b,b,a); break;
     case 'E': r=F::zero(); r.v[0]=F::eq(a,b); break;
     case 'i': r=F::inv(F::normalize(a)); break;
+    // constant-multiplicand product: b = the plain canonical constant w; its pair (w, wq) is derived as the NTT tables do
+    case 'S': { fl t=F::canonical(F::to_mont(F::pack(b))); r=F::mul_shoup(a,b,F::shoup_quotient(t)); break; }
+    case 'Q': { fl t=F::canonical(F::to_mont(F::pack(b))); r=F::shoup_quotient(t); break; }
+    case '8': r=F::sub8p(a,b); break;
   }
   print(r);
 }

@@ -69,6 +69,18 @@ def test_field29_against_python_integers(binaries):
             add("E", 1 if (a - b) % m == 0 else 0)
             if it % 10 == 0:    # inverse in the Montgomery domain: (a / R')^-1 * R' = R'^2 / a
                 add("i", pow(a, -1, m) * RR * RR % m if a % m else 0)
+        # the constant-multiplicand product (mul_shoup): any lazy a with limbs < 2^30 (here: up to 2^262 - 1 in value,
+        # written as a normalized 261-bit part the parser spreads over the limbs), every canonical constant w
+        for it in range(300):
+            a = random.randrange(1 << 261) if it > 12 else random.choice([0, 1, m - 1, m, (1 << 261) - 1, 168 * m, 5 * m - 1])
+            b = random.randrange(m) if it > 12 else random.choice([0, 1, 2, m - 1, m - 2, m // 2, (1 << 253), 3])
+            lines.append(f"{w} S {a:x} {b:x}")
+            exp.append(("S", a * b % m, m))
+            lines.append(f"{w} Q {a:x} {b:x}")
+            exp.append(("Q", (b << 261) // m, m))
+            b8 = random.randrange(int(7.9 * m))
+            lines.append(f"{w} 8 {a % (1 << 260):x} {b8:x}")
+            exp.append(("8", (a % (1 << 260) - b8) % m, m))
         for k in range(0, 160, 7):       # every multiple of p is recognised as zero
             lines.append(f"{w} z {k * m:x} 0")
             exp.append(("z", 1, m))
@@ -78,8 +90,10 @@ def test_field29_against_python_integers(binaries):
     assert len(res) == len(exp)
     for line, o, (op, e, m) in zip(lines, res, exp):
         v = int(o, 16)
-        if op in "zEpcxf":
+        if op in "zEpcxfQ":
             assert v == e, line
+        elif op == "S":
+            assert v % m == e and v < 4 * m, line        # (a < 2^261 here: the 4p bound)
         elif op == "w":
             assert v % m == e and v < 2 * m, line
         else:
