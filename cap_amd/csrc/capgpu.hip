@@ -627,6 +627,11 @@ int find_lagrange(uint64_t h, uint32_t log_n, const MsmBases** out) {
   std::lock_guard<std::mutex> lk(e->lag_mu);
   auto it = e->lagrange.find(log_n);
   if (it == e->lagrange.end()) {
+    if (e->lagrange_failed.count(log_n)) {  // (not retried for every proof: the callers commit from coefficients instead)
+      set_error("capgpu: the Lagrange-form commit key of the 2^%u domain could not be built earlier (out of device memory?)",
+                log_n);
+      return CAPGPU_ERR_OOM;
+    }
     if (B->n < ((size_t)1 << log_n) + 3) {
       set_error("capgpu: SRS %llu has %zu points, the Lagrange-form commit key of a 2^%u domain needs %zu",
                 (unsigned long long)h, B->n, log_n, ((size_t)1 << log_n) + 3);
@@ -636,10 +641,20 @@ int find_lagrange(uint64_t h, uint32_t log_n, const MsmBases** out) {
       set_error("capgpu: Lagrange-form commit key requested inside a stream capture");
       return CAPGPU_ERR_INVALID_ARG;
     }
+    if (const char* t = getenv("CAPGPU_TEST_FAIL_LAGRANGE"); t && atoi(t)) {  // test hook: as if the device were full
+      e->lagrange_failed.insert(log_n);
+      set_error("capgpu: Lagrange-form commit key: out of device memory (CAPGPU_TEST_FAIL_LAGRANGE)");
+      return CAPGPU_ERR_OOM;
+    }
     std::unique_ptr<MsmBases> L(new MsmBases);
     rc = lagrange_build(*B, log_n, L.get(), c.stream);
-    if (rc) return hip_fail((hipError_t)rc, "lagrange_build");
+    if (rc) {
+      e->lagrange_failed.insert(log_n);
+      msm_free_bases(L.get());
+      return hip_fail((hipError_t)rc, "lagrange_build");
+    }
     if ((rc = take_launch_error())) {
+      e->lagrange_failed.insert(log_n);
       msm_free_bases(L.get());
       return rc;
     }

@@ -18,6 +18,7 @@
 #include <map>
 #include <memory>
 #include <mutex>
+#include <set>
 #include <string>
 #include <thread>
 #include <vector>
@@ -56,6 +57,7 @@ struct SrsEntry {
   // uses; built on first use (find_lagrange), shared by the contexts of this device, never serialized
   std::mutex lag_mu;
   std::map<uint32_t, std::unique_ptr<MsmBases>> lagrange;  // log_n -> table of 2^log_n + 2 points
+  std::set<uint32_t> lagrange_failed;  // domains whose table could not be built (no memory): not retried per proof
   SrsEntry() = default;
   SrsEntry(const SrsEntry&) = delete;
   SrsEntry& operator=(const SrsEntry&) = delete;

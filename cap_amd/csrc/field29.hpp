@@ -45,9 +45,9 @@ struct FqP29 {
   // 4p, same inflation
   static constexpr uint32_t SUB4P[9] = {0x21f3f51cu, 0x241182dau, 0x31ca8d3bu, 0x2b548b42u, 0x361765dfu,
                                         0x2b6d0301u, 0x229b8503u, 0x397098cfu, 0x00c19138u};
-  // 8p with limbs 0..7 inflated into [2^30, 2^31)
-  static constexpr uint32_t SUB8P[9] = {0x43e7ea38u, 0x482305b4u, 0x43951a76u, 0x56a91685u, 0x4c2ecbbeu,
-                                        0x56da0603u, 0x45370a06u, 0x52e1319eu, 0x01832271u};
+  // 8p with limbs 0..7 inflated into [2^29, 2^30)
+  static constexpr uint32_t SUB8P[9] = {0x23e7ea38u, 0x282305b5u, 0x23951a77u, 0x36a91686u, 0x2c2ecbbfu,
+                                        0x36da0604u, 0x25370a07u, 0x32e1319fu, 0x01832272u};
   // constant-multiplicand product (mul_shoup): 2^261 - p, and -p^-1 mod 2^261
   static constexpr uint32_t NEGP[9] = {0x078302b9u, 0x1efb9f49u, 0x038d5cb0u, 0x1d2add2fu, 0x0a7a2687u,
                                        0x1d24bf3fu, 0x1f591ebeu, 0x11a3d9cbu, 0x1fcf9bb1u};
@@ -73,8 +73,8 @@ struct FrP29 {
                                         0x25b68180u, 0x214dc281u, 0x3cb84c67u, 0x0060c89bu};
   static constexpr uint32_t SUB4P[9] = {0x20000004u, 0x3c3eb27du, 0x39709142u, 0x3f4243ccu, 0x36174a0bu,
                                         0x2b6d0301u, 0x229b8503u, 0x397098cfu, 0x00c19138u};
-  static constexpr uint32_t SUB8P[9] = {0x40000008u, 0x587d64fau, 0x52e12285u, 0x5e848799u, 0x4c2e9417u,
-                                        0x56da0603u, 0x45370a06u, 0x52e1319eu, 0x01832271u};
+  static constexpr uint32_t SUB8P[9] = {0x20000008u, 0x387d64fbu, 0x32e12286u, 0x3e84879au, 0x2c2e9418u,
+                                        0x36da0604u, 0x25370a07u, 0x32e1319fu, 0x01832272u};
   static constexpr uint32_t NEGP[9] = {0x0fffffffu, 0x00f05360u, 0x11a3dbafu, 0x182f6f0cu, 0x0a7a2d7cu,
                                        0x1d24bf3fu, 0x1f591ebeu, 0x11a3d9cbu, 0x1fcf9bb1u};
   static constexpr uint32_t NPINV[9] = {0x0fffffffu, 0x170fac9fu, 0x1a446cf0u, 0x0d0c9698u, 0x02391658u,
@@ -327,10 +327,19 @@ struct Fl {
   static CAP_HD bool eq(const fl& a, const fl& b) { return is_zero(sub(a, weak_reduce(b))); }
 
   // ---- Montgomery multiplication: a * b * 2^-261 mod p (lazy) --------------------------------------
+  // The Montgomery digit m = c * (-p^-1) mod 2^29.  BN254's scalar field has r = 1 (mod 2^28), so -r^-1 = 2^28 - 1
+  // (mod 2^29) and the digit is a shift and a subtraction (CAP_FR_DIGIT_SHIFT: +4 .. 6 % on the row-wise product at four
+  // workgroups per CU, nothing at two - tools/ubench_shoup29.hip; the base field has no such luck).
+  CAP_WRAPS static CAP_HD uint32_t mont_digit(uint32_t c) {
+#ifdef CAP_FR_DIGIT_SHIFT
+    if constexpr (PR::NINV == 0x0fffffffu) return ((c << 28) - c) & M29;
+#endif
+    return mul_lo32(c, PR::NINV) & M29;
+  }
   static CAP_HD fl reduce_cols(uint64_t c[18]) {
 #pragma unroll
     for (int k = 0; k < 9; k++) {
-      uint32_t m = mul_lo32((uint32_t)c[k], PR::NINV) & M29;
+      uint32_t m = mont_digit((uint32_t)c[k]);
 #pragma unroll
       for (int j = 0; j < 9; j++) c[k + j] += (uint64_t)m * PR::MOD[j];
       c[k + 1] += c[k] >> 29;
@@ -474,7 +483,12 @@ struct Fl {
   // 143 multiply-adds and no serial digit chain against the 171 of the Montgomery product.
   // Bounds: limbs(a) < 2^30 (a normalized value or one lazy sum of two), w and wq normalized.  With Q = floor(a w / p):
   // Q - q <= a / 2^261 + 2, so the normalized result is < 4p for a < 2^261 and < 5p for a lazy sum of two (< 2^262).
+  // Two schedules, like the Montgomery product: SCHED 1 one running accumulator (the carry is the next column's addend;
+  // 0.38 - 0.5 of the Montgomery product's rate in the NTT's setting: one serial chain of 143 multiply-adds), SCHED 0
+  // independent 64-bit column accumulators whose carries walk up afterwards (1.11 - 1.15 of it at four workgroups per
+  // CU, 1.04 at two: tools/ubench_shoup29.hip, profiles/ubench_shoup29_r06.txt).
   static CAP_HD fl mul_shoup(const fl& a, const fl& w, const fl& wq) {
+    if constexpr (SCHED == 0) return mul_shoup_row(a, w, wq);
     uint32_t q[9];
     uint64_t acc = 0;
 #pragma unroll
@@ -508,6 +522,40 @@ struct Fl {
     }
     return r;  // (what is left in acc are bits 261.. of a w + q (2^261 - p): multiples of 2^261, dropped)
   }
+  static CAP_HD fl mul_shoup_row(const fl& a, const fl& w, const fl& wq) {
+    uint64_t c[10];  // columns 7 .. 16 of a * wq
+#pragma unroll
+    for (int k = 0; k < 10; k++) c[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+      for (int j = 0; j < 9; j++)
+        if (i + j >= 7) c[i + j - 7] += (uint64_t)a.v[i] * wq.v[j];
+    uint32_t q[9];
+    c[1] += c[0] >> 29;
+    c[2] += c[1] >> 29;
+#pragma unroll
+    for (int k = 2; k < 10; k++) {
+      q[k - 2] = (uint32_t)c[k] & M29;
+      if (k < 9) c[k + 1] += c[k] >> 29;
+    }
+    CAP_FL_ASSERT((c[9] >> 29) < (1ull << 31));
+    q[8] = (uint32_t)(c[9] >> 29);
+    uint64_t d[9];  // columns 0 .. 8 of a * w + q * (2^261 - p)
+#pragma unroll
+    for (int k = 0; k < 9; k++) d[k] = 0;
+#pragma unroll
+    for (int i = 0; i < 9; i++)
+#pragma unroll
+      for (int j = 0; i + j < 9; j++) d[i + j] += (uint64_t)a.v[i] * w.v[j] + (uint64_t)q[i] * PR::NEGP[j];
+    fl r;
+#pragma unroll
+    for (int k = 0; k < 9; k++) {
+      r.v[k] = (uint32_t)d[k] & M29;
+      if (k < 8) d[k + 1] += d[k] >> 29;
+    }
+    return r;
+  }
   // wq = floor(w * 2^261 / p) from t = w * 2^261 mod p, CANONICAL (the internal Montgomery form of w): the division
   // (w 2^261 - t) / p is exact and its quotient is below 2^261, so it is (-t) * p^-1 mod 2^261 - one low-half product.
   static CAP_HD fl shoup_quotient(const fl& t_canonical) {
@@ -522,17 +570,17 @@ struct Fl {
     }
     return r;
   }
-  // a - b + 8p, normalized, for a normalized b < 7.9 p (a mul_shoup result); limbs(a) < 2^30
+  // a - b + 8p, normalized, for a normalized b < 7.99 p (a mul_shoup result); limbs(a) < 2^31
   static CAP_HD fl sub8p(const fl& a, const fl& b) {
     fl r;
 #pragma unroll
     for (int i = 0; i < 9; i++) {
-      CAP_FL_ASSERT(i == 8 ? b.v[i] <= PR::SUB8P[i] : (b.v[i] < (1u << 29) && a.v[i] < (1u << 30)));
+      CAP_FL_ASSERT(i == 8 ? b.v[i] <= PR::SUB8P[i] : (b.v[i] < (1u << 29) && a.v[i] < (1u << 31)));
       r.v[i] = a.v[i] + (PR::SUB8P[i] - b.v[i]);
     }
     return normalize(r);
   }
-  // a - b + 8p WITHOUT carrying (see sub2p_lazy): limbs(a) + 2^31 at most, for limbs(a) < 2^30
+  // a - b + 8p WITHOUT carrying (see sub2p_lazy): limbs(a) + 2^30 at most, for limbs(a) < 2^30
   static CAP_HD fl sub8p_lazy(const fl& a, const fl& b) {
     fl r;
 #pragma unroll

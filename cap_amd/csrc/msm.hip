@@ -1821,7 +1821,7 @@ uint32_t quad_max_batch() {
 uint32_t quad_max_batch_wide() {
   static const uint32_t v = [] {
     const char* e = getenv("CAPGPU_MSM_QUAD_MAX_WIDE");
-    const int x = e ? atoi(e) : 130;  // (measured: tools/gpujob_quadwide2.sh)
+    const int x = e ? atoi(e) : 130;  // (measured: round-4 same-box A/B `quadwide2`, profiles/LOG.md)
     return (uint32_t)(x < 0 ? 0 : x);
   }();
   return v;
@@ -1885,7 +1885,7 @@ uint32_t small_max_batch() {
 // Smallest launch, in (sub-)MSMs, that takes the wide table (CAPGPU_MSM_WIDE_MIN).  32 until round 4, when a launch of
 // 32 .. 63 MSMs reduced its 16384 buckets through bit planes (0.9 ms for 40 MSMs); with the grid form (0.65 ms) and one
 // combine thread per single-item bucket the wide table pays from about two dozen MSMs: one-context rates at batch 6 (30
-// MSMs per wire launch) 573 -> 627 proofs/s, batch 4 (20) 521 / 515, batch 2 (10) 358 -> 315 (tools/gpujob_widemin.sh).
+// MSMs per wire launch) 573 -> 627 proofs/s, batch 4 (20) 521 / 515, batch 2 (10) 358 -> 315 (round-4 same-box A/B `widemin`, profiles/LOG.md).
 uint32_t wide_min_batch() {
   static const uint32_t v = [] {
     const char* e = getenv("CAPGPU_MSM_WIDE_MIN");
@@ -1936,13 +1936,13 @@ struct Plan {
 // Scalars are < 2^254 (canonical; msm_digits_local folds larger inputs by r first), so the top window of the deep table
 // holds top_bits = 254 - c (W - 1) of its c bits and its digit is at most 2^top_bits (with the carry from below).
 // Shifted left by (c - 1) - top_bits it still fits the 2^(c-1) buckets and lands on every 2^shift-th of them.
-// First measured in round 4 at 2^24 points (tools/gpujob_deepshift.sh, profiles/deepshift_r04.jsonl): the shift does what
+// First measured in round 4 at 2^24 points (round-4 same-box A/B `deepshift`, profiles/LOG.md, profiles/deepshift_r04.jsonl): the shift does what
 // it was meant to - msm_deep_sort<1> 2.21 -> 1.08 ms at c = 22, the crowded bins gone - and c = 22 does shorten the
 // accumulation (12 digits instead of 13), but the 4096 buckets that hold the top window's n / 4096 entries each are now one
 // in every 512 instead of 4096 in a row, and msm_combine - one thread per bucket, serial over the bucket's ~66 work items -
 // ran one long lane per wave: 0.2 -> 5.7 ms.  With those buckets on a list of their own, 32 lanes each (msm_combine_heavy:
 // 0.05 ms), c = 22 with the shift is the default from 2^23 points on: 2^24 points 18.17 -> 17.25 ms, 2^23 9.75 -> 9.43 ms,
-// 2^22 5.34 -> 5.29 ms (tools/gpujob_deepwide.sh; the 2^21 buckets cost +0.5 ms in sorts and reductions).  c = 20 with the
+// 2^22 5.34 -> 5.29 ms (round-4 same-box A/B `deepwide`, profiles/LOG.md; the 2^21 buckets cost +0.5 ms in sorts and reductions).  c = 20 with the
 // shift: 18.87 against 18.33 ms - the shift is for the 22-bit windows only.
 bool deep_wide_default() {  // CAPGPU_MSM_DEEP_WIDE=0: c = 20, unshifted, for every table (the plan until the end of round 4)
   static const bool on = [] {
@@ -2073,11 +2073,11 @@ uint32_t reduce_seg_len(uint32_t half) {
 // threads at a time; a launch of 1280 MSMs with 256 segments each is 2.5 such "rounds".  Choosing the segment length that
 // minimises rounds * 2 * seg_len plus the one-wave finish (1280 MSMs: 82 buckets, 200 segments; 256 MSMs: 32) was
 // measured and is no gain: msm_reduce_segments 9.33 -> 9.45 ms per step, msm_reduce_final 1.50 -> 1.65 ms
-// (tools/gpujob_segtune.sh) - the chip does not run this kernel in lock-step rounds.
+// (round-4 same-box A/B `segtune`, profiles/LOG.md) - the chip does not run this kernel in lock-step rounds.
 constexpr uint32_t kSegLenMin = 32, kSegLenMax = 128;
 uint32_t reduce_seg_len_for(uint32_t half, uint32_t sb) {
   // CAPGPU_MSM_SEG_TUNE: 1 = every launch, 0 = none; default: launches of up to 512 MSMs, whose segments all fit the chip at
-  // once - there the shorter chains do pay (batch 64, 320-MSM launches: 52.1 -> 50.9 ms, tools/gpujob_segtune2.sh; batches of
+  // once - there the shorter chains do pay (batch 64, 320-MSM launches: 52.1 -> 50.9 ms, round-4 same-box A/B `segtune2`, profiles/LOG.md; batches of
   // 27 - 51: no difference either way)
   static const int tune = [] {
     const char* e = getenv("CAPGPU_MSM_SEG_TUNE");
@@ -2391,7 +2391,7 @@ size_t accumulate_lds_bytes() {
 // 0 = a fixed stride).  The one-shot launch of a batch is ~12 000 workgroups of equal duration - their items are
 // length-sorted - so the three workgroups a CU holds start together, end together, and the CU idles while the next
 // three are dispatched: SQ_BUSY_CU_CYCLES said a CU was busy 0.95 of the launch (round 3: "not occupancy, not the tail").
-// Measured, same box, batch 256 (tools/gpujob_accpersist.sh): one-shot 114.2 ms per step; persistent + counter, k = 3 / 4 /
+// Measured, same box, batch 256 (round-4 same-box A/B `accpersist`, profiles/LOG.md): one-shot 114.2 ms per step; persistent + counter, k = 3 / 4 /
 // 6: 109.7 / 109.3 / 109.3 ms (-4.3 %, 1303 -> 1346 proofs/s on one context); persistent with a FIXED stride: 149.7 ms -
 // without the counter a workgroup cannot make up for a slower CU, and a stride of whole MSMs (64 chunks each) would
 // even hand it the same position of every MSM's length-sorted list (183 ms).

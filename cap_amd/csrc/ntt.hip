@@ -24,7 +24,7 @@ namespace cap {
 namespace {
 
 constexpr int kThreads = 256;
-// Elements per thread whose global loads are issued together.  Measured in round 4 (tools/gpujob_ntt_io.sh, same box,
+// Elements per thread whose global loads are issued together.  Measured in round 4 (round-4 same-box A/B `ntt_io`, profiles/LOG.md, same box,
 // col + row pass per step): 1 (the old element-by-element loop) 37.2-37.6 ms, 2: 36.7 ms, 4: 38.1-38.4 ms (135 VGPRs: three
 // waves per SIMD instead of four; held to 128 VGPRs with 52 B of scratch: 37.9 ms).  The passes are not waiting for
 // memory - they are issue-bound butterflies with a barrier per radix-4 round - so 2 stays, for what it is worth.
@@ -133,6 +133,28 @@ __device__ __forceinline__ uint32_t fl_any(const fl& a) {
   for (int k = 0; k < 9; k++) o |= a.v[k];
   return o;
 }
+// Round 6 (round-5 VERDICT item 4): the butterflies' twiddle products are constant-multiplicand products (Fl::mul_shoup,
+// independent column accumulators: 143 multiply-adds and no serial digit chain against the Montgomery product's 171).
+// tw_small holds PAIRS - entry i at [2i] the plain canonical twiddle, at [2i + 1] its quotient floor(w 2^261 / p) - and a
+// product is below 5p instead of 1.2p: the subtractions add 8p instead of 2p, values grow by at most 13p per radix-4
+// round (5 rounds + the inputs stay far below the 169p the limbs hold).  Everything outside the radix-4 rounds - coset
+// pre-scale, inter-pass twiddle, post-scale: factors from 32-byte tables - stays a Montgomery product.  Measured on one
+// box (profiles/ntt_shoup_ab_r06.txt): 768 x 2^16 coset transforms 4.17 -> 4.03 ms, column + row pass per headline step
+// 35.7 -> 34.3 ms, 1373 -> 1387 proofs/s; the microbenchmark behind the decision: profiles/ubench_shoup29_r06.txt.
+// -DCAP_NTT_NO_SHOUP builds the Montgomery rounds of rounds 1-5.
+#ifndef CAP_NTT_NO_SHOUP
+constexpr int kTwStride = 2;
+#define NTT_TW_MUL(x, idx) Fr29::mul_shoup((x), tw_small[2 * (idx)], tw_small[2 * (idx) + 1])
+#define NTT_SUB(u, t) Fr29::sub8p((u), (t))
+#define NTT_SUB_LAZY(u, t) Fr29::sub8p_lazy((u), (t))
+#define NTT_SUB_FROM_LAZY(u, t) Fr29::sub8p((u), (t))
+#else
+constexpr int kTwStride = 1;
+#define NTT_TW_MUL(x, idx) Fr29::mul((x), tw_small[(idx)])
+#define NTT_SUB(u, t) Fr29::sub2p((u), (t))
+#define NTT_SUB_LAZY(u, t) Fr29::sub2p_lazy((u), (t))
+#define NTT_SUB_FROM_LAZY(u, t) Fr29::sub2p((u), (t))
+#endif
 __device__ __forceinline__ void lds_ntt(fl* sh, const fl* __restrict__ tw_small, uint32_t log_len, uint32_t log_c) {
   const uint32_t half_tile = 1u << (log_len + log_c - 1);
   const uint32_t cmask = (1u << log_c) - 1;
@@ -154,59 +176,6 @@ __device__ __forceinline__ void lds_ntt(fl* sh, const fl* __restrict__ tw_small,
     __syncthreads();
   }
   const uint32_t quarter_tile = half_tile >> 1;
-#ifdef CAP_NTT_EXPERIMENT_NO_LDS_ROUNDS
-  // TIMING EXPERIMENT ONLY (wrong results): the radix-4 rounds chained in registers - the same multiplications, twiddle
-  // loads and additions as the real rounds, but no LDS traffic and no barrier between them: what a register-resident
-  // radix-16 / radix-256 round could save at most (round 5, tools/gpujob_r05_nttexp.sh)
-  for (uint32_t g = threadIdx.x; g < quarter_tile; g += kThreads) {
-    const uint32_t c = g & cmask, gg = g >> log_c;
-    uint32_t i0 = (((gg >> s0) << (s0 + 2)) << log_c) + c, st = (1u << s0) << log_c;
-    fl a = sh[i0], b = sh[i0 + st], cc = sh[i0 + 2 * st], d = sh[i0 + 3 * st];
-    for (uint32_t s = s0; s + 1 < log_len; s += 2) {
-      const uint32_t h = 1u << s, pos = gg & (h - 1);
-      fl a1, b1, c1, d1, t;
-      if (s == 0) {  // (the trivial first round, as in the shipped code: one multiplication for the four elements)
-        if (fl_any(b)) {
-          t = Fr29::weak_reduce(b);
-          a1 = Fr29::add(a, t);
-          b1 = Fr29::sub2p_lazy(a, t);
-        } else {
-          a1 = a;
-          b1 = a;
-        }
-        if (fl_any(d)) {
-          t = Fr29::weak_reduce(d);
-          c1 = Fr29::normalize(Fr29::add(cc, t));
-          d1 = Fr29::sub2p(cc, t);
-        } else {
-          c1 = cc;
-          d1 = cc;
-        }
-        t = Fr29::weak_reduce(c1);
-      } else {
-        const fl w1 = tw_small[pos << (log_len - 1 - s)];
-        t = Fr29::mul(b, w1);
-        a1 = Fr29::add(a, t);
-        b1 = Fr29::sub2p_lazy(a, t);
-        t = Fr29::mul(d, w1);
-        c1 = Fr29::add(cc, t);
-        d1 = Fr29::sub2p(cc, t);
-        t = Fr29::mul(c1, tw_small[pos << (log_len - 2 - s)]);
-      }
-      a = Fr29::normalize(Fr29::add(a1, t));
-      cc = Fr29::sub2p(a1, t);
-      t = Fr29::mul(d1, tw_small[(pos + h) << (log_len - 2 - s)]);
-      b = Fr29::normalize(Fr29::add(b1, t));
-      d = Fr29::sub2p(b1, t);
-    }
-    sh[i0] = a;
-    sh[i0 + st] = b;
-    sh[i0 + 2 * st] = cc;
-    sh[i0 + 3 * st] = d;
-  }
-  __syncthreads();
-  return;
-#endif
   for (uint32_t s = s0; s + 1 < log_len; s += 2) {
     const uint32_t h = 1u << s;
     const uint32_t step = h << log_c;
@@ -240,20 +209,20 @@ __device__ __forceinline__ void lds_ntt(fl* sh, const fl* __restrict__ tw_small,
         }
         t = Fr29::weak_reduce(c1);  // second-level twiddle of the (a1, c1) pair: omega^0 = 1
       } else {
-        const fl w1 = tw_small[pos << (log_len - 1 - s)];
-        t = Fr29::mul(b, w1);
+        const uint32_t i_w1 = pos << (log_len - 1 - s);
+        t = NTT_TW_MUL(b, i_w1);
         a1 = Fr29::add(a, t);
-        b1 = Fr29::sub2p_lazy(a, t);
-        t = Fr29::mul(d, w1);
+        b1 = NTT_SUB_LAZY(a, t);
+        t = NTT_TW_MUL(d, i_w1);
         c1 = Fr29::add(cc, t);
-        d1 = Fr29::sub2p(cc, t);
-        t = Fr29::mul(c1, tw_small[pos << (log_len - 2 - s)]);
+        d1 = NTT_SUB(cc, t);
+        t = NTT_TW_MUL(c1, pos << (log_len - 2 - s));
       }
       sh[i0] = Fr29::normalize(Fr29::add(a1, t));
-      sh[i2] = Fr29::sub2p(a1, t);
-      t = Fr29::mul(d1, tw_small[(pos + h) << (log_len - 2 - s)]);
+      sh[i2] = NTT_SUB(a1, t);
+      t = NTT_TW_MUL(d1, (pos + h) << (log_len - 2 - s));
       sh[i1] = Fr29::normalize(Fr29::add(b1, t));
-      sh[i3] = Fr29::sub2p(b1, t);
+      sh[i3] = NTT_SUB_FROM_LAZY(b1, t);
     }
     __syncthreads();
   }
@@ -435,9 +404,18 @@ __global__ __launch_bounds__(kThreads) CAP_NTT_ATTR void ntt_row_pass(PassParams
   }
 }
 
+// tw_small: the internal-form table `in` (x * 2^261, canonical) as the limbs the butterflies multiply by - kTwStride = 1:
+// the same values unpacked; kTwStride = 2 (CAP_NTT_SHOUP): pairs (plain canonical x, floor(x 2^261 / p))
 __global__ void table_unpack(fl* __restrict__ out, const fe* __restrict__ in, size_t n) {
   size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (e < n) out[e] = Fr29::load(in[e]);
+  if (e >= n) return;
+  if constexpr (kTwStride == 1) {
+    out[e] = Fr29::load(in[e]);
+  } else {
+    const fl t = Fr29::load(in[e]);
+    out[2 * e] = Fr29::load(Fr29::from_mont(t));
+    out[2 * e + 1] = Fr29::shoup_quotient(t);
+  }
 }
 
 // internal-form table: out[e] = pack(canonical(in_ext[e] * 2^5))  (x * 2^256 -> x * 2^261)
@@ -559,7 +537,7 @@ int ntt_build_small_tables(NttSmallTables* t, hipStream_t stream) {
            (const fe*)t->inv[s], n);
     for (int d = 0; d < 2; d++) {
       uint32_t** dst = d ? &t->inv_u[s] : &t->fwd_u[s];
-      e = hipMalloc(dst, sizeof(fl) * n);
+      e = hipMalloc(dst, sizeof(fl) * n * kTwStride);
       if (e != hipSuccess) return (int)e;
       launch("table_unpack", table_unpack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream,
              reinterpret_cast<fl*>(*dst), (const fe*)(d ? t->inv[s] : t->fwd[s]), n);

@@ -93,10 +93,13 @@ struct ProveGraphSig {
   const void *d_wires = nullptr, *ws = nullptr, *msm_ws = nullptr, *ntt_scratch = nullptr, *bases = nullptr;
   const void* lagrange = nullptr;  // the Lagrange-form commit key round 1 commits on (null: from coefficients)
   hipStream_t stream = nullptr;
+  // rounds 1-2 with the side stream (segments 1 and 3 are then empty: their transforms were captured inside segments 0
+  // and 7): a set captured one way must never be replayed the other way - round 3 would read stale coset evaluations
+  bool overlap = false;
   bool operator==(const ProveGraphSig& o) const {
     return key_uid == o.key_uid && srs == o.srs && P == o.P && num_inputs == o.num_inputs && form == o.form &&
            multi == o.multi && d_wires == o.d_wires && ws == o.ws && msm_ws == o.msm_ws && ntt_scratch == o.ntt_scratch &&
-           bases == o.bases && lagrange == o.lagrange && stream == o.stream;
+           bases == o.bases && lagrange == o.lagrange && stream == o.stream && overlap == o.overlap;
   }
 };
 struct ProveGraphSet {
@@ -581,8 +584,16 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   if (rc) return rc;
   // the Lagrange-form commit key (built on the first proof of this domain size under this SRS if preprocess did not);
   // sharded commitment MSMs (mode A of config 4) cut the monomial key by point range: they keep the coefficient form
+  // The Lagrange-form key is an OPTIMISATION (the same commitments come from the coefficients): when it cannot be had -
+  // its table is as large as the SRS's window table and is built on first use with temporaries of its own - the proof is
+  // made the coefficient way instead of failing.  Only a bad handle is an error of the call.
   const MsmBases* Lag = nullptr;
-  if (wire_commit_from_evals() && !comm_shard_prover() && (rc = find_lagrange(K.srs_handle, K.log_n, &Lag))) return rc;
+  if (wire_commit_from_evals() && !comm_shard_prover() && (rc = find_lagrange(K.srs_handle, K.log_n, &Lag))) {
+    if (rc == CAPGPU_ERR_BAD_HANDLE) return rc;
+    Lag = nullptr;
+    (void)hipGetLastError();
+    trace("pb_lagrange_fallback", c.slot, rc);
+  }
   // workspace
   const bool coeffs = form == CAPGPU_INPUT_COEFFS;
   if ((rc = scratch_reserve(c.prove_ws, carve(nullptr, K, P, num_inputs, coeffs).total))) return rc;
@@ -593,6 +604,19 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   if ((rc = get_domain3(K.log_m, &dom_q))) return rc;
   // small batches replay their kernel segments as hipGraphs (see ProveGraphSet)
   const uint32_t chunks = h_wires ? h2d_chunks(P) : 1;
+  // small batches run rounds 1-2 on two streams (r1_overlap_max); decided here, once, because it shapes the captured graphs
+  hipStream_t s2 = nullptr;
+  const bool overlap = chunks == 1 && P <= r1_overlap_max() && !c.prof.on && !comm_shard_prover() && s == c.own_stream &&
+                       (s2 = side_stream(c)) != nullptr;
+  // no exit path - an error between a fork and its join in particular - may leave the side stream running kernels on this
+  // context's workspace: the next call (or a scratch growth) would pull it from under them
+  struct SideDrain {
+    Context& c;
+    bool armed;
+    ~SideDrain() {
+      if (armed && c.side_stream) (void)hipStreamSynchronize(c.side_stream);
+    }
+  } side_drain{c, overlap};
   ProveGraphSet* gs = nullptr;
   // (only on the library's own stream: a caller's stream - capgpu_set_stream - may carry work of its own)
   if (P <= graph_max_batch() && chunks == 1 && !c.prof.on && comm_shard_slot() < 0 && s == c.own_stream) {
@@ -610,6 +634,7 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
     sig.bases = B->ext;
     sig.lagrange = Lag ? Lag->ext : nullptr;
     sig.stream = s;
+    sig.overlap = overlap;
     gs = graph_set_for(c, sig);
   }
   auto seg = [&](int id, const std::function<int()>& enqueue) -> int { return run_segment(c, gs, id, enqueue); };
@@ -786,9 +811,6 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
     if (chunks > 1 && c.copy_stream) CAP_HIP(hipStreamSynchronize(c.copy_stream));
     turn->pass(turn_idx);
   }
-  hipStream_t s2 = nullptr;
-  const bool overlap = chunks == 1 && P <= r1_overlap_max() && !c.prof.on && !comm_shard_prover() && s == c.own_stream &&
-                       (s2 = side_stream(c)) != nullptr;
   // round 3's coset evaluations of the wire and public-input polynomials (on the 6n quotient domain, straight from
   // their coefficient arrays: the transform zero-extends them) depend on nothing the transcript still has to produce
   auto r3_wire_cosets = [&](hipStream_t st) -> int {
@@ -1146,6 +1168,7 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
     affine_to_words(ha[p * 2], proofs[p].opening_proof);
     affine_to_words(ha[p * 2 + 1], proofs[p].shifted_opening_proof);
   }
+  side_drain.armed = false;  // (every join was waited for in stream order and the stream has drained)
   return take_launch_error();
 }
 
@@ -1494,7 +1517,9 @@ int capgpu_plonk_preprocess_ex(uint64_t srs_handle, size_t n, size_t num_inputs,
   // with the SRS): made here so that the first proof does not pay for it
   if (wire_commit_from_evals() && !comm_shard_prover()) {
     const MsmBases* Lag = nullptr;
-    if ((rc = find_lagrange(srs_handle, K->log_n, &Lag))) return rc;
+    // (an optimisation: a key whose Lagrange-form table cannot be built proves from coefficients - see prove_batch)
+    if ((rc = find_lagrange(srs_handle, K->log_n, &Lag)) == CAPGPU_ERR_BAD_HANDLE) return rc;
+    (void)hipGetLastError();
   }
   *pk_handle_out = register_key(K);
   return take_launch_error();

@@ -361,7 +361,24 @@ int capgpu_plonk_set_coalescing(uint32_t window_us, uint32_t max_batch);
  * witness values of a CAP circuit are mostly zeros, booleans and range-check limbs (src/circuit/transfer.rs:53-193): as
  * MSM scalars they have at most one non-zero digit where a coefficient has seventeen.  Proof bytes are identical.
  * mode: 1 = from evaluations (the default), 0 = from coefficients, -1 = back to the default (CAPGPU_WIRE_COMMIT=coeffs
- * makes 0 the process default).  Process-wide; takes effect with the next prove call. */
+ * makes 0 the process default).  Process-wide; takes effect with the next prove call.
+ * When the Lagrange-form key cannot be built (device memory) the call commits from coefficients instead of failing.
+ *
+ * TIMING AND THE SECRET WITNESS - what this library does and does not promise.  Like the arkworks prover it replaces
+ * (ark-ec's multi_scalar_mul skips zero scalars and treats ones apart; its field inversions are variable-time) this
+ * library is NOT hardened against timing side channels: kernel durations and memory traffic may depend on secret data,
+ * and an observer who can time proofs precisely must be kept away by the deployment, not by this code.  What depends on
+ * what:
+ *  - mode 1 (default): the wire MSMs' scalars are the secret witness values themselves; the bucket sort skips zero digits,
+ *    so round 1's duration grows with the number of non-zero 15-bit digits of the witness (zeros, booleans and small
+ *    limbs are cheap: the same property the speed-up comes from).  It reveals an aggregate of the witness's sparsity per
+ *    proof (per batch, in a batch), not individual values.
+ *  - mode 0 (CAPGPU_WIRE_COMMIT=coeffs): the scalars are the blinded polynomials' coefficients - full-width values
+ *    whatever the witness holds; round 1's work is then independent of the witness to the degree jf-plonk's own is.  This
+ *    is the mode to choose where proof timing is observable by an adversary.
+ *  - the permutation product's commitment (either mode) and everything from round 3 on work on challenge-randomised,
+ *    full-width data; round 2's one shared inversion runs a fixed-length chain in both modes (it costs nothing).
+ * Power, electromagnetic and co-tenant cache channels on a shared GPU are out of scope in both modes. */
 int capgpu_plonk_set_wire_commit(int mode);
 /* device batches run and proofs made through the coalescer so far */
 int capgpu_plonk_coalescing_stats(uint64_t* batches_out, uint64_t* proofs_out);

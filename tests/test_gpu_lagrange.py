@@ -135,3 +135,35 @@ def test_lagrange_key_against_the_closed_form(cg, tau, log_n):
         got = cr.g1_to_affine(cg.lagrange_commit(h, log_n, e))
         assert cr.affine_to_ints(got) == cr.affine_to_ints(pts[j]), j
     cg.srs_free(h)
+
+
+def test_a_lagrange_key_that_cannot_be_built_falls_back_to_coefficients(cg, tau):
+    """the Lagrange-form key is an optimisation; when its table cannot be built (device full) neither
+    preprocess nor prove may fail - they commit from coefficients, the same bytes.  CAPGPU_TEST_FAIL_LAGRANGE makes the
+    build fail as an out-of-memory would; the failure is remembered per (SRS, domain), so a fresh SRS is used."""
+    import os
+    sc = bu.synthetic_circuit(9, 4, seed=77)
+    n = sc.n
+    ws, ps = sc.witnesses_mont([11, 12, 13])
+    bls = np.stack([bu.to_mont_array(bu.blinders(40 + p)) for p in range(3)])
+    h_ok = cg.srs_generate(tau, n + 3)
+    pk_ok, _ = cg.plonk_preprocess(h_ok, n, 4, sc.selectors_mont(), sc.sigma_mont())
+    cg.plonk_set_wire_commit_from_evals(True)
+    want = [bytes(p) for p in cg.plonk_prove_batch(pk_ok, ws, ps, bls, b"fb", 3)]
+    os.environ["CAPGPU_TEST_FAIL_LAGRANGE"] = "1"
+    try:
+        h = cg.srs_generate(tau, n + 3)
+        pk, _ = cg.plonk_preprocess(h, n, 4, sc.selectors_mont(), sc.sigma_mont())     # does not fail
+        got = [bytes(p) for p in cg.plonk_prove_batch(pk, ws, ps, bls, b"fb", 3)]       # nor does this
+    finally:
+        del os.environ["CAPGPU_TEST_FAIL_LAGRANGE"]
+    assert got == want
+    # the failure is remembered: no rebuild attempt per proof, still the same proofs; a direct commitment on the key says why
+    assert [bytes(p) for p in cg.plonk_prove_batch(pk, ws, ps, bls, b"fb", 3)] == want
+    with pytest.raises(cg.CapGpuError) as e:
+        cg.lagrange_commit(h, 9, ws[0][0])
+    assert e.value.code == -5
+    for k in (pk, pk_ok):
+        cg.plonk_free_key(k)
+    for s in (h, h_ok):
+        cg.srs_free(s)

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Device time of batches of NTTs (HIP events, median of 30): tools/gpu_ntt_time.py TAG - one JSON line.  For A/B runs of
-library builds (CAPGPU_LIBRARY) on one box: tools/gpujob_r05_nttexp.sh."""
+library builds (CAPGPU_LIBRARY) on one box: tools/gpujob.sh ntt."""
 import json
 import os
 import sys

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""One proof at a time, N times (for kernel traces of a single proof: tools/gpujob_r05_trace1.sh)."""
+"""One proof at a time, N times (for kernel traces of a single proof: rocprofv3 --kernel-trace -- python3 tools/gpu_prove1.py)."""
 import os
 import sys
 import time

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Small-launch latencies on one GPU, one JSON line: single MSMs of 2^15 / 2^17 points (device time, HIP events) and proof
 batches of 1 .. 16 (host wall time per call).  For same-box A/B runs of the knobs that are read once per process
-(CAPGPU_MSM_CHAINED, CAPGPU_R1_OVERLAP_MAX, CAPGPU_WIRE_COMMIT, CAPGPU_LIBRARY ...): tools/gpujob_r05_small.sh."""
+(CAPGPU_MSM_CHAINED, CAPGPU_R1_OVERLAP_MAX, CAPGPU_WIRE_COMMIT, CAPGPU_LIBRARY ...): tools/gpujob.sh env."""
 import json
 import os
 import sys

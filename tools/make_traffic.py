@@ -1,4 +1,4 @@
-"""profiles/traffic_rNN.json from a tools/gpuprof.sh output directory:
+"""profiles/traffic_rNN.json from a tools/gpujob.sh prof output directory:
     python tools/make_traffic.py gpurun_out/prof_X BATCH [profiles/traffic_r02.json]"""
 import csv
 import glob

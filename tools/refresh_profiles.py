@@ -1,4 +1,4 @@
-"""Copy the outputs of tools/gpujob_final.sh TAG (gpurun_out/final_TAG, gpurun_out/prof_TAG) into profiles/ under the
+"""Copy the outputs of tools/gpujob.sh final TAG (gpurun_out/final_TAG, gpurun_out/prof_TAG) into profiles/ under the
 round's names.  Run here after the gpurun call:  python tools/refresh_profiles.py TAG [ROUND]"""
 import ast
 import glob
@@ -39,7 +39,7 @@ shutil.copy(os.path.join(prof, "summary.txt"), os.path.join(dst, "rocprof_" + rn
 stats = glob.glob(os.path.join(prof, "trace", "**", "*kernel_stats.csv"), recursive=True)
 shutil.copy(stats[0], os.path.join(dst, "rocprof_" + rnd, "kernel_stats.csv"))
 
-# clock / busy-CU pass (tools/gpuprof_clock.sh): counter per nanosecond of the same dispatch -> clock and busy share.
+# clock / busy-CU pass (tools/gpujob.sh clock): counter per nanosecond of the same dispatch -> clock and busy share.
 # "PAIR" (round 4): GRBM_GUI_ACTIVE and SQ_BUSY_CU_CYCLES collected in ONE pass, so that the busy share is a ratio of two
 # counters of the same dispatches (separate passes may run at different clocks: round 4's gave 1.04 for msm_accumulate).
 if os.path.exists(os.path.join(src, "clock.json")):
@@ -58,7 +58,7 @@ if os.path.exists(os.path.join(src, "clock.json")):
             if bc and ghz > 0:
                 e["cu_busy_frac"] = round(bc["counter_per_ns"] / 256.0 / ghz, 3)   # ... over the 256 CUs
         derived[k] = e
-    json.dump({"source": "tools/gpuprof_clock.sh: rocprofv3 --pmc <counter(s)> --kernel-trace (no other trace domain) on "
+    json.dump({"source": "tools/gpujob.sh clock: rocprofv3 --pmc <counter(s)> --kernel-trace (no other trace domain) on "
                          "bench.py --one-context --steps 1 --warmup 1 --no-msm --no-extras, batch 256; counter value / "
                          "duration of the same dispatch, launches >= 0.2 ms only; entries marked same_pass come from the "
                          "pass that collected GRBM_GUI_ACTIVE and SQ_BUSY_CU_CYCLES together",
@@ -67,7 +67,7 @@ if os.path.exists(os.path.join(src, "clock.json")):
                "derived": derived, "raw_counter_per_ns": {k: v for k, v in raw.items() if k != "PAIR"}, "pair_pass": pair},
               open(os.path.join(dst, f"clock_{rnd}.json"), "w"), indent=1)
 
-# instruction counters: tools/gpuprof_insts.sh prints  name {counter: (sum, launches), ...}  per kernel
+# instruction counters: tools/gpujob.sh insts prints  name {counter: (sum, launches), ...}  per kernel
 kern = {}
 for ln in open(os.path.join(src, "insts.txt")):
     if " {'SQ_" not in ln:
