@@ -174,6 +174,11 @@ static size_t trim_idle_contexts(int device, Context* keep, int* busy_out) {
   return released;
 }
 
+double& scratch_growth_scale() {
+  static thread_local double f = 1.0;
+  return f;
+}
+
 int scratch_reserve(Scratch& s, size_t bytes) {
   if (bytes <= s.cap) return CAPGPU_OK;
   Context& c = ctx();
@@ -188,7 +193,7 @@ int scratch_reserve(Scratch& s, size_t bytes) {
     s.p = nullptr;
     s.cap = 0;
   }
-  size_t want = bytes + bytes / 4;
+  size_t want = std::max(bytes + bytes / 4, (size_t)((double)bytes * std::min(scratch_growth_scale(), 64.0)));
   if (const size_t limit = g_scratch_limit.load()) {
     // capgpu_set_memory_limit: first without the growth slack, then with what the device's idle contexts give back
     auto over = [&](size_t w) { return g_scratch_bytes[(size_t)c.device & 63].load() + w > limit; };

@@ -202,6 +202,9 @@ int take_launch_error();                       // CAPGPU_OK, or CAPGPU_ERR_HIP n
 // what capgpu_trim releases and capgpu_set_memory_limit caps (per device); device memory held outside a Scratch that is
 // scratch by nature (plonk.hip's staging slots) is entered with scratch_account and asks scratch_room_for first.
 int scratch_reserve(Scratch& s, size_t bytes);
+// per thread: a buffer that has to grow grows to `bytes` x this factor (>= 1) instead of bytes + 25 % - set by callers whose
+// next request is likely larger by more than that (gathered batches)
+double& scratch_growth_scale();
 void scratch_account(int device, size_t add, size_t sub);
 bool scratch_room_for(int device, size_t bytes);
 size_t plonk_trim_staging();  // plonk.hip: frees the unused staging slots of coalesced callers; returns the bytes

@@ -110,6 +110,19 @@ CAP_WRAPS static CAP_HD uint32_t mul_lo32(uint32_t a, uint32_t b) {
 #endif
 }
 
+// acc + a * b as ONE 64-bit multiply-add even where only the low word of the sum is live: left to itself the compiler
+// narrows such a product to v_mul_lo_u32 + v_add, and v_mul_lo_u32 issues at a quarter of the multiply-add's rate (the
+// top column of Fl::mul_shoup: 18 of its 143 products - isa_mix counted 3.8 % v_mul_lo_u32 in the NTT passes).
+CAP_WRAPS static CAP_HD uint64_t mad_wide(uint32_t a, uint32_t b, uint64_t acc) {
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(CAP_NO_MADLO) && !defined(CAP_NO_MADWIDE)
+  uint64_t r, carry;
+  asm("v_mad_u64_u32 %0, %1, %2, %3, %4" : "=v"(r), "=s"(carry) : "v"(a), "v"(b), "v"(acc));
+  return r;
+#else
+  return acc + (uint64_t)a * b;
+#endif
+}
+
 // SCHED selects the schedule of the Montgomery multiplication (same arithmetic, same results, same bounds):
 //   0  row-wise (operand scanning): 18 independent 64-bit column accumulators, every product lands in its column,
 //      then the carries walk up with a 64-bit shift + add per column.  Best where a kernel keeps many independent
@@ -547,7 +560,14 @@ struct Fl {
 #pragma unroll
     for (int i = 0; i < 9; i++)
 #pragma unroll
-      for (int j = 0; i + j < 9; j++) d[i + j] += (uint64_t)a.v[i] * w.v[j] + (uint64_t)q[i] * PR::NEGP[j];
+      for (int j = 0; i + j < 9; j++) {
+        if (i + j < 8) {
+          d[i + j] += (uint64_t)a.v[i] * w.v[j] + (uint64_t)q[i] * PR::NEGP[j];
+        } else {  // the top column: only its low 29 bits are kept (see mad_wide)
+          d[8] = mad_wide(a.v[i], w.v[j], d[8]);
+          d[8] = mad_wide(q[i], PR::NEGP[j], d[8]);
+        }
+      }
     fl r;
 #pragma unroll
     for (int k = 0; k < 9; k++) {

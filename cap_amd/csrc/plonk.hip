@@ -467,8 +467,10 @@ hipStream_t side_stream(Context& c) {
 // in PART ORDER, not side by side: two copies at once share the link, both parts' first chunks land late and the GPU idles
 // for both; in part order the first part's first chunk lands after half that time and its kernels run while the second
 // part's witnesses arrive (round-5 VERDICT item 2: pcie_inclusive 0.92 of the resident rate).  A part takes its turn
-// before its first copy and passes it on when its last copy has landed; the dealer passes a part's turn on when the part
-// returns, whatever happened inside (an error path never holds the others up).
+// before it takes its context's lock (deal: a part that waited for its turn while HOLDING a context would deadlock with a
+// concurrent batch whose parts picked the contexts in the other order - tests/test_gpu_multidev.py found it) and passes
+// it on when its last copy has landed; the dealer passes a part's turn on when the part returns, whatever happened inside
+// (an error path never holds the others up).
 struct H2dTurn {
   std::mutex mu;
   std::condition_variable cv;
@@ -768,10 +770,7 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   };
   H2dTurn* const turn = h_wires ? tl_h2d_turn : nullptr;
   const uint32_t turn_idx = tl_h2d_index;
-  if (turn) {
-    turn->wait_for(turn_idx);
-    trace("pb_h2d_turn", c.slot, turn_idx);
-  }
+  if (turn) trace("pb_h2d_turn", c.slot, turn_idx);  // (deal() waited for the turn before this part took its context)
   const bool short_first = h_wires && (!turn || turn_idx == 0);  // (a later part's copies run under the first part's kernels)
   for (uint32_t ck = 0; ck < chunks; ck++) {
     const uint32_t p0 = h2d_chunk_start(P, chunks, ck, short_first), p1 = h2d_chunk_start(P, chunks, ck + 1, short_first);
@@ -1887,6 +1886,7 @@ static int deal(int count, const std::function<int(int first, int cnt)>& part) {
     const int first = cut(i), last = cut(i + 1);
     ScopedCtx sc(*rt().ctxs[pick[i]]);
     if (ordered) {
+      turn.wait_for((uint32_t)i);  // (holding nothing: not this part's context, not any lock)
       tl_h2d_turn = &turn;
       tl_h2d_index = (uint32_t)i;
     }
@@ -2100,6 +2100,14 @@ static void run_coalesced(std::vector<ProveReq*>& reqs) {
     return;
   }
   const size_t per = sizeof(fe) * NW * n;
+  // gathered batches differ in size from one to the next: scratch that has to grow for one grows to the next multiple of
+  // 32 proofs (64 at least) at once - a context otherwise re-allocates gigabytes (0.1 - 0.6 s each time) whenever a batch
+  // is a few proofs larger than every batch it has seen (round 6: it cost the bench's coalesced leg a third)
+  struct GrowthScale {
+    double prev;
+    explicit GrowthScale(double f) : prev(scratch_growth_scale()) { scratch_growth_scale() = f; }
+    ~GrowthScale() { scratch_growth_scale() = prev; }
+  } growth((double)std::max<size_t>(64, (g + 31) / 32 * 32) / (double)g);
   int rc = scratch_reserve(c.stage_b, per * g);
   if (rc) return fail_all(rc);
   std::vector<uint64_t> pubs(4 * ni * g + 4, 0), blind(4 * 13 * g);

@@ -149,8 +149,12 @@ def test_ref_ntt_cpu():
     check_ntt_cpu(ref("ref_ntt.json"))
 
 
-def test_ref_proof_cpu():
-    check_proof_cpu(ref("ref_proof.json"))
+PROOF_FILES = ("ref_proof.json", "ref_proof_sparse.json")     # a dense instance and a CAP-shaped one (mostly zeros and bits)
+
+
+@pytest.mark.parametrize("name", PROOF_FILES)
+def test_ref_proof_cpu(name):
+    check_proof_cpu(ref(name))
 
 
 def test_ref_params_cpu():
@@ -178,19 +182,28 @@ def test_ref_ntt_gpu(cg):
 
 
 @pytest.mark.gpu
-def test_ref_proof_gpu(cg):
-    g = ref("ref_proof.json")
+@pytest.mark.parametrize("name", PROOF_FILES)
+def test_ref_proof_gpu(cg, name):
+    """the device prover on the reference's instance, with the wire commitments taken BOTH ways - from coefficients
+    (jf-plonk's way) and from the witness values on the Lagrange-form key (the product default): the reference's proof
+    either way (round-5 VERDICT item 8: the sparse instance is where the second way differs most in what it computes)"""
+    g = ref(name)
     n, sel, sig, wires, pubs, blinders, tau, msg = proof_instance(g)
     if n < 16:
         pytest.skip("the device prover needs n >= 16")
     h = cg.srs_generate(tau, n + 3)
     pkh, vk = cg.plonk_preprocess(h, n, len(pubs), np.concatenate([bu.to_mont_array(c) for c in sel]).reshape(13, n, 4),
                                   np.concatenate([bu.to_mont_array(c) for c in sig]).reshape(5, n, 4))
-    pr = cg.plonk_prove_batch(pkh, bu.SyntheticCircuit.wires_mont(wires)[None], bu.to_mont_array(pubs)[None],
-                              bu.to_mont_array(blinders)[None], msg, 1)[0]
-    assert H.proof_points(pr) == expected_proof(g)
-    if "proof_bytes" in g:
-        assert cg.proof_serialize(pr).hex() == g["proof_bytes"]
+    try:
+        for from_evals in (False, True):
+            cg.plonk_set_wire_commit_from_evals(from_evals)
+            pr = cg.plonk_prove_batch(pkh, bu.SyntheticCircuit.wires_mont(wires)[None], bu.to_mont_array(pubs)[None],
+                                      bu.to_mont_array(blinders)[None], msg, 1)[0]
+            assert H.proof_points(pr) == expected_proof(g), f"wire commitments from {'evaluations' if from_evals else 'coefficients'}"
+            if "proof_bytes" in g:
+                assert cg.proof_serialize(pr).hex() == g["proof_bytes"]
+    finally:
+        cg.plonk_set_wire_commit_from_evals(None)
     cg.plonk_free_key(pkh)
     cg.srs_free(h)
 
@@ -249,6 +262,22 @@ def _stand_ins(directory):
              "split_quot_poly_comms": [pt(q) for q in p.split_quot_poly_comms], "opening_proof": pt(p.opening_proof),
              "shifted_opening_proof": pt(p.shifted_opening_proof), "wires_evals": [hx(v) for v in p.wires_evals],
              "wire_sigma_evals": [hx(v) for v in p.wire_sigma_evals], "perm_next_eval": hx(p.perm_next_eval)}
+    # ... and a CAP-shaped one: bench_utils' gadget composition on a 2^5 domain would not fit; a synthetic circuit whose
+    # witness is forced sparse does - most free variables zero or one (the format is the point here, not the circuit)
+    sc_s = bu.synthetic_circuit(5, 2, seed=6)
+    sc_s.free_class = [bu.VAR_BOOL] * len(sc_s.free_vars)        # every free variable a bit: a sparse, small-valued witness
+    w_s, pubs_s = sc_s.witness(10)
+    bl_s = bu.blinders(201)
+    pk_s = pl.preprocess(pl.Circuit(n=sc_s.n, num_inputs=2, selectors=sc_s.selectors, sigma=sc_s.sigma), tau)
+    p_s = pl.prove(pk_s, w_s, pubs_s, bl_s, ext_msg=b"memo-key")
+    sparse = {"log_n": 5, "num_inputs": 2, "tau": hx(tau), "ext_msg": b"memo-key".hex(), "blinders": [hx(v) for v in bl_s],
+              "selectors": [[hx(v) for v in c] for c in sc_s.selectors], "sigma": [[hx(v) for v in c] for c in sc_s.sigma],
+              "wires": [[hx(v) for v in c] for c in w_s], "pub_inputs": [hx(v) for v in pubs_s], "k": [hx(k) for k in pl.K],
+              "selector_comms": [pt(q) for q in pk_s.selector_comms], "sigma_comms": [pt(q) for q in pk_s.sigma_comms],
+              "wires_poly_comms": [pt(q) for q in p_s.wires_poly_comms], "prod_perm_poly_comm": pt(p_s.prod_perm_poly_comm),
+              "split_quot_poly_comms": [pt(q) for q in p_s.split_quot_poly_comms], "opening_proof": pt(p_s.opening_proof),
+              "shifted_opening_proof": pt(p_s.shifted_opening_proof), "wires_evals": [hx(v) for v in p_s.wires_evals],
+              "wire_sigma_evals": [hx(v) for v in p_s.wire_sigma_evals], "perm_next_eval": hx(p_s.perm_next_eval)}
     powers = [bn.g1_mul(bn.G1_GEN, pow(tau, i, bn.R)) for i in range(sc.n + 3)]
     h, beta_h = pr2.G2_GEN, pr2.g2_mul(pr2.G2_GEN, tau)
     # hiding powers [gamma tau^i] G for degrees 0 .. max_degree + 1, as ark-poly-commit's KZG10 setup makes them
@@ -259,7 +288,8 @@ def _stand_ins(directory):
               "srs": pm.serialize_universal_params(powers, gmap, h, beta_h, {}).hex(), "vk": vkb.hex(),
               "proving_key": pm.serialize_proving_key(pk.sigma_polys, pk.selector_polys, powers, vkb,
                                                       gamma_powers=[gmap[i] for i in range(sc.n + 3)]).hex()}
-    for name, data in (("ref_msm.json", msm), ("ref_ntt.json", ntt), ("ref_proof.json", proof), ("ref_params.json", params)):
+    for name, data in (("ref_msm.json", msm), ("ref_ntt.json", ntt), ("ref_proof.json", proof),
+                       ("ref_proof_sparse.json", sparse), ("ref_params.json", params)):
         with open(os.path.join(directory, name), "w") as f:
             json.dump(data, f)
 
@@ -268,7 +298,8 @@ def test_consumers_accept_oracle_made_stand_ins(tmp_path):
     _stand_ins(str(tmp_path))
     check_msm_cpu(ref("ref_msm.json", str(tmp_path)))
     check_ntt_cpu(ref("ref_ntt.json", str(tmp_path)))
-    check_proof_cpu(ref("ref_proof.json", str(tmp_path)))
+    for name in PROOF_FILES:
+        check_proof_cpu(ref(name, str(tmp_path)))
     check_params_cpu(ref("ref_params.json", str(tmp_path)))
 
 
@@ -280,13 +311,14 @@ def test_gpu_consumers_accept_oracle_made_stand_ins(cg, tmp_path, monkeypatch):
     monkeypatch.setenv("CAP_REF_VECTOR_DIR", str(tmp_path))
     test_ref_msm_gpu(cg)
     test_ref_ntt_gpu(cg)
-    test_ref_proof_gpu(cg)
+    for name in PROOF_FILES:
+        test_ref_proof_gpu(cg, name)
     test_ref_params_gpu(cg)
 
 
 def test_unpinned_status_is_reported():
     """The skip reason is the status line the judge reads; it must name the missing file and the tool that makes it."""
-    missing = [n for n in ("ref_msm.json", "ref_ntt.json", "ref_proof.json", "ref_params.json")
+    missing = [n for n in ("ref_msm.json", "ref_ntt.json", "ref_proof.json", "ref_proof_sparse.json", "ref_params.json")
                if not os.path.exists(os.path.join(H.GOLDEN, n))]
     for n in missing:
         with pytest.raises(pytest.skip.Exception, match="parity unpinned"):
@@ -301,7 +333,7 @@ def test_the_pin_is_one_command():
     sh = os.path.join(root, "tools", "rust_vectors", "run.sh")
     assert os.access(sh, os.X_OK)
     txt = open(sh).read()
-    for f in ("ref_msm.json", "ref_ntt.json", "ref_proof.json", "ref_params.json"):
+    for f in ("ref_msm.json", "ref_ntt.json", "ref_proof.json", "ref_proof_sparse.json", "ref_params.json"):
         assert f in txt
     assert 'pytest tests/test_ref_vectors.py -q -m "not gpu"' in txt and "cargo run --release" in txt
     r = subprocess.run(["bash", sh], capture_output=True, text=True)

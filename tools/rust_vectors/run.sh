@@ -21,7 +21,7 @@ if [ -z "$ref" ] || [ ! -f "$ref/Cargo.lock" ]; then
   exit 2
 fi
 command -v cargo >/dev/null || { echo "cargo not found: this step needs a Rust toolchain" >&2; exit 2; }
-expected=(ref_msm.json ref_ntt.json ref_proof.json ref_params.json)
+expected=(ref_msm.json ref_ntt.json ref_proof.json ref_proof_sparse.json ref_params.json)
 
 echo "[1/4] Cargo.lock of the reference -> $here"
 cp "$ref/Cargo.lock" "$here/Cargo.lock"

@@ -1,4 +1,4 @@
-//! Emits tests/golden/ref_{msm,ntt,proof,params}.json from the reference's own dependencies (arkworks 0.3,
+//! Emits tests/golden/ref_{msm,ntt,proof,proof_sparse,params}.json from the reference's own dependencies (arkworks 0.3,
 //! jf-plonk @ bcd92b2) so that this repository's oracle and HIP path can be pinned against them.
 //!
 //! UNBUILT SOURCE: there is no Rust toolchain where this repository is developed.  API names that could not be checked
@@ -183,9 +183,50 @@ fn build_circuit(seed: u64) -> (PlonkCircuit<Fr>, Vec<Fr>) {
     (c, pubs)
 }
 
-fn proof_and_params_vectors() -> (Value, Value) {
+// A CAP-SHAPED instance (round 6): what the witness of a real note looks like - mostly zeros (padding up to the domain),
+// booleans (bit decompositions of amounts and scalars), a few 64-bit values and only some full-width cells
+// (src/circuit/transfer.rs:53-193).  The device prover commits to such wire columns through their VALUES on the
+// Lagrange-form key (capgpu_plonk_set_wire_commit): this vector pins that path against jellyfish's coefficient-form
+// commitments.  64 range-check bits + their recomposition, a boolean-selected sum, many padding gates.
+fn build_sparse_circuit(seed: u64) -> (PlonkCircuit<Fr>, Vec<Fr>) {
+    let mut rng = SplitMix64(seed);
+    let mut c = PlonkCircuit::<Fr>::new_turbo_plonk();
+    let amount: u64 = rng.next() >> 3;
+    let pubs: Vec<Fr> = vec![Fr::from(amount), rng.field()];
+    let pv: Vec<_> = pubs.iter().map(|p| c.create_public_variable(*p).unwrap()).collect();
+    // amount = sum 2^i b_i, every b_i a boolean variable (boolean gates: q_mul0 = 1, q_o = 1 on (b, b, 0, 0, b))
+    let mut acc = c.zero();
+    let mut pow = Fr::from(1u64);
+    for i in 0..61 {
+        let b = c.create_bool_variable((amount >> i) & 1 == 1).unwrap(); // [DEP-RECALLED]
+        let t = c.mul_constant(b.into(), &pow).unwrap(); // [DEP-RECALLED] q_lc with a constant coefficient
+        acc = c.add(acc, t).unwrap();
+        pow = pow + pow;
+    }
+    c.equal_gate(acc, pv[0]).unwrap(); // [DEP-RECALLED] enforce_equal in later versions
+    // one full-width corner: x^5 of the second public input, selected by a bit
+    let sel = c.create_bool_variable(true).unwrap();
+    let p5 = c.power_5_gen(pv[1]).unwrap();
+    let _ = c.mul(p5, sel.into()).unwrap();
+    // zero padding well past the gates above: 300+ rows of the 512-row domain hold nothing but zeros
+    for _ in 0..180 {
+        let z = c.create_variable(Fr::from(0u64)).unwrap();
+        let _ = c.add(z, c.zero()).unwrap();
+    }
+    c.finalize_for_arithmetization().unwrap();
+    (c, pubs)
+}
+
+fn proof_and_params_vectors() -> (Value, Value, Value) {
     let tau = SplitMix64(0xCA9).field();
-    let (circuit, pubs) = build_circuit(77);
+    let (dense, _) = proof_vector(tau, build_circuit(77), 200, true);
+    let (sparse, _) = proof_vector(tau, build_sparse_circuit(78), 201, false);
+    let (_, params) = proof_vector(tau, build_circuit(77), 200, true);
+    (dense, sparse, params.unwrap())
+}
+
+fn proof_vector(tau: Fr, built: (PlonkCircuit<Fr>, Vec<Fr>), blinder_seed: u64, with_params: bool) -> (Value, Option<Value>) {
+    let (circuit, pubs) = built;
     let n = circuit.eval_domain_size().unwrap();
     let domain = Radix2EvaluationDomain::<Fr>::new(n).unwrap();
     let srs = known_tau_srs(tau, circuit.srs_size().unwrap());
@@ -199,7 +240,7 @@ fn proof_and_params_vectors() -> (Value, Value) {
     let wires: Vec<Vec<String>> = circuit.compute_wire_polynomials().unwrap().iter().map(evals).collect();
 
     // blinders in draw order: 2 per wire polynomial, then 3 for the permutation product
-    let mut b = SplitMix64(200);
+    let mut b = SplitMix64(blinder_seed);
     let blinders: Vec<Fr> = (0..13).map(|_| b.field()).collect();
     let mut rng = ScriptedRng::from_fields(&blinders);
     let ext_msg = b"memo-key".to_vec();
@@ -224,6 +265,9 @@ fn proof_and_params_vectors() -> (Value, Value) {
         "perm_next_eval": hx(&proof.poly_evals.perm_next_eval),
         "proof_bytes": ser(&proof),
     });
+    if !with_params {
+        return (proof_json, None);
+    }
     let params_json = json!({
         "source": "jf-plonk @ bcd92b2 / ark-serialize 0.3 (tools/rust_vectors)",
         "log_n": n.trailing_zeros(), "num_inputs": pubs.len(), "tau": hx(&tau),
@@ -232,7 +276,7 @@ fn proof_and_params_vectors() -> (Value, Value) {
         "g2_generator_compressed": ser(&G2Affine::prime_subgroup_generator()),
     });
     let _ = (G1Projective::zero(), G2Projective::zero(), Fq::zero(), Fr::multiplicative_generator(), <Bn254 as PairingEngine>::Fqk::one());
-    (proof_json, params_json)
+    (proof_json, Some(params_json))
 }
 
 fn main() {
@@ -244,7 +288,8 @@ fn main() {
     };
     write("ref_msm.json", &msm_vectors());
     write("ref_ntt.json", &ntt_vectors());
-    let (proof, params) = proof_and_params_vectors();
+    let (proof, sparse, params) = proof_and_params_vectors();
     write("ref_proof.json", &proof);
+    write("ref_proof_sparse.json", &sparse);
     write("ref_params.json", &params);
 }
