@@ -5,6 +5,10 @@
 #include <stdio.h>
 #include <string.h>
 
+#include <execinfo.h>
+#include <signal.h>
+#include <unistd.h>
+
 #include <algorithm>
 #include <functional>
 #include <string>
@@ -835,9 +839,44 @@ extern "C" {
 const char* capgpu_last_error(void) { return last_error(); }
 const char* capgpu_version(void) { return "capgpu 0.2.0 (gfx950)"; }
 
+// CAPGPU_SEGV_BACKTRACE=1 (diagnostics): a SIGSEGV / SIGABRT in any thread of the process prints that thread's native
+// stack (symbol + offset: resolve with addr2line on libcapgpu.so) before the previous handler - Python's faulthandler
+// under pytest - gets its turn.  A fault in a pool or dealer thread is otherwise invisible to the Python-side report.
+static struct sigaction g_prev_segv, g_prev_abrt;
+static void segv_backtrace(int sig, siginfo_t* info, void* uctx) {
+  void* frames[64];
+  const int n = backtrace(frames, 64);
+  const char msg[] = "\ncapgpu: fatal signal, native stack of the faulting thread:\n";
+  (void)!write(2, msg, sizeof(msg) - 1);
+  backtrace_symbols_fd(frames, n, 2);
+  struct sigaction* prev = sig == SIGSEGV ? &g_prev_segv : &g_prev_abrt;
+  if (prev->sa_flags & SA_SIGINFO) {
+    if (prev->sa_sigaction) prev->sa_sigaction(sig, info, uctx);
+  } else if (prev->sa_handler && prev->sa_handler != SIG_DFL && prev->sa_handler != SIG_IGN) {
+    prev->sa_handler(sig);
+  }
+  signal(sig, SIG_DFL);
+  raise(sig);
+}
+static void install_segv_backtrace() {
+  const char* e = getenv("CAPGPU_SEGV_BACKTRACE");
+  if (!e || !atoi(e)) return;
+  static bool done = false;
+  if (done) return;
+  done = true;
+  struct sigaction sa;
+  memset(&sa, 0, sizeof(sa));
+  sa.sa_sigaction = segv_backtrace;
+  sa.sa_flags = SA_SIGINFO | SA_ONSTACK;
+  sigemptyset(&sa.sa_mask);
+  sigaction(SIGSEGV, &sa, &g_prev_segv);
+  sigaction(SIGABRT, &sa, &g_prev_abrt);
+}
+
 int capgpu_init(const int* device_ids, int n_devices) {
   static std::mutex init_mu;
   std::lock_guard<std::mutex> ilk(init_mu);
+  install_segv_backtrace();
   Runtime& R = rt();
   if (R.initialised.load()) return CAPGPU_OK;
   int count = 0;

@@ -467,17 +467,18 @@ hipStream_t side_stream(Context& c) {
 // in PART ORDER, not side by side: two copies at once share the link, both parts' first chunks land late and the GPU idles
 // for both; in part order the first part's first chunk lands after half that time and its kernels run while the second
 // part's witnesses arrive (round-5 VERDICT item 2: pcie_inclusive 0.92 of the resident rate).  A part takes its turn
-// before it takes its context's lock (deal: a part that waited for its turn while HOLDING a context would deadlock with a
-// concurrent batch whose parts picked the contexts in the other order - tests/test_gpu_multidev.py found it) and passes
-// it on when its last copy has landed; the dealer passes a part's turn on when the part returns, whatever happened inside
-// (an error path never holds the others up).
+// before its first copy - for a BOUNDED time: it holds its context's lock while it waits, and a concurrent batch whose
+// parts picked the contexts in the other order would otherwise deadlock with it (tests/test_gpu_multidev.py found that);
+// after 100 ms it copies anyway, side by side as before round 6 - and passes it on when its last copy has landed; the
+// dealer passes a part's turn on when the part returns, whatever happened inside (an error path never holds the others
+// up).  Only batches of 64 proofs and more take turns: below that the copies are too short to matter.
 struct H2dTurn {
   std::mutex mu;
   std::condition_variable cv;
   uint32_t next = 0;
-  void wait_for(uint32_t idx) {
+  bool wait_for(uint32_t idx, uint32_t timeout_ms) {  // false: timed out (the caller goes ahead regardless)
     std::unique_lock<std::mutex> lk(mu);
-    cv.wait(lk, [&] { return next >= idx; });
+    return cv.wait_for(lk, std::chrono::milliseconds(timeout_ms), [&] { return next >= idx; });
   }
   void pass(uint32_t idx) {  // part idx is done copying (idempotent)
     std::lock_guard<std::mutex> lk(mu);
@@ -770,7 +771,10 @@ int prove_batch(const ProvingKey& K, uint32_t P, const fe* d_wires, const uint64
   };
   H2dTurn* const turn = h_wires ? tl_h2d_turn : nullptr;
   const uint32_t turn_idx = tl_h2d_index;
-  if (turn) trace("pb_h2d_turn", c.slot, turn_idx);  // (deal() waited for the turn before this part took its context)
+  if (turn) {
+    const bool in_time = turn->wait_for(turn_idx, 100);
+    trace("pb_h2d_turn", c.slot, in_time ? (int64_t)turn_idx : -1);
+  }
   const bool short_first = h_wires && (!turn || turn_idx == 0);  // (a later part's copies run under the first part's kernels)
   for (uint32_t ck = 0; ck < chunks; ck++) {
     const uint32_t p0 = h2d_chunk_start(P, chunks, ck, short_first), p1 = h2d_chunk_start(P, chunks, ck + 1, short_first);
@@ -1866,7 +1870,7 @@ static int deal(int count, const std::function<int(int first, int cnt)>& part) {
   // (parts on different devices have a link each: only the parts of ONE device take turns)
   bool one_device = true;
   for (size_t i = 1; i < parts; i++) one_device = one_device && rt().ctxs[pick[i]]->device == rt().ctxs[pick[0]]->device;
-  const bool ordered = h2d_in_part_order() && one_device;
+  const bool ordered = h2d_in_part_order() && one_device && count >= 64;
   // Two parts whose copies go in part order do not start together: the first has the device to itself while the second's
   // witnesses arrive, stays ahead through every round and would end well before it, leaving the second part's last rounds
   // alone on the device (its host steps uncovered).  The first part is therefore the larger: CAPGPU_DEAL_FIRST_SIXTEENTHS
@@ -1879,14 +1883,13 @@ static int deal(int count, const std::function<int(int first, int cnt)>& part) {
   auto cut = [&](size_t i) -> int {  // first proof of part i
     if (i == 0) return 0;
     if (i >= parts) return count;
-    if (ordered && parts == 2 && count >= 64) return (int)((uint64_t)count * first16 / 16);
+    if (ordered && parts == 2) return (int)((uint64_t)count * first16 / 16);
     return (int)((uint64_t)count * i / parts);
   };
   auto body = [&](size_t i) {
     const int first = cut(i), last = cut(i + 1);
     ScopedCtx sc(*rt().ctxs[pick[i]]);
     if (ordered) {
-      turn.wait_for((uint32_t)i);  // (holding nothing: not this part's context, not any lock)
       tl_h2d_turn = &turn;
       tl_h2d_index = (uint32_t)i;
     }

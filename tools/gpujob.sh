@@ -20,7 +20,7 @@ case "$job" in
 suite)
   tag=$1
   O=gpurun_out/suite_$tag; mkdir -p $O
-  timeout 2400 python -m pytest tests -m gpu -q --durations=10 --timeout=600 > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
+  timeout 1500 python -m pytest tests -m gpu -q --durations=10 --timeout=300 > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
   python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
   S0=$SECONDS; timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; echo "bench.py wall $((SECONDS-S0)) s"; tail -c 2000 $O/bench.json; echo
   ;;
@@ -28,9 +28,10 @@ final)
   tag=$1
   O=gpurun_out/final_$tag
   mkdir -p $O
-  timeout 2400 python -m pytest tests -m gpu -q --durations=10 --timeout=600 > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
+  timeout 1500 python -m pytest tests -m gpu -q --durations=10 --timeout=300 > $O/pytest_gpu.txt 2>&1; tail -3 $O/pytest_gpu.txt
   python -c "import __graft_entry__ as g; g.smoke()" > $O/smoke.txt 2>&1; tail -1 $O/smoke.txt
-  timeout 900 python bench.py > $O/bench.json 2> $O/bench.err; tail -c 300 $O/bench.err
+  S0=$SECONDS; timeout 900 python bench.py --steps 20 --warmup 5 > $O/bench.json 2> $O/bench.err; echo "driver command wall $((SECONDS-S0)) s"; tail -c 300 $O/bench.err
+  bash tools/gpujob.sh phase $tag > $O/phase.log 2>&1; cp gpurun_out/phase_$tag/phase.jsonl $O/phase.jsonl
   timeout 600 python bench.py --steps 20 --warmup 5 --no-extras --no-cpu-baseline --no-reference-schedule --no-msm > $O/bench_20steps.json 2>/dev/null
   timeout 600 python bench.py --workload mixed64 --steps 12 --warmup 3 --no-msm > $O/bench_mixed64.json 2>/dev/null
   CAPGPU_ALLOW_DUPLICATE_DEVICES=1 timeout 600 python bench.py --single-process --devices 0,0 --batch 128 --steps 4 --warmup 1 --msm-log-n 22 > $O/bench_single_process.json 2>/dev/null
