@@ -273,6 +273,29 @@ pub fn set_coalescing(window_us: u32, max_batch: u32) -> Result<()> {
     check(unsafe { capgpu_plonk_set_coalescing(window_us, max_batch) })
 }
 
+/// How the wire commitments are computed: `true` (the default) from the witness VALUES on the Lagrange-form key - round 1's
+/// time then depends on the witness's sparsity -, `false` from coefficients, as jf-plonk does (witness-independent work;
+/// the mode for deployments where an adversary can time proofs: include/capgpu.h, "TIMING AND THE SECRET WITNESS").
+pub fn set_wire_commit_from_evals(on: bool) -> Result<()> {
+    check(unsafe { capgpu_plonk_set_wire_commit(if on { 1 } else { 0 }) })
+}
+
+/// Releases the workspace of every idle device context (scratch, pinned result areas, captured launch graphs): tables -
+/// SRS, proving keys, NTT domains - stay.  Returns the device bytes given back.  A process that shares the GPU calls this
+/// when it goes idle; the next proof allocates again.
+pub fn trim() -> Result<u64> {
+    let mut released = 0u64;
+    let mut busy: c_int = 0;
+    check(unsafe { capgpu_trim(&mut released, &mut busy) })?;
+    Ok(released)
+}
+
+/// Caps the workspace the library holds per device (0 = no cap).  A `prove` that would grow past it fails with
+/// `CAPGPU_ERR_OOM` (after trimming the device's idle contexts): prove in smaller batches, or raise the cap.
+pub fn set_memory_limit(scratch_bytes_per_device: u64) -> Result<()> {
+    check(unsafe { capgpu_set_memory_limit(scratch_bytes_per_device) })
+}
+
 /// A device-resident commit key (`UniversalSrs::powers_of_g` / `CommitKey::powers_of_g`).
 pub struct Srs {
     handle: u64,
