@@ -13,6 +13,7 @@
 #   env TAG VAR=VAL...        short bench under environment overrides
 #   ntt TAG LIB...            device time of batches of coset NTTs for several library builds (tools/gpu_ntt_time.py)
 #   phase TAG [VAR=VAL...]    host-side phase traces of the host-witness and coalesced paths (tools/gpu_phase_trace.py)
+#   campaign TAG [SEED]       fuzz / stress campaign: prover, primitives, parameter blobs, threads, leaks, graph capture
 #   w2                        bench.py --gpus 2 on this one GPU (gloo, shared device): the N > 1 line and its wall time
 #   ubench NAME               build and run tools/ubench_NAME.hip (microbenchmarks behind DESIGN.md's numbers)
 job=$1; shift
@@ -211,6 +212,23 @@ phase)
   done
   cat $O/phase.jsonl; tail -3 $O/phase.err
   ;;
+campaign)
+  # fuzz / stress campaign on the round's binary (seeds differ from the bounded slices under -m gpu): TAG [SEED_BASE]
+  tag=$1; seed=${2:-61000}
+  O=gpurun_out/campaign_$tag.txt; : > $O
+  step() { name=$1; shift; echo "== $name" >> $O; S0=$SECONDS; "$@" 2>&1 | tail -2 >> $O; echo "wall $((SECONDS-S0)) s" >> $O; }
+  step fuzz_prover timeout 900 python tools/gpu_fuzz_prover.py 120 $((seed+1))
+  step fuzz_prover_big timeout 900 python tools/gpu_fuzz_prover.py 8 $((seed+2)) big
+  step fuzz_prims timeout 900 python tools/gpu_fuzz_prims.py 3000 $((seed+3))
+  step fuzz_params timeout 300 python tools/gpu_fuzz_params.py 300 $((seed+4))
+  step thread_stress timeout 300 python tools/gpu_thread_stress.py 45
+  step leak timeout 300 python tools/gpu_leak_check.py 200
+  step capture_stress timeout 600 python tools/gpu_capture_stress.py 400
+  step fuzz_prover_coeff_commit_no_graphs env CAPGPU_WIRE_COMMIT=coeffs CAPGPU_GRAPH_MAX_BATCH=0 timeout 900 python tools/gpu_fuzz_prover.py 60 $((seed+5))
+  step fuzz_prover_prestage_inflight3 env CAPGPU_COALESCE_PRESTAGE=1 CAPGPU_COALESCE_INFLIGHT=3 timeout 900 python tools/gpu_fuzz_prover.py 60 $((seed+6))
+  step thread_stress_prestage env CAPGPU_COALESCE_PRESTAGE=1 timeout 300 python tools/gpu_thread_stress.py 30
+  cat $O
+  ;;
 w2)
   mkdir -p gpurun_out
   S0=$SECONDS
@@ -225,6 +243,6 @@ ubench)
   mkdir -p gpurun_out; timeout 600 tools/ubench_$name.bin | tee gpurun_out/ubench_$name.txt
   ;;
 *)
-  echo "usage: tools/gpujob.sh suite|final|prof|insts|clock|ab|env|ntt|phase|w2|ubench ..." >&2; exit 2
+  echo "usage: tools/gpujob.sh suite|final|prof|insts|clock|ab|env|ntt|phase|campaign|w2|ubench ..." >&2; exit 2
   ;;
 esac
