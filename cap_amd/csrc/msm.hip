@@ -2050,8 +2050,14 @@ Plan choose_plan(const MsmBases& bases, size_t n, uint32_t batch) {
   // running-sum additions per bucket instead of a log-depth tree, and (b) buckets still hold several entries
   if (bases.ext2 && n >= 4096) {
     uint32_t parts = n > kMaxSubPoints ? (uint32_t)((n + 65535) / 65536) : 1;
-    if ((size_t)batch * parts >= wide_min_batch()) {
-      const size_t n_sub = parts > 1 ? (size_t)65536 : n;
+    const size_t n_sub0 = parts > 1 ? (size_t)65536 : n;
+    // (sub-)MSMs of >= 2^16 points put twice the entries into each of the 16384 buckets, so the wide table's bucket
+    // reduction weighs half as much: it pays from 4 of them, not two dozen (round 6, same box, ms per call at 2^17 points:
+    // 2 MSMs 0.76 -> 0.65, 5 MSMs 1.40 -> 1.21, 8 MSMs 1.99 -> 1.76; at 2^16: 5 MSMs 0.80 -> 0.77, 8 MSMs 1.10 -> 1.01; a
+    // lone 2^17-point MSM stays on the narrow table: 0.48 against 0.53)
+    const size_t wide_from = n_sub0 >= 65536 ? std::min<size_t>(wide_min_batch(), 4) : wide_min_batch();
+    if ((size_t)batch * parts >= wide_from) {
+      const size_t n_sub = n_sub0;
       pl = Plan{bases.c2, bases.windows2, pick_sub_bits(n_sub, bases.c2, bases.windows2), bases.ext2, parts, n_sub};
       return pl;
     }

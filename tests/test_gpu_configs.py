@@ -70,6 +70,11 @@ def test_msm_plans_of_the_baseline_sizes(cg, tau):
                                           "slice": 1}
     p = cg.msm_plan(h, 32770, 1280)                       # the prover's 5P-wide commitment launch at n = 2^15
     assert (p["c"], p["sort"], p["parts"], p["slice"], p["bin_buckets"]) == (15, "two-level", 1, 1280, 128)
+    # a round of an n = 2^17 circuit (5 commitments: BASELINE config 2's size as a batch): the wide table from 4 (sub-)MSMs
+    # of >= 2^16 points on (round 6); the lone call above stays on the narrow one
+    p = cg.msm_plan(h, 1 << 17, 5)
+    assert (p["c"], p["sort"], p["parts"], p["n_sub"]) == (15, "two-level", 2, 65536), p
+    assert cg.msm_plan(h, 1 << 16, 3)["c"] == 13 and cg.msm_plan(h, 1 << 16, 4)["c"] == 15
     p = cg.msm_plan(h, (1 << 17) + 2, 40)                 # a batch at n = 2^17: parts instead of the narrow table
     # parts of 2^16 points: bins of 64 buckets, so that a bin (4352 entries) still fits the level-2 sort's LDS stage
     assert (p["c"], p["sort"], p["parts"], p["n_sub"], p["bin_buckets"]) == (15, "two-level", 3, 65536, 64)
