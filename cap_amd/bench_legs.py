@@ -246,6 +246,8 @@ def headline_last(out: dict) -> dict:
                 summary[name + "_over_value"] = r3(v / val)
                 if o[key].get("over_resident_same_minute"):
                     summary[name + "_over_resident_same_minute"] = r3(o[key]["over_resident_same_minute"])
+                if o[key].get("callers_128_over_resident_same_minute"):
+                    summary[name + "_128_callers_over_resident_same_minute"] = r3(o[key]["callers_128_over_resident_same_minute"])
     if isinstance(o.get("n1_same_run"), dict):
         summary["value_over_n_times_n1_same_run"] = r3(o["n1_same_run"].get("value_over_n_times_this"))
     m64 = o.get("mixed64") or o.get("mixed64_multi_gpu")
