@@ -83,6 +83,8 @@ extern "C" {
     pub fn capgpu_memcpy_h2d(dev_dst: *mut c_void, host_src: *const c_void, bytes: usize) -> c_int;
     pub fn capgpu_memcpy_d2h(host_dst: *mut c_void, dev_src: *const c_void, bytes: usize) -> c_int;
     pub fn capgpu_sync() -> c_int;
+    pub fn capgpu_sync_all() -> c_int;
+    pub fn capgpu_runtime_info(hip_runtime_version_out: *mut c_int, hip_driver_version_out: *mut c_int) -> c_int;
     pub fn capgpu_timer_begin() -> c_int;
     pub fn capgpu_timer_end(ms_out: *mut f64) -> c_int;
     pub fn capgpu_context_count(count_out: *mut c_int) -> c_int;

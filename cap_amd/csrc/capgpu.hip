@@ -1186,6 +1186,34 @@ int capgpu_sync(void) {
   CAP_HIP(hipStreamSynchronize(ctx().stream));
   return CAPGPU_OK;
 }
+int capgpu_sync_all(void) {
+  CAP_CHECK_INIT();
+  int prev = -1;
+  (void)hipGetDevice(&prev);
+  std::vector<int> seen;
+  hipError_t e = hipSuccess;
+  for (auto& cp : rt().ctxs) {
+    if (std::find(seen.begin(), seen.end(), cp->device) != seen.end()) continue;
+    seen.push_back(cp->device);
+    if (e == hipSuccess) e = hipSetDevice(cp->device);
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+  }
+  if (prev >= 0) (void)hipSetDevice(prev);
+  CAP_HIP(e);
+  return CAPGPU_OK;
+}
+int capgpu_runtime_info(int* hip_runtime_version_out, int* hip_driver_version_out) {
+  int v = 0;
+  if (hip_runtime_version_out) {
+    CAP_HIP(hipRuntimeGetVersion(&v));
+    *hip_runtime_version_out = v;
+  }
+  if (hip_driver_version_out) {
+    CAP_HIP(hipDriverGetVersion(&v));
+    *hip_driver_version_out = v;
+  }
+  return CAPGPU_OK;
+}
 // device time of whatever the calling thread's context executes between the two calls: HIP events on ITS stream
 // ("hipEvent around device section"); a pair per context, created on first use
 int capgpu_timer_begin(void) {

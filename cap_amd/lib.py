@@ -224,6 +224,18 @@ class DevBuf:
             pass
 
 
+def sync_all():
+    """capgpu_sync_all: hipDeviceSynchronize on every bound device"""
+    check(load().capgpu_sync_all())
+
+
+def runtime_info():
+    """(HIP runtime version, HIP driver version) the process runs on - the first libamdhip64.so.7 the loader met"""
+    r, d = ctypes.c_int(0), ctypes.c_int(0)
+    check(load().capgpu_runtime_info(ctypes.byref(r), ctypes.byref(d)))
+    return r.value, d.value
+
+
 def sync():
     check(load().capgpu_sync())
 

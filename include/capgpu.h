@@ -160,6 +160,14 @@ int capgpu_free(void* dev_ptr);
 int capgpu_memcpy_h2d(void* dev_dst, const void* host_src, size_t bytes);
 int capgpu_memcpy_d2h(void* host_dst, const void* dev_src, size_t bytes);
 int capgpu_sync(void);
+/* waits for everything enqueued on every bound device (hipDeviceSynchronize per device): what a caller without a HIP
+ * binding of its own uses where a torch program would call torch.cuda.synchronize() */
+int capgpu_sync_all(void);
+/* HIP runtime / driver version the PROCESS runs on (hipRuntimeGetVersion: e.g. 70226015).  The library is built against
+ * /opt/rocm; a process that loaded another libamdhip64.so.7 first - PyTorch's wheel bundles its own - runs the library on
+ * THAT runtime (same SONAME: the loader keeps the first).  bench.py records it: the host-witness legs differ by 3 % between
+ * the two runtimes on this image. */
+int capgpu_runtime_info(int* hip_runtime_version_out, int* hip_driver_version_out);
 /* Device time, in milliseconds, of the work the calling thread's context executes between the two calls (HIP events on
  * its stream; _end waits for that work).  SURVEY 8d's "hipEvent around device section": bench.py times its MSM / NTT
  * legs with it.  ONE measurement per context at a time, owned by the thread that opened it: that thread may restart it
