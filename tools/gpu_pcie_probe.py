@@ -77,6 +77,22 @@ for _ in range(60):
     cg.plonk_prove_batch_dev(pk, d1, pubs[:1], blind[:1], msg, 1)
 out["resident_after_latency_leg"] = resident(6)
 out["host_after_latency_leg"] = host()
-for k in ("0", "1", "2", "3", "after_latency_leg"):
+# what else the bench does before that leg: the whole batch on ONE context with the HIP-event profiler on (context 0's scratch
+# grows to 256 proofs' worth), the issue-rate microbenchmarks
+cg.set_device(0)
+cg.profile_reset()
+cg.profile_enable(True)
+for _ in range(3):
+    cg.plonk_prove_batch_dev(pk, d, pubs, blind, msg, P)
+cg.profile_stats()
+cg.profile_enable(False)
+out["resident_after_profiled_pass"] = resident(6)
+out["host_after_profiled_pass"] = host()
+cg.ubench_mad_rate()
+cg.ubench_issue_rates()
+out["resident_after_ubench"] = resident(6)
+out["host_after_ubench"] = host()
+out["resident_3steps"] = resident(3)
+for k in ("0", "1", "2", "3", "after_latency_leg", "after_profiled_pass", "after_ubench"):
     out["ratio_" + k] = out["host_" + k] / out["resident_" + k]
 print(json.dumps({k: round(v, 4 if k.startswith("ratio") else 1) for k, v in out.items()}))
