@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include <execinfo.h>
+#include <fcntl.h>
 #include <signal.h>
 #include <unistd.h>
 
@@ -843,12 +844,31 @@ const char* capgpu_version(void) { return "capgpu 0.2.0 (gfx950)"; }
 // stack (symbol + offset: resolve with addr2line on libcapgpu.so) before the previous handler - Python's faulthandler
 // under pytest - gets its turn.  A fault in a pool or dealer thread is otherwise invisible to the Python-side report.
 static struct sigaction g_prev_segv, g_prev_abrt;
+static int g_segv_fd = -1;  // a file of its own (CAPGPU_SEGV_BACKTRACE=<path>): a test runner may have redirected fd 2
 static void segv_backtrace(int sig, siginfo_t* info, void* uctx) {
   void* frames[64];
   const int n = backtrace(frames, 64);
   const char msg[] = "\ncapgpu: fatal signal, native stack of the faulting thread:\n";
-  (void)!write(2, msg, sizeof(msg) - 1);
-  backtrace_symbols_fd(frames, n, 2);
+  for (int fd : {2, g_segv_fd}) {
+    if (fd < 0) continue;
+    (void)!write(fd, msg, sizeof(msg) - 1);
+    backtrace_symbols_fd(frames, n, fd);
+    if (info) {
+      char line[96];
+      const int len = snprintf(line, sizeof(line), "signal %d, fault address %p, thread %ld\n", sig, info->si_addr, (long)gettid());
+      if (len > 0) (void)!write(fd, line, (size_t)len);
+    }
+  }
+  // the loaded objects' base addresses (offsets above are relative to them)
+  if (g_segv_fd >= 0) {
+    const int maps = open("/proc/self/maps", O_RDONLY);
+    if (maps >= 0) {
+      char buf[4096];
+      ssize_t k;
+      while ((k = read(maps, buf, sizeof(buf))) > 0) (void)!write(g_segv_fd, buf, (size_t)k);
+      close(maps);
+    }
+  }
   struct sigaction* prev = sig == SIGSEGV ? &g_prev_segv : &g_prev_abrt;
   if (prev->sa_flags & SA_SIGINFO) {
     if (prev->sa_sigaction) prev->sa_sigaction(sig, info, uctx);
@@ -860,10 +880,15 @@ static void segv_backtrace(int sig, siginfo_t* info, void* uctx) {
 }
 static void install_segv_backtrace() {
   const char* e = getenv("CAPGPU_SEGV_BACKTRACE");
-  if (!e || !atoi(e)) return;
+  if (!e || !*e || !strcmp(e, "0")) return;
   static bool done = false;
   if (done) return;
   done = true;
+  if (strcmp(e, "1") != 0) {  // a path: <path>.<pid>
+    char path[512];
+    snprintf(path, sizeof(path), "%s.%d", e, (int)getpid());
+    g_segv_fd = open(path, O_WRONLY | O_CREAT | O_APPEND, 0644);
+  }
   struct sigaction sa;
   memset(&sa, 0, sizeof(sa));
   sa.sa_sigaction = segv_backtrace;

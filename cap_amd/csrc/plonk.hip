@@ -128,7 +128,27 @@ static std::atomic<uint64_t> g_graph_captured{0}, g_graph_replayed{0};
 
 namespace {
 
+// hipGraph replay is used only on a HIP runtime at least as new as the one this library was built with.  A process that
+// loaded ANOTHER libamdhip64.so.7 first runs the library on that copy (same SONAME: the loader keeps the first) - PyTorch's
+// wheel bundles ROCm 7.0.2's - and round 6 caught three crashes INSIDE that runtime, under stream capture / graph launch
+// (tests/test_gpu_graphs.py, test_gpu_input_forms.py, test_gpu_lagrange.py; one in ~12 suite runs; never on /opt/rocm's
+// 7.2 in thousands of captures: tools/gpu_capture_stress.py, the fuzz campaigns).  On an older runtime small batches launch
+// directly - a few per cent of latency - unless CAPGPU_GRAPH_FORCE=1.
+bool graph_runtime_ok() {
+  static const bool ok = [] {
+    const char* f = getenv("CAPGPU_GRAPH_FORCE");
+    if (f && atoi(f) != 0) return true;
+    int v = 0;
+    if (hipRuntimeGetVersion(&v) != hipSuccess) {
+      (void)hipGetLastError();
+      return false;
+    }
+    return v >= HIP_VERSION;
+  }();
+  return ok;
+}
 uint32_t graph_max_batch() {
+  if (!graph_runtime_ok()) return 0;
   const char* e = getenv("CAPGPU_GRAPH_MAX_BATCH");
   const int x = e ? atoi(e) : 16;
   return (uint32_t)(x < 0 ? 0 : (x > 64 ? 64 : x));

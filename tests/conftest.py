@@ -10,7 +10,31 @@ if ROOT not in sys.path:
 
 # a fatal signal in ANY native thread of the product library prints that thread's stack before Python's faulthandler
 # reports the Python side (cap_amd/csrc/capgpu.hip: CAPGPU_SEGV_BACKTRACE; round 6 met one unexplained crash in ~12 suite runs)
-os.environ.setdefault("CAPGPU_SEGV_BACKTRACE", "1")
+# (into a file of its own under gpurun_out/ - pytest captures fd 2, and what a crashing test wrote there is lost)
+try:
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    os.environ.setdefault("CAPGPU_SEGV_BACKTRACE", os.path.join(ROOT, "gpurun_out", "capgpu_fatal_signal"))
+except OSError:
+    os.environ.setdefault("CAPGPU_SEGV_BACKTRACE", "1")
+
+
+# Which libamdhip64.so.7 serves this process is decided by what is loaded first (same SONAME: the loader keeps the first):
+# PyTorch's wheel bundles ROCm 7.0.2's, libcapgpu.so is built against /opt/rocm's 7.2.  The suite runs TORCH FIRST, made
+# explicit here (rounds 1-5 got that order by accident: test_dist_cpu imports torch at collection): torch's runtime with
+# torch's RCCL is a consistent pair, which /opt/rocm's runtime with torch's RCCL - what a later `import torch` would leave the
+# library's dlopen("librccl.so") with - is not (ncclCommInitRank fails).  On that older runtime the library keeps hipGraph
+# replay off (plonk.hip: graph_runtime_ok - round 6 caught three crashes inside the 7.0.2 runtime under stream capture);
+# tests/test_gpu_graphs.py therefore re-runs itself in a child process with CAPGPU_TEST_LIBRARY_FIRST=1, where the library
+# is loaded first and runs - as under bench.py at N = 1, smoke(), the fuzz campaigns and any Rust caller - on the runtime
+# it was built with.
+if os.environ.get("CAPGPU_TEST_LIBRARY_FIRST") == "1":
+    from cap_amd import lib as _capgpu_lib
+    _capgpu_lib.load()
+else:
+    try:
+        import torch  # noqa: F401
+    except Exception:                              # noqa: BLE001
+        pass
 
 
 def pytest_configure(config):

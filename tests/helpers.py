@@ -10,6 +10,13 @@ from oracle import capref as cr
 GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 
 
+def gpu_present() -> bool:
+    """Is there an AMD GPU this process can open?  (The kernel driver's device node - not torch.cuda.is_available(): the
+    tests load libcapgpu.so before torch, so the process runs on /opt/rocm's HIP runtime, and torch's own view of the
+    device is then beside the point - see tests/conftest.py.)"""
+    return os.path.exists("/dev/kfd") and os.access("/dev/kfd", os.R_OK | os.W_OK)
+
+
 def load_golden(name):
     with open(os.path.join(GOLDEN, name)) as f:
         return json.load(f)

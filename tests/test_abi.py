@@ -52,9 +52,9 @@ def test_struct_layouts_match_header():
 def test_no_silent_fallback_without_device():
     """On a box without a GPU every compute entry point must refuse; on the GPU box this test only checks
     the not-initialised path before anything else has called capgpu_init in this process."""
-    import torch
+    from tests import helpers as H
     L = cg.load()
-    if torch.cuda.is_available():
+    if H.gpu_present():
         pytest.skip("GPU present: the refusal path is covered on the CPU-only runner")
     rc = L.capgpu_init(None, 0)
     assert rc == -2 and b"no CPU fallback" in L.capgpu_last_error()

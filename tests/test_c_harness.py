@@ -43,8 +43,7 @@ def expected_proof_bytes():
 
 
 def test_harness_builds_and_fails_loudly_without_a_gpu(harness):
-    import torch
-    if torch.cuda.is_available():
+    if H.gpu_present():
         pytest.skip("a GPU is present: covered by the gpu test")
     r = subprocess.run([harness, os.path.join(H.GOLDEN, "harness_log5.bin")], capture_output=True, text=True)
     assert r.returncode == 2 and "no CPU fallback" in r.stderr

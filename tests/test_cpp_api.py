@@ -29,8 +29,7 @@ def api_test(tmp_path_factory):
 
 
 def test_cpp_api_builds_and_fails_loudly_without_a_gpu(api_test):
-    import torch
-    if torch.cuda.is_available():
+    if H.gpu_present():
         pytest.skip("a GPU is present: covered by the gpu test")
     r = subprocess.run([api_test] + ARGS, capture_output=True, text=True)
     assert r.returncode == 2

@@ -237,8 +237,7 @@ def test_batch_verify_and_proof_serialization(tau):
     assert not cg.plonk_batch_verify(vks, h2, bh, pubs_l, proofs, [msgs[0], b"x"])
     assert not cg.plonk_batch_verify(vks, h2, bh, pubs_l, [proofs[0], proofs[0]], msgs)
     # the device form of the batch verifier has no host path behind it: without an initialised GPU it says so
-    import torch
-    if not torch.cuda.is_available():
+    if not H.gpu_present():
         with pytest.raises(cg.CapGpuError) as e:
             cg.plonk_batch_verify(vks, h2, bh, pubs_l, proofs, msgs, on_device=True)
         assert e.value.code in (-6, -2)
