@@ -845,10 +845,12 @@ const char* capgpu_version(void) { return "capgpu 0.2.0 (gfx950)"; }
 // under pytest - gets its turn.  A fault in a pool or dealer thread is otherwise invisible to the Python-side report.
 static struct sigaction g_prev_segv, g_prev_abrt;
 static int g_segv_fd = -1;  // a file of its own (CAPGPU_SEGV_BACKTRACE=<path>): a test runner may have redirected fd 2
+static char g_segv_path[512];  // "<path>.<pid>", opened in the handler (open is async-signal-safe): no empty files otherwise
 static void segv_backtrace(int sig, siginfo_t* info, void* uctx) {
   void* frames[64];
   const int n = backtrace(frames, 64);
   const char msg[] = "\ncapgpu: fatal signal, native stack of the faulting thread:\n";
+  if (g_segv_path[0] && g_segv_fd < 0) g_segv_fd = open(g_segv_path, O_WRONLY | O_CREAT | O_APPEND, 0644);
   for (int fd : {2, g_segv_fd}) {
     if (fd < 0) continue;
     (void)!write(fd, msg, sizeof(msg) - 1);
@@ -885,9 +887,7 @@ static void install_segv_backtrace() {
   if (done) return;
   done = true;
   if (strcmp(e, "1") != 0) {  // a path: <path>.<pid>
-    char path[512];
-    snprintf(path, sizeof(path), "%s.%d", e, (int)getpid());
-    g_segv_fd = open(path, O_WRONLY | O_CREAT | O_APPEND, 0644);
+    snprintf(g_segv_path, sizeof(g_segv_path), "%s.%d", e, (int)getpid());
   }
   struct sigaction sa;
   memset(&sa, 0, sizeof(sa));

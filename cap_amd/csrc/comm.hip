@@ -18,6 +18,8 @@
 // RCCL is loaded at capgpu_comm_init time (dlopen), so the library itself loads - and the single-GPU path runs - on
 // machines without it.  If the process already holds an RCCL (PyTorch ships one), that copy is used.
 #include <dlfcn.h>
+
+#include <string>
 #include <rccl/rccl.h>  // types only: every function is looked up at run time
 #include <stdio.h>
 #include <string.h>
@@ -88,7 +90,25 @@ int load_rccl(Rccl& r) {
   const char* override_path = getenv("CAPGPU_RCCL_LIBRARY");
   void* h = nullptr;
   if (override_path) h = dlopen(override_path, RTLD_NOW | RTLD_LOCAL);
-  // a copy already in the process (same soname) first: two RCCLs in one process would each set up their own IPC state
+  // The RCCL that sits BESIDE the HIP runtime serving this process first (round 6): a process may hold two ROCm stacks -
+  // PyTorch's wheel bundles libamdhip64 + librccl of ROCm 7.0.2 next to /opt/rocm's 7.2 - and which libamdhip64.so.7 serves
+  // everything is decided by load order; an RCCL from the other stack fails in ncclCommInitRank ("unhandled cuda error":
+  // seen with the library loaded before torch).  dladdr on a runtime entry point names the file, its directory the stack.
+  if (!h) {
+    Dl_info info;
+    if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &info) && info.dli_fname) {
+      std::string dir(info.dli_fname);
+      const size_t slash = dir.rfind('/');
+      if (slash != std::string::npos) {
+        dir.resize(slash + 1);
+        for (const char* name : {"librccl.so.1", "librccl.so"}) {
+          if (h) break;
+          h = dlopen((dir + name).c_str(), RTLD_NOW | RTLD_LOCAL);
+        }
+      }
+    }
+  }
+  // a copy already in the process (same soname) next: two RCCLs in one process would each set up their own IPC state
   if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_NOLOAD);
   if (!h) h = dlopen("librccl.so.1", RTLD_NOW | RTLD_LOCAL);
   if (!h) h = dlopen("/opt/rocm/lib/librccl.so.1", RTLD_NOW | RTLD_LOCAL);
