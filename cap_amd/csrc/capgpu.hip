@@ -184,6 +184,11 @@ double& scratch_growth_scale() {
   return f;
 }
 
+void context_trim_if_pending(Context& c) {
+  c.trim_pending = false;
+  (void)trim_context(c);
+}
+
 int scratch_reserve(Scratch& s, size_t bytes) {
   if (bytes <= s.cap) return CAPGPU_OK;
   Context& c = ctx();
@@ -205,6 +210,7 @@ int scratch_reserve(Scratch& s, size_t bytes) {
     if (over(want)) want = bytes;
     if (over(want)) (void)trim_idle_contexts(c.device, &c, nullptr);
     if (over(want)) {
+      c.trim_pending = true;  // (what this failing call has already grown is released at the context's next entry)
       set_error("capgpu: this call needs %zu more bytes of device scratch; %zu are in use on device %d and "
                 "capgpu_set_memory_limit allows %zu (prove in smaller batches, or raise the limit)",
                 want, g_scratch_bytes[(size_t)c.device & 63].load(), c.device, limit);

@@ -125,6 +125,9 @@ struct Context {
   Profiler prof;
   LaunchError lerr;
   int depth = 0;  // nesting of entry points on this context (Entry)
+  // a call on this context failed against capgpu_set_memory_limit and left buffers sized for it behind: the next outermost
+  // entry releases the context's scratch first, so that a smaller call finds the room the failed one was refused
+  bool trim_pending = false;
   std::recursive_mutex mu;
 };
 
@@ -170,12 +173,16 @@ struct ScopedCtx {
 // behind by a call that returned early is never reported by the next one (entry points call each other: the latch
 // survives the inner calls of one outer call).
 int& thread_entry_depth();  // context locks the calling thread holds through Entry
+void context_trim_if_pending(Context& c);  // capgpu.hip; called with c.mu held and no call in progress on c
 struct Entry {
   Context& c;
   explicit Entry(Context& c_) : c(c_) {
     c.mu.lock();
     thread_entry_depth()++;
-    if (c.depth++ == 0) c.lerr = LaunchError{};
+    if (c.depth++ == 0) {
+      c.lerr = LaunchError{};
+      if (c.trim_pending) context_trim_if_pending(c);
+    }
   }
   ~Entry() {
     c.depth--;
