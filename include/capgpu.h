@@ -140,7 +140,8 @@ int capgpu_mem_info(uint64_t* free_bytes_out, uint64_t* total_bytes_out);
  *  - capgpu_set_memory_limit caps the scratch the library holds PER DEVICE (sum over that device's contexts; 0 = no
  *    cap, the default).  A call that would grow past it first takes the growth slack off, then trims the device's idle
  *    contexts, and then fails with CAPGPU_ERR_OOM naming the bytes it needed - the caller proves in smaller batches
- *    (scratch is proportional to the batch) or raises the cap.  Scratch already held above a new cap is trimmed from
+ *    (scratch is proportional to the batch; what the failed call had already grown is released at its context's next
+ *    entry) or raises the cap.  Scratch already held above a new cap is trimmed from
  *    idle contexts at once.  Tables are not counted.
  *  - capgpu_scratch_info: scratch bytes currently held on the calling thread's device, and the cap. */
 int capgpu_trim(uint64_t* bytes_released_out, int* contexts_busy_out);
