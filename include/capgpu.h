@@ -103,7 +103,7 @@ extern "C" {
  * A device may be listed once (CAPGPU_ERR_INVALID_ARG otherwise; CAPGPU_ALLOW_DUPLICATE_DEVICES=1 lifts this for tests
  * that drive the multi-device paths on one GPU).  CAPGPU_CONTEXTS_PER_DEVICE=k gives every listed device k contexts,
  * whose batches overlap on that device; the default is 4 when ONE device is bound (capgpu_device_count then reports 4:
- * a host-buffer batch is cut in two, gathered batches of coalesced calls use all four) and 1 per device otherwise.  One process per GPU (torchrun) keeps working: each process binds one device
+ * a host-buffer batch is cut in two, gathered batches of coalesced calls take any free one, two parts at a time) and 1 per device otherwise.  One process per GPU (torchrun) keeps working: each process binds one device
  * and the ranks meet through capgpu_comm_* ("multi-GPU" below).  Idempotent: a second call is a no-op. */
 int capgpu_init(const int* device_ids, int n_devices);
 /* number of device CONTEXTS bound by capgpu_init (0 before it): the range of capgpu_set_device's slots.  NOT a GPU
